@@ -1,0 +1,209 @@
+"""Host-side graph containers and the seeded synthetic cell-graph generator.
+
+Mirrors the slice of the torch_geometric data API that the reference's hot path
+and training loop touch:
+
+* ``Data(x, pos, y, edge_index, patch_idx)``        -- dataflow/data.py:330-354 builds these
+* ``Batch.from_data_list`` (node-offset concat + sorted ``batch`` vector)
+                                                     -- consumed at model/network.py:239-240
+* ``DataListLoader`` (a DataLoader whose collate is the identity: yields python lists of Data)
+                                                     -- train.py:52,175 iterate it
+* ``radius_graph(pos, r, batch, loop, max_num_neighbors)``
+                                                     -- dataflow/data.py:348, prepare_cv_dataset.py:102
+
+Nothing here runs on the GPU; the device-side structure (CSR etc.) is built in graph.py.
+"""
+import numpy as np
+import torch
+from scipy.spatial import cKDTree
+
+
+class Data(object):
+    """Attribute bag with the torch_geometric ``Data`` surface the reference uses."""
+
+    def __init__(self, x=None, edge_index=None, y=None, pos=None, **kwargs):
+        self.x, self.edge_index, self.y, self.pos = x, edge_index, y, pos
+        for k, v in kwargs.items():
+            setattr(self, k, v)
+
+    @property
+    def keys(self):
+        return [k for k, v in self.__dict__.items() if v is not None]
+
+    def __iter__(self):  # dataflow/data.py:344 iterates ``for key, item in data``
+        for k in self.keys:
+            yield k, getattr(self, k)
+
+    def __getitem__(self, k):
+        return getattr(self, k)
+
+    def __setitem__(self, k, v):
+        setattr(self, k, v)
+
+    def __contains__(self, k):
+        return getattr(self, k, None) is not None
+
+    @property
+    def num_nodes(self):
+        return self.x.shape[0] if self.x is not None else self.pos.shape[0]
+
+    @property
+    def num_edges(self):
+        return self.edge_index.shape[1]
+
+    def to(self, device, non_blocking=False):
+        out = self.__class__()
+        for k, v in self:
+            out[k] = v.to(device, non_blocking=non_blocking) if torch.is_tensor(v) else v
+        return out
+
+    def __repr__(self):
+        parts = ['%s=%s' % (k, list(v.shape) if torch.is_tensor(v) else v) for k, v in self]
+        return '%s(%s)' % (self.__class__.__name__, ', '.join(parts))
+
+
+class Batch(Data):
+    """Several graphs as one disconnected graph; ``batch[i]`` = graph id of node i (sorted)."""
+
+    @staticmethod
+    def from_data_list(data_list):
+        out = Batch()
+        keys = data_list[0].keys
+        offset, cat, batch_vec = 0, {k: [] for k in keys}, []
+        for g, d in enumerate(data_list):
+            n = d.num_nodes
+            for k in keys:
+                v = d[k]
+                if k == 'edge_index':
+                    v = v + offset          # cumulative node offset
+                cat[k].append(v)
+            batch_vec.append(torch.full((n,), g, dtype=torch.long))
+            offset += n
+        for k in keys:
+            if torch.is_tensor(cat[k][0]):
+                out[k] = torch.cat(cat[k], dim=1 if k == 'edge_index' else 0)
+            else:
+                out[k] = cat[k]
+        out.batch = torch.cat(batch_vec)
+        out.num_graphs = len(data_list)
+        out._node_counts = [d.num_nodes for d in data_list]   # host-side: lets graph.py skip a device sync
+        return out
+
+
+def _identity_collate(items):
+    return items
+
+
+class DataListLoader(torch.utils.data.DataLoader):
+    """Yields python lists of ``Data`` (train.py:52 ``Batch.from_data_list(data)`` expects that)."""
+
+    def __init__(self, dataset, batch_size=1, shuffle=False, **kwargs):
+        kwargs.pop('collate_fn', None)
+        super().__init__(dataset, batch_size, shuffle, collate_fn=_identity_collate, **kwargs)
+
+
+def radius_graph(pos, r, batch=None, loop=False, max_num_neighbors=32):
+    """k-nearest (k = max_num_neighbors, + self) within radius r; rows ascending.
+
+    Semantics of torch_cluster 1.4.2's CPU path (cKDTree.query with
+    distance_upper_bound = r + 1e-8), SURVEY B.5.  Returns int64 [2, nnz] with
+    row = query / aggregating centre and col = neighbour.
+    """
+    if batch is not None:
+        raise NotImplementedError('per-graph construction only (as the reference calls it: batch=None)')
+    p = pos.detach().cpu().numpy().astype(np.float64)
+    tree = cKDTree(p)
+    k = max_num_neighbors + 1
+    _, col = tree.query(p, k=k, distance_upper_bound=r + 1e-8)
+    col = col.reshape(p.shape[0], k)
+    row = np.repeat(np.arange(p.shape[0]), k).reshape(p.shape[0], k)
+    keep = col < tree.n
+    if not loop:
+        keep &= col != row
+    return torch.from_numpy(np.stack([row[keep], col[keep]]).astype(np.int64))
+
+
+class SyntheticCellGraphs(torch.utils.data.Dataset):
+    """Seeded synthetic cell graphs.
+
+    graph g (seed = base_seed + g): N_g ~ U{0.8 N .. 1.2 N}; positions uniform in a square of side
+    sqrt(N_g * 1784) px (real nucleus density); edges = <= 8 nearest within 100 px + self loop;
+    x ~ N(0,1)^F (stands for z-scored features, dataflow/data.py:353); y ~ U{0..classes-1}.
+    ``fuse_from`` > 0 draws that many candidate nuclei first and keeps N_g of them with the
+    reference's 'fuse' sampler (70 % farthest-point + 30 % random, dataflow/data.py:210-219).
+    """
+
+    def __init__(self, num_graphs, mean_nodes, num_features=16, num_classes=3, base_seed=0,
+                 radius=100.0, max_neighbours=8, density_px2=1784.0, fuse_from=0):
+        self.num_graphs, self.mean_nodes, self.num_features = num_graphs, mean_nodes, num_features
+        self.num_classes, self.base_seed, self.radius = num_classes, base_seed, radius
+        self.max_neighbours, self.density_px2, self.fuse_from = max_neighbours, density_px2, fuse_from
+        self.idxlist = ['synthetic_%06d.pt' % i for i in range(num_graphs)]
+        self.epoch = self.val_epoch = 0
+
+    def set_epoch(self, epoch):       # train.py:173
+        self.epoch = epoch
+
+    def set_val_epoch(self, epoch):   # train.py:36
+        self.val_epoch = epoch
+
+    def __len__(self):
+        return self.num_graphs
+
+    def __getitem__(self, idx):
+        rng = np.random.RandomState(self.base_seed + idx)
+        lo, hi = int(round(0.8 * self.mean_nodes)), int(round(1.2 * self.mean_nodes))
+        n = int(rng.randint(lo, hi + 1))
+        if self.fuse_from > 0:
+            cand = max(self.fuse_from, n)
+            side = np.sqrt(cand * self.density_px2 / 2.0)  # candidates are 2x denser; sampling restores density
+            allpos = rng.uniform(0.0, side, size=(cand, 2))
+            keep = fuse_sample(allpos, n, rng)
+            pos = allpos[keep]
+        else:
+            side = np.sqrt(n * self.density_px2)
+            pos = rng.uniform(0.0, side, size=(n, 2))
+        pos = torch.from_numpy(pos.astype(np.float32))
+        x = torch.from_numpy(rng.standard_normal((n, self.num_features)).astype(np.float32))
+        y = torch.tensor([int(rng.randint(0, self.num_classes))], dtype=torch.long)
+        edge_index = radius_graph(pos, self.radius, None, True, self.max_neighbours)
+        return Data(x=x, pos=pos, y=y, edge_index=edge_index, patch_idx=torch.tensor([idx]))
+
+
+def fuse_sample(pos, k, rng, farthest_frac=0.7):
+    """'fuse' node sampler: 70 % farthest-point + 30 % uniform random from the rest.
+
+    dataflow/data.py:210-219 with common/utils.py:187-203 (FarthestSampler on the distance table);
+    here distances come from coordinates directly.
+    """
+    n = pos.shape[0]
+    kf = int(k * farthest_frac)
+    chosen = np.empty(kf, dtype=np.int64)
+    dist = np.full(n, np.inf)
+    cur = int(rng.randint(n))
+    for i in range(kf):
+        chosen[i] = cur
+        d = ((pos - pos[cur]) ** 2).sum(1)
+        dist = np.minimum(dist, d)
+        cur = int(dist.argmax())
+    rest = np.setdiff1d(np.arange(n), chosen)
+    extra = rng.choice(rest, size=k - kf, replace=False)
+    return np.sort(np.concatenate([chosen, extra]))
+
+
+def partition_by_nodes(data_list, num_parts):
+    """Contiguous split of a list of Data into <= num_parts chunks balanced by cumulative node count.
+
+    The rule of torch_geometric.nn.DataParallel.scatter: a graph goes to chunk
+    floor(num_parts * m / total) where m is the midpoint of its interval on the cumulative
+    node-count axis; empty chunks are dropped (so fewer than num_parts chunks may come back).
+    """
+    num_parts = min(num_parts, len(data_list))
+    counts = torch.tensor([d.num_nodes for d in data_list], dtype=torch.float64)
+    cum = torch.cat([counts.new_zeros(1), counts.cumsum(0)])
+    mid = (cum[:-1] + cum[1:]) / 2.0
+    part = (num_parts * mid / cum[-1].item()).long().clamp(0, num_parts - 1)
+    chunks = [[] for _ in range(num_parts)]
+    for d, p in zip(data_list, part.tolist()):
+        chunks[p].append(d)
+    return [c for c in chunks if c]

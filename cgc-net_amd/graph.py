@@ -1,0 +1,78 @@
+"""Device-side structure of one batch of cell graphs at level 1 (replaces the reference's dense
+``[B, Nmax, Nmax]`` adjacency, model/utils.py:3-36 / model/network.py:237-243).
+
+Layout in HBM (all int32 / fp32, contiguous):
+  rowptr[n+1], col[cap]            CSR, row = aggregating centre, columns sorted, duplicates collapsed
+  val[cap] or None                 per-edge weight (only after ``_re_norm_adj``; None = all ones)
+  inv_d[n]                         1 / max(rowsum, 1)   (DenseSAGEConv's clamped mean divisor)
+  t_rowptr[n+1], t_col, t_perm     the transpose (for backward); t_perm -> slot in ``val``
+  gptr[B+1]                        first node of each graph; nmax = max nodes per graph (host int)
+n = total real nodes: padding rows of the dense layout are never materialised, their effect on
+BatchNorm statistics and on the max readout is applied analytically (count = B*nmax).
+"""
+import torch
+
+from . import kernels
+
+
+class BatchGraph(object):
+    def __init__(self, n, counts, device):
+        self.n = int(n)
+        self.counts = [int(c) for c in counts]
+        self.B = len(self.counts)
+        self.nmax = max(self.counts) if self.counts else 0
+        ptr = [0]
+        for c in self.counts:
+            ptr.append(ptr[-1] + c)
+        assert ptr[-1] == self.n, 'batch vector and x disagree on the node count'
+        self.gptr_host = ptr
+        self.gptr = torch.tensor(ptr, dtype=torch.int32, device=device)
+        self.val = None
+        self.renorm_p = None
+
+    @property
+    def padded_rows(self):
+        """B * Nmax: the row count the reference's BatchNorm sees at level 1."""
+        return self.B * self.nmax
+
+    @staticmethod
+    def node_counts_of(batch):
+        """Per-graph node counts, from host metadata when the Batch carries it (no device sync)."""
+        counts = getattr(batch, '_node_counts', None)
+        if counts is not None:
+            return list(counts)
+        b = batch.batch
+        num = int(b[-1]) + 1 if b.numel() else 0            # model/utils.py:17
+        return torch.bincount(b, minlength=num).tolist()    # one D2H sync for foreign Batch objects
+
+    @classmethod
+    def from_batch(cls, batch, renorm_p=None):
+        x, edge_index = batch.x, batch.edge_index
+        g = cls(x.shape[0], cls.node_counts_of(batch), x.device)
+        g._build(edge_index.contiguous(), renorm_p)
+        return g
+
+    def _build(self, edge_index, renorm_p):
+        K = kernels.get()
+        s = K.csr_build(edge_index, self.n, add_diag=renorm_p is not None)
+        self.rowptr, self.col, self.rowidx = s['rowptr'], s['col'], s['rowidx']
+        self.t_rowptr, self.t_col, self.t_perm = s['t_rowptr'], s['t_col'], s['t_perm']
+        self.cap = s['cap']
+        if renorm_p is not None:
+            self.renorm_p = float(renorm_p)
+            self.val = torch.empty(max(self.cap, 1), dtype=torch.float32, device=self.col.device)
+            K.edge_renorm(self.rowptr, self.col, self.n, self.renorm_p, self.val)
+        self.inv_d = torch.empty(max(self.n, 1), dtype=torch.float32, device=self.col.device)
+        K.csr_invdeg(self.rowptr, self.val, self.n, self.inv_d)
+
+    @property
+    def nnz(self):
+        return int(self.rowptr[self.n])     # device sync; only for reporting
+
+
+def uniform_ptr(B, C, device, _cache={}):
+    """gptr of B graphs with exactly C nodes each (levels 2 and 3)."""
+    key = (B, C, str(device))
+    if key not in _cache:
+        _cache[key] = torch.arange(0, (B + 1) * C, C, dtype=torch.int32, device=device)
+    return _cache[key]

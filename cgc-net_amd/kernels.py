@@ -1,0 +1,313 @@
+"""Tensor-level front door of ``libcgc_hip.so`` (the C-ABI declared in include/cgc_hip.h).
+
+``KernelSpec`` documents the exact arithmetic of every entry point -- it is the contract that the
+HIP kernels (csrc/*.hip), the op-level checker (oracle/flat_ref.py, tests only) and the autograd
+layer (ops.py) share.  ``HipKernels`` marshals torch tensors to raw device pointers and calls the
+library through ctypes on torch's current HIP stream.  There is exactly one product implementation:
+``get()`` raises if the library cannot be loaded or a tensor is not on the GPU.
+
+All float tensors are fp32, all index tensors int32 unless stated; "ld" = leading dimension in
+elements of a row-major matrix.  Kernels never allocate and never synchronise.
+"""
+import ctypes
+import os
+
+import torch
+
+ACT_CODES = {'identity': 0, 'relu': 1, 'elu': 2, 'leakyrelu': 3}
+L2_EPS = 1e-12       # F.normalize eps
+RENORM_EPS = 1e-15   # model/network.py:8
+
+
+class KernelSpec(object):
+    """Semantics of the kernel entry points (all outputs are caller-allocated ``out`` tensors)."""
+
+    # ------------------------------------------------------------------ graph structure (A1)
+    def csr_build(self, edge_index, n, add_diag):
+        """COO (int64 [2,E], row = aggregating centre) -> CSR + its transpose, both column-sorted.
+
+        Duplicate edges collapse (model/utils.py:28-33 ASSIGNS 1); ``add_diag`` inserts (i,i) for
+        every i (needed by edge_renorm, whose result always has a diagonal).  Returns a dict of
+        int32 tensors: rowptr[n+1], col[cap], rowidx[cap], t_rowptr[n+1], t_col[cap], t_perm[cap]
+        with cap = E (+n); entries at or beyond nnz = rowptr[n] are undefined.  t_col[k] is the
+        source row of transposed slot k and t_perm[k] its slot in the forward arrays.
+        """
+        raise NotImplementedError
+
+    def edge_renorm(self, rowptr, col, n, p, val_out):
+        """Level-1 ``_re_norm_adj`` (model/network.py:183-191) on a 0/1 CSR that holds its diagonal:
+        val[k] = p if col[k]==row else (1/(c+1e-15))*(1-p), c = number of off-diagonal entries of the row."""
+        raise NotImplementedError
+
+    def csr_invdeg(self, rowptr, val, n, out):
+        """out[i] = 1 / max(sum_k val[k] (or the entry count when val is None), 1)  -- DenseSAGEConv's clamp."""
+        raise NotImplementedError
+
+    def spmm(self, rowptr, col, perm, val, pre, post, x, out, n, width):
+        """out[i,:] = post[i] * sum_{k in row i} w_k * pre[col[k]] * x[col[k],:]
+        with w_k = val[perm[k]] / val[k] / 1 and pre/post optional.  x, out: [n, width] contiguous."""
+        raise NotImplementedError
+
+    # ------------------------------------------------------------------ dense contractions (MFMA fp32)
+    def gemm(self, A, B, C, M, N, K, transA, transB, lda, ldb, ldc, alpha=1.0, beta=0.0, bias=None,
+             batch=1, strideA=0, strideB=0, strideC=0, gptr=None, ragged=0, max_ragged=0):
+        """C_b = alpha * op(A_b) op(B_b) + beta * C_b (+ bias[N]),  b = 0..batch-1, row-major.
+
+        op(A) is M x K (stored [M,K] or, transA, [K,M]); op(B) is K x N (stored [K,N] or, transB, [N,K]).
+        Operand b starts at base + b*stride (+ ragged offset).  ragged=1: M_b = gptr[b+1]-gptr[b], A
+        (not transposed) and C advance by gptr[b] rows.  ragged=2: K_b = gptr[b+1]-gptr[b], A (transposed)
+        and B (not transposed) advance by gptr[b] rows.  max_ragged bounds the ragged extent (grid size).
+        """
+        raise NotImplementedError
+
+    def reduce_batch_sum(self, ws, out, parts, numel, beta=0.0):
+        """out[j] = beta*out[j] + sum_s ws[s*numel + j]  (deterministic split-K combine)."""
+        raise NotImplementedError
+
+    # ------------------------------------------------------------------ conv epilogue: L2 norm, activation, BatchNorm (A4, A5)
+    def l2norm_act_stats(self, h, n, F, normalize, act, hn_out, rinv_out, stats_out):
+        """hn = h / max(||h||_2, 1e-12) row-wise (or hn = h), rinv = that reciprocal;
+        stats[0,f] = sum_i act(hn)[i,f], stats[1,f] = sum_i act(hn)[i,f]^2 (None to skip)."""
+        raise NotImplementedError
+
+    def bn_finalize(self, stats, count, eps, momentum, running_mean, running_var, mean_out, istd_out):
+        """mean = s0/count, var = s1/count - mean^2 (biased), istd = rsqrt(var+eps); running stats get
+        momentum updates with the unbiased var*count/(count-1).  ``count`` = B*Nmax INCLUDING the
+        zero padding rows of the dense layout (model/network.py:101-107)."""
+        raise NotImplementedError
+
+    def bn_act_apply(self, hn, n, F, act, mean, istd, gamma, beta, y_out, ldy):
+        """y = (act(hn) - mean) * istd * gamma + beta   (mean None -> y = act(hn))."""
+        raise NotImplementedError
+
+    def bn_bwd_reduce(self, dy, ldy, hn, n, F, act, mean, istd, sums_out):
+        """sums[0,f] = sum_i dy, sums[1,f] = sum_i dy * xhat, xhat = (act(hn)-mean)*istd."""
+        raise NotImplementedError
+
+    def bn_act_l2_bwd(self, dy, ldy, hn, rinv, n, F, act, normalize, mode, mean, istd, gamma, sums, count, dh_out):
+        """Backward of BN o act o l2norm for one row block.
+        mode 2 (batch stats): do = gamma*istd*(dy - s0/count - xhat*s1/count); mode 1 (running stats):
+        do = gamma*istd*dy; mode 0 (no BN): do = dy.   dhn = do*act'(hn);
+        normalize: dh = rinv*(dhn - hn*<hn,dhn>) (dh = dhn*1e12 where the norm clamp was active)."""
+        raise NotImplementedError
+
+    def colsum(self, x, ld, n, F, out):
+        """out[f] = sum_i x[i,f]."""
+        raise NotImplementedError
+
+    # ------------------------------------------------------------------ assignment softmax (A8), readout (A9)
+    def softmax_fwd(self, x, n, C, out):
+        raise NotImplementedError
+
+    def softmax_bwd(self, S, dS, n, C, dx_out):
+        """dx = S * (dS - <dS, S>_row)."""
+        raise NotImplementedError
+
+    def segment_max_fwd(self, x, gptr, B, D, nmax, out, arg_out):
+        """Per graph b and column d: max over its rows (first index on ties); a graph with fewer than
+        nmax rows also competes against the zero padding rows of the dense layout (model/network.py:264):
+        if its max is < 0 the result is 0 and arg = -1."""
+        raise NotImplementedError
+
+    def segment_max_bwd(self, dout, arg, B, D, dx_zeroed):
+        """dx[arg[b,d], d] = dout[b,d] where arg >= 0 (dx arrives zero-filled)."""
+        raise NotImplementedError
+
+    # ------------------------------------------------------------------ dense adjacency ops at levels 2-3 (A4, A6)
+    def dense_rownorm_fwd(self, A, R, C, out, invd_out, ge1_out):
+        """s = rowsum(A); d = max(s,1); out = A/d; invd = 1/d; ge1 = (s >= 1)  (clamp(min=1) of DenseSAGEConv)."""
+        raise NotImplementedError
+
+    def dense_rownorm_bwd(self, dOut, Anorm, invd, ge1, R, C, dA_out):
+        """dA = invd * (dOut - ge1 * <dOut, Anorm>_row)."""
+        raise NotImplementedError
+
+    def dense_renorm_fwd(self, A, R, C, p, out):
+        """``_re_norm_adj`` on [B,C,C] viewed as [R=B*C, C]; the diagonal of row i is column i mod C."""
+        raise NotImplementedError
+
+    def dense_renorm_bwd(self, A, dOut, R, C, p, dA_out):
+        raise NotImplementedError
+
+
+# ----------------------------------------------------------------------------------------------
+_LIB_NAME = 'libcgc_hip.so'
+_instance = None
+
+
+def lib_path():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc', _LIB_NAME)
+
+
+def get():
+    """The process-wide kernel table.  Raises (never falls back) when the HIP library is unusable."""
+    global _instance
+    if _instance is None:
+        _instance = HipKernels()
+    return _instance
+
+
+def is_native():
+    return isinstance(_instance, HipKernels)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr() if t is not None else 0)
+
+
+class HipKernels(KernelSpec):
+    def __init__(self):
+        path = lib_path()
+        if not os.path.exists(path):
+            raise RuntimeError('%s not built: run `python -c "import __graft_entry__ as g; g.build()"` '
+                               '(there is no CPU fallback)' % path)
+        if not torch.cuda.is_available():
+            raise RuntimeError('cgc_net_amd needs an AMD GPU (gfx950); torch.cuda.is_available() is False '
+                               'and there is no CPU fallback')
+        self.lib = ctypes.CDLL(path)
+        from . import _abi
+        _abi.declare(self.lib)
+
+    # -- helpers
+    @staticmethod
+    def _stream():
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    @staticmethod
+    def _chk(rc, name):
+        if rc != 0:
+            raise RuntimeError('%s failed with code %d' % (name, rc))
+
+    @staticmethod
+    def _dev(*ts):
+        for t in ts:
+            if t is not None and not t.is_cuda:
+                raise RuntimeError('cgc_net_amd kernels take GPU tensors only (got a %s tensor)' % t.device)
+
+    # -- graph structure
+    def csr_build(self, edge_index, n, add_diag):
+        self._dev(edge_index)
+        assert edge_index.dtype == torch.int64 and edge_index.is_contiguous()
+        E = edge_index.shape[1]
+        cap = E + (n if add_diag else 0)
+        dev = edge_index.device
+        i32 = dict(dtype=torch.int32, device=dev)
+        out = {k: torch.empty(n + 1, **i32) for k in ('rowptr', 't_rowptr')}
+        out.update({k: torch.empty(max(cap, 1), **i32) for k in ('col', 'rowidx', 't_col', 't_perm')})
+        ws = torch.empty(3 * (n + 1) + 2 * max(cap, 1), **i32)
+        rc = self.lib.cgc_csr_build(_ptr(edge_index), ctypes.c_int64(E), n, int(add_diag),
+                                    _ptr(out['rowptr']), _ptr(out['col']), _ptr(out['rowidx']),
+                                    _ptr(out['t_rowptr']), _ptr(out['t_col']), _ptr(out['t_perm']),
+                                    _ptr(ws), self._stream())
+        self._chk(rc, 'cgc_csr_build')
+        out['cap'] = cap
+        return out
+
+    def edge_renorm(self, rowptr, col, n, p, val_out):
+        self._dev(rowptr, col, val_out)
+        self._chk(self.lib.cgc_edge_renorm(_ptr(rowptr), _ptr(col), n, ctypes.c_float(p), _ptr(val_out),
+                                           self._stream()), 'cgc_edge_renorm')
+
+    def csr_invdeg(self, rowptr, val, n, out):
+        self._dev(rowptr, val, out)
+        self._chk(self.lib.cgc_csr_invdeg(_ptr(rowptr), _ptr(val), n, _ptr(out), self._stream()), 'cgc_csr_invdeg')
+
+    def spmm(self, rowptr, col, perm, val, pre, post, x, out, n, width):
+        self._dev(rowptr, col, perm, val, pre, post, x, out)
+        assert x.is_contiguous() and out.is_contiguous()
+        self._chk(self.lib.cgc_spmm(_ptr(rowptr), _ptr(col), _ptr(perm), _ptr(val), _ptr(pre), _ptr(post),
+                                    _ptr(x), _ptr(out), n, width, self._stream()), 'cgc_spmm')
+
+    # -- dense contractions
+    def gemm(self, A, B, C, M, N, K, transA, transB, lda, ldb, ldc, alpha=1.0, beta=0.0, bias=None,
+             batch=1, strideA=0, strideB=0, strideC=0, gptr=None, ragged=0, max_ragged=0):
+        self._dev(A, B, C, bias, gptr)
+        rc = self.lib.cgc_gemm_f32(int(transA), int(transB), M, N, K, ctypes.c_float(alpha), _ptr(A), lda,
+                                   _ptr(B), ldb, ctypes.c_float(beta), _ptr(C), ldc, _ptr(bias), batch,
+                                   ctypes.c_int64(strideA), ctypes.c_int64(strideB), ctypes.c_int64(strideC),
+                                   _ptr(gptr), ragged, max_ragged, self._stream())
+        self._chk(rc, 'cgc_gemm_f32')
+
+    def reduce_batch_sum(self, ws, out, parts, numel, beta=0.0):
+        self._dev(ws, out)
+        self._chk(self.lib.cgc_reduce_batch_sum(_ptr(ws), _ptr(out), parts, ctypes.c_int64(numel),
+                                                ctypes.c_float(beta), self._stream()), 'cgc_reduce_batch_sum')
+
+    # -- conv epilogue
+    def l2norm_act_stats(self, h, n, F, normalize, act, hn_out, rinv_out, stats_out):
+        self._dev(h, hn_out, rinv_out, stats_out)
+        nblk = self.lib.cgc_stats_blocks(n, F)
+        ws = torch.empty(max(nblk, 1) * 2 * F, dtype=torch.float32, device=h.device) if stats_out is not None else None
+        self._chk(self.lib.cgc_l2norm_act_stats(_ptr(h), n, F, int(normalize), act, _ptr(hn_out), _ptr(rinv_out),
+                                                _ptr(stats_out), _ptr(ws), self._stream()), 'cgc_l2norm_act_stats')
+
+    def bn_finalize(self, stats, count, eps, momentum, running_mean, running_var, mean_out, istd_out):
+        self._dev(stats, running_mean, running_var, mean_out, istd_out)
+        F = mean_out.numel()
+        self._chk(self.lib.cgc_bn_finalize(_ptr(stats), F, ctypes.c_double(count), ctypes.c_float(eps),
+                                           ctypes.c_float(momentum), _ptr(running_mean), _ptr(running_var),
+                                           _ptr(mean_out), _ptr(istd_out), self._stream()), 'cgc_bn_finalize')
+
+    def bn_act_apply(self, hn, n, F, act, mean, istd, gamma, beta, y_out, ldy):
+        self._dev(hn, mean, istd, gamma, beta, y_out)
+        self._chk(self.lib.cgc_bn_act_apply(_ptr(hn), n, F, act, _ptr(mean), _ptr(istd), _ptr(gamma), _ptr(beta),
+                                            _ptr(y_out), ldy, self._stream()), 'cgc_bn_act_apply')
+
+    def bn_bwd_reduce(self, dy, ldy, hn, n, F, act, mean, istd, sums_out):
+        self._dev(dy, hn, mean, istd, sums_out)
+        nblk = self.lib.cgc_stats_blocks(n, F)
+        ws = torch.empty(max(nblk, 1) * 2 * F, dtype=torch.float32, device=hn.device)
+        self._chk(self.lib.cgc_bn_bwd_reduce(_ptr(dy), ldy, _ptr(hn), n, F, act, _ptr(mean), _ptr(istd),
+                                             _ptr(sums_out), _ptr(ws), self._stream()), 'cgc_bn_bwd_reduce')
+
+    def bn_act_l2_bwd(self, dy, ldy, hn, rinv, n, F, act, normalize, mode, mean, istd, gamma, sums, count, dh_out):
+        self._dev(dy, hn, rinv, mean, istd, gamma, sums, dh_out)
+        self._chk(self.lib.cgc_bn_act_l2_bwd(_ptr(dy), ldy, _ptr(hn), _ptr(rinv), n, F, act, int(normalize), mode,
+                                             _ptr(mean), _ptr(istd), _ptr(gamma), _ptr(sums),
+                                             ctypes.c_double(count), _ptr(dh_out), self._stream()), 'cgc_bn_act_l2_bwd')
+
+    def colsum(self, x, ld, n, F, out):
+        self._dev(x, out)
+        nblk = self.lib.cgc_stats_blocks(n, F)
+        ws = torch.empty(max(nblk, 1) * 2 * F, dtype=torch.float32, device=x.device)
+        self._chk(self.lib.cgc_colsum(_ptr(x), ld, n, F, _ptr(out), _ptr(ws), self._stream()), 'cgc_colsum')
+
+    # -- softmax / readout
+    def softmax_fwd(self, x, n, C, out):
+        self._dev(x, out)
+        self._chk(self.lib.cgc_softmax_fwd(_ptr(x), n, C, _ptr(out), self._stream()), 'cgc_softmax_fwd')
+
+    def softmax_bwd(self, S, dS, n, C, dx_out):
+        self._dev(S, dS, dx_out)
+        self._chk(self.lib.cgc_softmax_bwd(_ptr(S), _ptr(dS), n, C, _ptr(dx_out), self._stream()), 'cgc_softmax_bwd')
+
+    def segment_max_fwd(self, x, gptr, B, D, nmax, out, arg_out):
+        self._dev(x, gptr, out, arg_out)
+        self._chk(self.lib.cgc_segment_max_fwd(_ptr(x), _ptr(gptr), B, D, nmax, _ptr(out), _ptr(arg_out),
+                                               self._stream()), 'cgc_segment_max_fwd')
+
+    def segment_max_bwd(self, dout, arg, B, D, dx_zeroed):
+        self._dev(dout, arg, dx_zeroed)
+        self._chk(self.lib.cgc_segment_max_bwd(_ptr(dout), _ptr(arg), B, D, _ptr(dx_zeroed), self._stream()),
+                  'cgc_segment_max_bwd')
+
+    # -- dense adjacency ops
+    def dense_rownorm_fwd(self, A, R, C, out, invd_out, ge1_out):
+        self._dev(A, out, invd_out, ge1_out)
+        self._chk(self.lib.cgc_dense_rownorm_fwd(_ptr(A), R, C, _ptr(out), _ptr(invd_out), _ptr(ge1_out),
+                                                 self._stream()), 'cgc_dense_rownorm_fwd')
+
+    def dense_rownorm_bwd(self, dOut, Anorm, invd, ge1, R, C, dA_out):
+        self._dev(dOut, Anorm, invd, ge1, dA_out)
+        self._chk(self.lib.cgc_dense_rownorm_bwd(_ptr(dOut), _ptr(Anorm), _ptr(invd), _ptr(ge1), R, C, _ptr(dA_out),
+                                                 self._stream()), 'cgc_dense_rownorm_bwd')
+
+    def dense_renorm_fwd(self, A, R, C, p, out):
+        self._dev(A, out)
+        self._chk(self.lib.cgc_dense_renorm_fwd(_ptr(A), R, C, ctypes.c_float(p), _ptr(out), self._stream()),
+                  'cgc_dense_renorm_fwd')
+
+    def dense_renorm_bwd(self, A, dOut, R, C, p, dA_out):
+        self._dev(A, dOut, dA_out)
+        self._chk(self.lib.cgc_dense_renorm_bwd(_ptr(A), _ptr(dOut), R, C, ctypes.c_float(p), _ptr(dA_out),
+                                                self._stream()), 'cgc_dense_renorm_bwd')

@@ -1,0 +1,361 @@
+"""nn.Module surface of the hot path -- same class names, constructor signatures, forward contracts
+and state_dict keys as the reference's ``model/network.py`` (so that ``train.py:178-183`` and a
+reference checkpoint work unchanged), with the arithmetic scheduled onto the HIP kernels (ops.py).
+
+What differs from the reference, by design:
+* level 1 never builds the dense ``[B, Nmax, Nmax]`` adjacency (model/network.py:237-243): the batch is
+  kept flat (``[Ntot, F]`` rows + CSR, graph.py); masks are implicit; the effect of the zero padding rows
+  on BatchNorm statistics (model/network.py:101-107) and on the max readout (:264) is applied analytically.
+* ``(S^T A) S`` is evaluated as ``S^T (A S)`` with ``A S`` a sparse product (model/network.py:207).
+* no ``.cuda()`` calls inside the model: it runs on the device its parameters live on.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .graph import BatchGraph, uniform_ptr
+
+EPS = 1e-15
+RENORM_P = 0.4      # model/network.py:260,271,280
+
+
+def _activation_module(name):
+    assert name in ('relu', 'elu', 'leakyrelu')          # model/network.py:84-91
+    return {'relu': nn.ReLU, 'elu': nn.ELU, 'leakyrelu': nn.LeakyReLU}[name](inplace=True)
+
+
+# ------------------------------------------------------------------------------------------------
+# operators (torch_geometric 1.2.1 signatures)
+# ------------------------------------------------------------------------------------------------
+class DenseSAGEConv(nn.Module):
+    """``DenseSAGEConv(in, out, normalize=True, bias=True)``; weight is [in, out] as in PyG."""
+
+    def __init__(self, in_channels, out_channels, normalize=True, bias=True):
+        super().__init__()
+        self.in_channels, self.out_channels, self.normalize = in_channels, out_channels, normalize
+        self.weight = nn.Parameter(torch.empty(in_channels, out_channels))
+        if bias:
+            self.bias = nn.Parameter(torch.empty(out_channels))
+        else:
+            self.register_parameter('bias', None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        bound = 1.0 / math.sqrt(self.in_channels)
+        with torch.no_grad():
+            self.weight.uniform_(-bound, bound)
+            if self.bias is not None:
+                self.bias.uniform_(-bound, bound)
+
+    def project(self, agg):
+        """[rows, in] aggregated features -> [rows, out]: linear (+bias); the caller applies l2/act/BN."""
+        return ops.linear_bias(agg, self.weight, self.bias, out_in_layout=False)
+
+    def forward(self, x, adj, mask=None, add_loop=True):
+        x = x.unsqueeze(0) if x.dim() == 2 else x
+        adj = adj.unsqueeze(0) if adj.dim() == 2 else adj
+        B, N, _ = x.shape
+        if add_loop:
+            adj = adj.clone()
+            idx = torch.arange(N, device=adj.device)
+            adj[:, idx, idx] = 1
+        agg = ops.bmatmul(ops.rownorm_clamp(adj), x)
+        out = self.project(agg.reshape(B * N, -1))
+        if self.normalize:
+            out = ops.l2_act_bn(out, None, B * N, 'identity', True, self.training)
+        out = out.view(B, N, -1)
+        if mask is not None:
+            out = out * mask.view(B, N, 1).to(out.dtype)
+        return out
+
+    def __repr__(self):
+        return '%s(%d, %d)' % (self.__class__.__name__, self.in_channels, self.out_channels)
+
+
+class DenseGINConv(nn.Module):
+    """``DenseGINConv(nn, eps=0)``: nn(adj @ x [+ (1+eps) x]); the MLP's Linear layers run on the HIP GEMM."""
+
+    def __init__(self, nn_module, eps=0.0):
+        super().__init__()
+        self.nn = nn_module
+        self.register_buffer('eps', torch.tensor([float(eps)]))
+
+    def mlp(self, h):
+        for layer in self.nn:
+            if isinstance(layer, nn.Linear):
+                h = ops.linear_bias(h, layer.weight, layer.bias, out_in_layout=True)
+            elif isinstance(layer, nn.ReLU):
+                h = ops.l2_act_bn(h, None, h.shape[0], 'relu', False, self.training)
+            elif isinstance(layer, nn.ELU):
+                h = ops.l2_act_bn(h, None, h.shape[0], 'elu', False, self.training)
+            elif isinstance(layer, nn.LeakyReLU):
+                h = ops.l2_act_bn(h, None, h.shape[0], 'leakyrelu', False, self.training)
+            else:
+                raise NotImplementedError(type(layer))
+        return h
+
+    def forward(self, x, adj, mask=None, add_loop=True):
+        x = x.unsqueeze(0) if x.dim() == 2 else x
+        adj = adj.unsqueeze(0) if adj.dim() == 2 else adj
+        B, N, _ = x.shape
+        out = ops.bmatmul(adj, x)
+        if add_loop:
+            out = (1 + float(self.eps)) * x + out
+        out = self.mlp(out.reshape(B * N, -1)).view(B, N, -1)
+        if mask is not None:
+            out = out * mask.view(B, N, 1).to(out.dtype)
+        return out
+
+
+# ------------------------------------------------------------------------------------------------
+class DenseJK(nn.Module):
+    """LSTM-attention jumping knowledge over a block's three layer outputs (model/network.py:11-55).
+    The recurrence stays on torch.nn.LSTM (MIOpen): SURVEY A7."""
+
+    def __init__(self, mode, channels=None, num_layers=None):
+        super().__init__()
+        self.channel = channels
+        self.mode = mode.lower()
+        assert self.mode in ['cat', 'max', 'lstm']
+        if self.mode == 'lstm':
+            assert channels is not None and num_layers is not None
+            self.lstm = nn.LSTM(channels, channels * num_layers // 2, bidirectional=True, batch_first=True)
+            self.att = nn.Linear(2 * channels * num_layers // 2, 1)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        if hasattr(self, 'lstm'):
+            self.lstm.reset_parameters()
+        if hasattr(self, 'att'):
+            self.att.reset_parameters()
+
+    def forward(self, xs):
+        """[..., layers*channels] -> [..., channels]; works on [B, N, 3C] and on flat [Ntot, 3C] rows alike."""
+        lead = xs.shape[:-1]
+        seq = xs.reshape(-1, xs.shape[-1] // self.channel, self.channel)   # [rows, layers, channels]
+        alpha, _ = self.lstm(seq)
+        alpha = torch.softmax(self.att(alpha).squeeze(-1), dim=-1)
+        return (seq * alpha.unsqueeze(-1)).sum(dim=1).reshape(*lead, self.channel)
+
+    def __repr__(self):
+        return '{}({})'.format(self.__class__.__name__, self.mode)
+
+
+# ------------------------------------------------------------------------------------------------
+class GNN_Module(nn.Module):
+    """Three convolutions, each followed by activation THEN BatchNorm, concatenated; optional Linear
+    (model/network.py:57-125)."""
+
+    def __init__(self, input_dim, hidden_dim, embedding_dim, bias, bn, add_loop, lin=True, gcn_name='SAGE',
+                 sync=False, activation='relu', jk=False):
+        super().__init__()
+        if sync:
+            raise NotImplementedError('sync BatchNorm: the reference path creates only bn1 and cannot run '
+                                      '(SURVEY Appendix C.4)')
+        self.jk, self.add_loop, self.gcn_name, self.activation = jk, add_loop, gcn_name, activation
+        self.gcn1 = self._gcn(gcn_name, input_dim, hidden_dim, bias, activation)
+        self.active1 = _activation_module(activation)
+        self.gcn2 = self._gcn(gcn_name, hidden_dim, hidden_dim, bias, activation)
+        self.active2 = _activation_module(activation)
+        self.gcn3 = self._gcn(gcn_name, hidden_dim, embedding_dim, bias, activation)
+        self.active3 = _activation_module(activation)
+        self.use_bn = bool(bn)
+        if bn:
+            self.bn1 = nn.BatchNorm1d(hidden_dim)
+            self.bn2 = nn.BatchNorm1d(hidden_dim)
+            self.bn3 = nn.BatchNorm1d(embedding_dim)
+        self.lin = nn.Linear(2 * hidden_dim + embedding_dim, embedding_dim) if lin is True else None
+
+    @staticmethod
+    def _gcn(name, input_dim, hidden_dim, bias, activation='relu'):
+        if name == 'SAGE':
+            return DenseSAGEConv(input_dim, hidden_dim, normalize=True, bias=bias)
+        nn1 = nn.Sequential(nn.Linear(input_dim, hidden_dim), _activation_module(activation),
+                            nn.Linear(hidden_dim, hidden_dim))
+        return DenseGINConv(nn1)
+
+    @property
+    def mean_aggregation(self):
+        return self.gcn_name == 'SAGE'
+
+    # -- core: rows are nodes; `aggregate` maps [rows, F] -> [rows, F]; `count` = rows the BatchNorm of the
+    #    dense layout would see (B*Nmax); `row_mask` only for the dense API with padded rows.
+    def run_rows(self, x, aggregate, count, agg0=None, row_mask=None):
+        outs, h = [], x
+        for k in (1, 2, 3):
+            conv = getattr(self, 'gcn%d' % k)
+            bn = getattr(self, 'bn%d' % k) if self.use_bn else None
+            agg = agg0 if (k == 1 and agg0 is not None) else aggregate(h)
+            if self.mean_aggregation:
+                z, normalize = conv.project(agg), conv.normalize
+            else:
+                if self.add_loop:
+                    agg = agg + (1 + float(conv.eps)) * h
+                z, normalize = conv.mlp(agg), False
+            if row_mask is None:
+                h = ops.l2_act_bn(z, bn, count, self.activation, normalize, self.training)
+            else:   # padded dense layout: conv output is masked BEFORE activation/BN (model/network.py:114)
+                if normalize:
+                    z = ops.l2_act_bn(z, None, count, 'identity', True, self.training)
+                h = ops.l2_act_bn(z * row_mask, bn, count, self.activation, False, self.training)
+            outs.append(h)
+        h = torch.cat(outs, dim=-1)
+        if row_mask is not None:
+            h = h * row_mask
+        if self.lin is not None:
+            h = ops.linear_bias(h, self.lin.weight, self.lin.bias, out_in_layout=True)
+            if row_mask is not None:
+                h = h * row_mask
+        return h
+
+    def forward_graph(self, x, g, agg0=None):
+        """Level-1 path on flat rows + CSR (``g``: graph.BatchGraph).  Returns [Ntot, width]."""
+        mean = self.mean_aggregation
+        return self.run_rows(x, lambda h: ops.aggregate(h, g, mean), g.padded_rows, agg0)
+
+    def forward(self, x, adj, mask=None):
+        """Dense-tensor contract of the reference: x [B,N,F], adj [B,N,N], mask [B,N,1] or None."""
+        B, N, _ = x.shape
+        if self.add_loop and self.mean_aggregation:
+            adj = adj.clone()
+            idx = torch.arange(N, device=adj.device)
+            adj[:, idx, idx] = 1
+        a = ops.rownorm_clamp(adj) if self.mean_aggregation else adj
+        row_mask = mask.reshape(B * N, 1).to(x.dtype) if mask is not None else None
+        out = self.run_rows(x.reshape(B * N, -1), lambda h: ops.bmatmul(a, h.view(B, N, -1)).view(B * N, -1),
+                            B * N, None, row_mask)
+        return out.view(B, N, -1)
+
+
+# ------------------------------------------------------------------------------------------------
+class SoftPoolingGcnEncoder(nn.Module):
+    """model/network.py:127-291.  ``forward(data)`` takes a Batch-like object (``.x .edge_index .batch .y``)
+    when ``load_data_sparse`` else the tuple ``(x[B,N,F], adj[B,N,N], num_nodes[B][, label])``; returns
+    ``(logits, loss)`` in training mode and ``logits`` in eval mode."""
+
+    def __init__(self, max_num_nodes, input_dim, hidden_dim, embedding_dim, bias, bn, assign_hidden_dim, label_dim,
+                 assign_ratio=0.25, pred_hidden_dims=[50], concat=True, gcn_name='SAGE',
+                 collect_assign=False, load_data_sparse=False, norm_adj=False,
+                 activation='relu', drop_out=0., jk=False):
+        super().__init__()
+        self.jk, self.drop_out, self.norm_adj = jk, drop_out, norm_adj
+        self.load_data_sparse, self.collect_assign = load_data_sparse, collect_assign
+        self.assign_matrix = []
+        kw = dict(add_loop=False, gcn_name=gcn_name, activation=activation, jk=jk)
+        assign_dim = int(max_num_nodes * assign_ratio)
+        self.GCN_embed_1 = GNN_Module(input_dim, hidden_dim, embedding_dim, bias, bn, lin=False, **kw)
+        if jk:
+            self.jk1 = DenseJK('lstm', hidden_dim, 3)
+        self.GCN_pool_1 = GNN_Module(input_dim, assign_hidden_dim, assign_dim, bias, bn, **kw)
+        if concat and not jk:
+            input_dim = hidden_dim * 2 + embedding_dim
+        else:
+            input_dim = embedding_dim
+        assign_dim = int(assign_dim * assign_ratio)
+        self.GCN_embed_2 = GNN_Module(input_dim, hidden_dim, embedding_dim, bias, bn, lin=False, **kw)
+        if jk:
+            self.jk2 = DenseJK('lstm', hidden_dim, 3)
+        self.GCN_pool_2 = GNN_Module(input_dim, assign_hidden_dim, assign_dim, bias, bn, **kw)
+        self.GCN_embed_3 = GNN_Module(input_dim, hidden_dim, embedding_dim, bias, bn, lin=False, **kw)
+        if jk:
+            self.jk3 = DenseJK('lstm', hidden_dim, 3)
+        self.pred_model = self.build_readout_module(input_dim * 3, pred_hidden_dims, label_dim, activation)
+        self.last_graph = None
+
+    def build_readout_module(self, pred_input_dim, pred_hidden_dims, label_dim, activation):
+        if len(pred_hidden_dims) == 0:
+            return nn.Linear(pred_input_dim, label_dim)
+        layers = []
+        for pred_dim in pred_hidden_dims:
+            layers += [nn.Linear(pred_input_dim, pred_dim), _activation_module(activation)]
+            pred_input_dim = pred_dim
+            if self.drop_out > 0:
+                layers.append(nn.Dropout(self.drop_out))
+        layers.append(nn.Linear(pred_dim, label_dim))
+        return nn.Sequential(*layers)
+
+    # -- inputs --------------------------------------------------------------------------------
+    class _Flat(object):
+        pass
+
+    def _flat_from_dense(self, x, adj, num_nodes):
+        """The tuple input form (model/network.py:253-256): 0/1 dense adjacency -> flat rows + edge list."""
+        counts = [int(c) for c in (num_nodes.tolist() if torch.is_tensor(num_nodes) else num_nodes)]
+        B, N, _ = adj.shape
+        dev = x.device
+        cnt = torch.tensor(counts, device=dev)
+        off = torch.cumsum(cnt, 0) - cnt
+        real = torch.arange(N, device=dev).unsqueeze(0) < cnt.unsqueeze(1)         # [B, N]
+        b, r, c = (adj * real.unsqueeze(2).to(adj.dtype)).nonzero(as_tuple=True)   # padded rows carry no edges
+        flat = self._Flat()
+        flat.x = x[real]
+        flat.edge_index = torch.stack([off[b] + r, off[b] + c])
+        flat._node_counts = counts
+        return flat
+
+    # -- stages --------------------------------------------------------------------------------
+    def _level1(self, data):
+        g = BatchGraph.from_batch(data, RENORM_P if self.norm_adj else None)
+        self.last_graph = g
+        x = data.x
+        emb_blk, pool_blk = self.GCN_embed_1, self.GCN_pool_1
+        agg0 = ops.aggregate(x, g, emb_blk.mean_aggregation)     # shared by both blocks' first conv
+        embed = emb_blk.forward_graph(x, g, agg0)
+        if self.jk:
+            embed = self.jk1(embed)
+        readout = ops.segment_max(embed, g.gptr, g.B, g.nmax)
+        s = ops.softmax_rows(pool_blk.forward_graph(x, g, agg0))
+        if self.collect_assign:
+            self.assign_matrix.append(self._pad_assign(s.detach(), g))
+        xn, an = ops.diff_pool_sparse(embed, s, g)
+        return readout, xn, an
+
+    @staticmethod
+    def _pad_assign(s, g):
+        """[Ntot, C] -> the reference's [B, Nmax, C]; its padded rows hold softmax(0) = 1/C."""
+        out = s.new_full((g.B, g.nmax, s.shape[1]), 1.0 / s.shape[1])
+        for b in range(g.B):
+            out[b, :g.counts[b]] = s[g.gptr_host[b]:g.gptr_host[b + 1]]
+        return out
+
+    def _dense_level(self, level, x, adj):
+        B, C, _ = x.shape
+        if self.norm_adj:
+            adj = ops.renorm_dense(adj, RENORM_P)
+        emb_blk = getattr(self, 'GCN_embed_%d' % level)
+        a = ops.rownorm_clamp(adj) if emb_blk.mean_aggregation else adj
+
+        def aggregate(h):
+            return ops.bmatmul(a, h.view(B, C, -1)).view(B * C, -1)
+        xf = x.reshape(B * C, -1)
+        agg0 = aggregate(xf)
+        embed = emb_blk.run_rows(xf, aggregate, B * C, agg0)
+        if self.jk:
+            embed = getattr(self, 'jk%d' % level)(embed)
+        readout = ops.segment_max(embed, uniform_ptr(B, C, x.device), B, C)
+        if level == 3:
+            return readout, None, None
+        s = ops.softmax_rows(getattr(self, 'GCN_pool_%d' % level).run_rows(xf, aggregate, B * C, agg0))
+        if self.collect_assign:
+            self.assign_matrix.append(s.detach().view(B, C, -1))
+        xn, an = ops.diff_pool_dense(embed.view(B, C, -1), adj, s.view(B, C, -1))
+        return readout, xn, an
+
+    def forward(self, data):
+        self.assign_matrix = []
+        if self.load_data_sparse:
+            label = data.y
+        else:
+            label = data[3] if self.training else None
+            data = self._flat_from_dense(data[0], data[1], data[2])
+        out1, x, adj = self._level1(data)
+        out2, x, adj = self._dense_level(2, x, adj)
+        out3, _, _ = self._dense_level(3, x, adj)
+        output = self.pred_model(torch.cat([out1, out2, out3], dim=1))
+        if self.training:
+            cls_loss = F.cross_entropy(output, label.view(-1))
+            return output, cls_loss
+        return output

@@ -1,0 +1,403 @@
+"""Autograd layer: each Function is a forward/backward pair scheduled over the kernel table
+(kernels.py).  No arithmetic happens here -- only buffer allocation (torch caching allocator),
+shape bookkeeping and the order in which C-ABI entry points are launched on the current stream.
+
+Reference arithmetic being re-expressed:
+  aggregate / linear_bias / l2_act_bn   DenseSAGEConv + act + BatchNorm of GNN_Module  (A4, A5; model/network.py:109-125)
+  softmax_rows, diff_pool_*             _diff_pool                                     (A8; model/network.py:194-208)
+  segment_max                           max readout incl. zero padding rows           (A9; model/network.py:264)
+  rownorm_clamp, renorm_dense           clamp(min=1) mean divisor, _re_norm_adj at levels 2-3 (A4, A6)
+"""
+import torch
+from torch.autograd import Function
+
+from . import kernels
+from .kernels import ACT_CODES
+
+
+def K():
+    return kernels.get()
+
+
+def _f32c(t):
+    return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.contiguous().float()
+
+
+def _rows_ld(t):
+    """(tensor, ld) for a 2-D fp32 tensor whose rows are contiguous (e.g. a column slice of a wider one)."""
+    if t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= t.shape[1] and t.dtype == torch.float32:
+        return t, t.stride(0)
+    t = _f32c(t)
+    return t, t.shape[-1]
+
+
+# ----------------------------------------------------------------------------------------------
+# split-K helper for the tall-skinny "weight gradient" contractions  out[Fa,Fb] = A[n,Fa]^T B[n,Fb]
+# ----------------------------------------------------------------------------------------------
+_SPLIT_CACHE = {}
+
+
+def _split_ptr(n, parts, device):
+    key = (n, parts, str(device))
+    if key not in _SPLIT_CACHE:
+        chunk = -(-n // parts)
+        chunk = -(-chunk // 32) * 32
+        ptr = [min(i * chunk, n) for i in range(parts + 1)]
+        _SPLIT_CACHE[key] = (torch.tensor(ptr, dtype=torch.int32, device=device), chunk)
+    return _SPLIT_CACHE[key]
+
+
+def gemm_tn_rows(A, lda, Fa, B, ldb, Fb, n, out, ldc=None, beta=0.0):
+    """out[Fa,Fb] (ld ldc) = beta*out + A[:n,:Fa]^T @ B[:n,:Fb]; rows split over workgroups, combined deterministically."""
+    ldc = Fb if ldc is None else ldc
+    tiles = (-(-Fa // 128)) * (-(-Fb // 128))
+    parts = max(1, min(-(-1024 // tiles), -(-n // 512)))
+    if parts == 1 or ldc != Fb:
+        # (strided destinations take the direct path; they only occur for small slices)
+        K().gemm(A, B, out, Fa, Fb, n, True, False, lda, ldb, ldc, 1.0, beta)
+        return
+    ptr, chunk = _split_ptr(n, parts, A.device)
+    ws = torch.empty(parts, Fa * Fb, dtype=torch.float32, device=A.device)
+    K().gemm(A, B, ws, Fa, Fb, 0, True, False, lda, ldb, Fb, 1.0, 0.0, None,
+             parts, 0, 0, Fa * Fb, ptr, 2, chunk)
+    K().reduce_batch_sum(ws, out, parts, Fa * Fb, beta)
+
+
+# ----------------------------------------------------------------------------------------------
+# level-1 neighbour aggregation on the CSR (K1 narrow / K4 wide SpMM)
+# ----------------------------------------------------------------------------------------------
+class _Aggregate(Function):
+    @staticmethod
+    def forward(ctx, x, g, mean):
+        x = _f32c(x)
+        out = torch.empty_like(x)
+        K().spmm(g.rowptr, g.col, None, g.val, None, g.inv_d if mean else None, x, out, g.n, x.shape[1])
+        ctx.g, ctx.mean = g, mean
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        g = ctx.g
+        dy = _f32c(dy)
+        dx = torch.empty_like(dy)
+        # transpose aggregation: dx[j] = sum_i w_ij * inv_d[i] * dy[i]
+        K().spmm(g.t_rowptr, g.t_col, g.t_perm if g.val is not None else None, g.val,
+                 g.inv_d if ctx.mean else None, None, dy, dx, g.n, dy.shape[1])
+        return dx, None, None
+
+
+def aggregate(x, g, mean=True):
+    """(A x) / clamp(rowsum A, 1)  (mean=True, DenseSAGEConv) or plain A x (mean=False: A S of _diff_pool, GIN)."""
+    return _Aggregate.apply(x, g, mean)
+
+
+# ----------------------------------------------------------------------------------------------
+# y = x W (+ b)
+# ----------------------------------------------------------------------------------------------
+class _LinearBias(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, out_in_layout):
+        x, weight = _f32c(x), _f32c(weight)
+        n, fin = x.shape
+        fout = weight.shape[0] if out_in_layout else weight.shape[1]
+        y = torch.empty(n, fout, dtype=torch.float32, device=x.device)
+        K().gemm(x, weight, y, n, fout, fin, False, out_in_layout, fin, weight.shape[1], fout, 1.0, 0.0, bias)
+        ctx.save_for_backward(x, weight)
+        ctx.out_in, ctx.has_bias = out_in_layout, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy, ld = _rows_ld(dy)
+        n, fin = x.shape
+        fout = dy.shape[1]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            # dx = dy W^T : with W [in,out] that is op(B)=W^T (transB); with W [out,in] it is plain W
+            K().gemm(dy, weight, dx, n, fin, fout, False, not ctx.out_in, ld, weight.shape[1], fin)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(weight)
+            if ctx.out_in:      # dW[out,in] = dy^T x
+                gemm_tn_rows(dy, ld, fout, x, fin, fin, n, dw)
+            else:               # dW[in,out] = x^T dy
+                gemm_tn_rows(x, fin, fin, dy, ld, fout, n, dw)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.empty(fout, dtype=torch.float32, device=dy.device)
+            K().colsum(dy, ld, n, fout, db)
+        return dx, dw, db, None
+
+
+def linear_bias(x, weight, bias=None, out_in_layout=False):
+    return _LinearBias.apply(x, weight, bias, out_in_layout)
+
+
+# ----------------------------------------------------------------------------------------------
+# row L2-normalise -> activation -> BatchNorm (statistics over `count` rows, zero padding included)
+# ----------------------------------------------------------------------------------------------
+class _L2ActBN(Function):
+    @staticmethod
+    def forward(ctx, h, gamma, beta, running_mean, running_var, count, act, normalize, bn_mode, eps, momentum):
+        h = _f32c(h)
+        n, F = h.shape
+        dev = h.device
+        hn = torch.empty_like(h)
+        rinv = torch.empty(n, dtype=torch.float32, device=dev)
+        mean = istd = None
+        if bn_mode == 2:
+            stats = torch.empty(2, F, dtype=torch.float32, device=dev)
+            K().l2norm_act_stats(h, n, F, normalize, act, hn, rinv, stats)
+            mean = torch.empty(F, dtype=torch.float32, device=dev)
+            istd = torch.empty(F, dtype=torch.float32, device=dev)
+            K().bn_finalize(stats, float(count), eps, momentum, running_mean, running_var, mean, istd)
+        else:
+            K().l2norm_act_stats(h, n, F, normalize, act, hn, rinv, None)
+            if bn_mode == 1:
+                mean, istd = running_mean, torch.rsqrt(running_var + eps)
+        y = torch.empty_like(h)
+        K().bn_act_apply(hn, n, F, act, mean, istd, gamma, beta, y, F)
+        ctx.save_for_backward(hn, rinv, mean, istd, gamma)
+        ctx.cfg = (act, normalize, bn_mode, float(count))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        hn, rinv, mean, istd, gamma = ctx.saved_tensors
+        act, normalize, bn_mode, count = ctx.cfg
+        n, F = hn.shape
+        dy, ld = _rows_ld(dy)
+        sums = dgamma = dbeta = None
+        if bn_mode != 0:
+            sums = torch.empty(2, F, dtype=torch.float32, device=hn.device)
+            K().bn_bwd_reduce(dy, ld, hn, n, F, act, mean, istd, sums)
+            dbeta, dgamma = sums[0], sums[1]
+        dh = torch.empty_like(hn)
+        K().bn_act_l2_bwd(dy, ld, hn, rinv, n, F, act, normalize, bn_mode, mean, istd, gamma, sums, count, dh)
+        return dh, dgamma, dbeta, None, None, None, None, None, None, None, None
+
+
+def l2_act_bn(h, bn, count, act='relu', normalize=True, training=True):
+    """BN(act(l2norm(h))) with BatchNorm statistics over ``count`` rows (rows beyond h's are zeros).
+
+    ``bn`` is an nn.BatchNorm1d (parameter/buffer holder) or None.  In training mode the running
+    statistics and num_batches_tracked are updated as nn.BatchNorm1d does.
+    """
+    code = ACT_CODES[act]
+    if bn is None:
+        return _L2ActBN.apply(h, None, None, None, None, count, code, normalize, 0, 0.0, 0.0)
+    use_batch = training or bn.running_mean is None
+    if use_batch and training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    momentum = bn.momentum if bn.momentum is not None else 1.0 / float(max(int(bn.num_batches_tracked), 1))
+    rm, rv = (bn.running_mean, bn.running_var) if (training and bn.track_running_stats) else (None, None)
+    if use_batch:
+        return _L2ActBN.apply(h, bn.weight, bn.bias, rm, rv, count, code, normalize, 2, bn.eps, momentum)
+    return _L2ActBN.apply(h, bn.weight, bn.bias, bn.running_mean, bn.running_var, count, code, normalize, 1,
+                          bn.eps, 0.0)
+
+
+# ----------------------------------------------------------------------------------------------
+# assignment softmax, max readout
+# ----------------------------------------------------------------------------------------------
+class _SoftmaxRows(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _f32c(x)
+        s = torch.empty_like(x)
+        K().softmax_fwd(x, x.shape[0], x.shape[1], s)
+        ctx.save_for_backward(s)
+        return s
+
+    @staticmethod
+    def backward(ctx, ds):
+        s, = ctx.saved_tensors
+        ds = _f32c(ds)
+        dx = torch.empty_like(s)
+        K().softmax_bwd(s, ds, s.shape[0], s.shape[1], dx)
+        return dx
+
+
+def softmax_rows(x):
+    return _SoftmaxRows.apply(x)
+
+
+class _SegmentMax(Function):
+    @staticmethod
+    def forward(ctx, x, gptr, B, nmax):
+        x = _f32c(x)
+        D = x.shape[1]
+        out = torch.empty(B, D, dtype=torch.float32, device=x.device)
+        arg = torch.empty(B, D, dtype=torch.int32, device=x.device)
+        K().segment_max_fwd(x, gptr, B, D, nmax, out, arg)
+        ctx.save_for_backward(arg)
+        ctx.n = x.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        arg, = ctx.saved_tensors
+        B, D = arg.shape
+        dx = torch.zeros(ctx.n, D, dtype=torch.float32, device=dout.device)
+        K().segment_max_bwd(_f32c(dout), arg, B, D, dx)
+        return dx, None, None, None
+
+
+def segment_max(x, gptr, B, nmax):
+    """[n, D] -> [B, D]: per-graph max over nodes; graphs shorter than nmax also see the zero padding rows."""
+    return _SegmentMax.apply(x, gptr, B, nmax)
+
+
+# ----------------------------------------------------------------------------------------------
+# DiffPool on the sparse level:  X' = S^T X,  A' = S^T (A S)   per graph
+# ----------------------------------------------------------------------------------------------
+class _DiffPoolSparse(Function):
+    @staticmethod
+    def forward(ctx, embed, s, g):
+        embed, s = _f32c(embed), _f32c(s)
+        n, dx = embed.shape
+        c = s.shape[1]
+        dev = s.device
+        p = torch.empty_like(s)                                   # P = A S   (K4, wide SpMM)
+        K().spmm(g.rowptr, g.col, None, g.val, None, None, s, p, n, c)
+        xo = torch.empty(g.B, c, dx, dtype=torch.float32, device=dev)
+        ao = torch.empty(g.B, c, c, dtype=torch.float32, device=dev)
+        # ragged-K, transposed-A contractions: per graph  [c x N_b] . [N_b x (dx | c)]
+        K().gemm(s, embed, xo, c, dx, 0, True, False, c, dx, dx, 1.0, 0.0, None, g.B, 0, 0, c * dx, g.gptr, 2, g.nmax)
+        K().gemm(s, p, ao, c, c, 0, True, False, c, c, c, 1.0, 0.0, None, g.B, 0, 0, c * c, g.gptr, 2, g.nmax)
+        ctx.save_for_backward(embed, s, p)
+        ctx.g = g
+        return xo, ao
+
+    @staticmethod
+    def backward(ctx, dxo, dao):
+        embed, s, p = ctx.saved_tensors
+        g = ctx.g
+        n, dx = embed.shape
+        c = s.shape[1]
+        dxo, dao = _f32c(dxo), _f32c(dao)
+        # dP = S dA'   (ragged-M, NN)
+        dp = torch.empty_like(s)
+        K().gemm(s, dao, dp, 0, c, c, False, False, c, c, c, 1.0, 0.0, None, g.B, 0, c * c, 0, g.gptr, 1, g.nmax)
+        # dS = A^T dP  (transpose SpMM) + P dA'^T + X dX'^T
+        ds = torch.empty_like(s)
+        K().spmm(g.t_rowptr, g.t_col, g.t_perm if g.val is not None else None, g.val, None, None, dp, ds, n, c)
+        K().gemm(p, dao, ds, 0, c, c, False, True, c, c, c, 1.0, 1.0, None, g.B, 0, c * c, 0, g.gptr, 1, g.nmax)
+        K().gemm(embed, dxo, ds, 0, c, dx, False, True, dx, dx, c, 1.0, 1.0, None, g.B, 0, c * dx, 0, g.gptr, 1, g.nmax)
+        # dX = S dX'
+        de = torch.empty_like(embed)
+        K().gemm(s, dxo, de, 0, dx, c, False, False, c, dx, dx, 1.0, 0.0, None, g.B, 0, c * dx, 0, g.gptr, 1, g.nmax)
+        return de, ds, None
+
+
+def diff_pool_sparse(embed, s, g):
+    return _DiffPoolSparse.apply(embed, s, g)
+
+
+# ----------------------------------------------------------------------------------------------
+# strided-batched dense matmul C_b = op(A_b) op(B_b)  (levels 2-3: A~ x, S^T X, A S, S^T (A S))
+# ----------------------------------------------------------------------------------------------
+def _bgemm(A, B, C, tA, tB, beta=0.0):
+    """A, B, C: contiguous [batch, r, c] tensors; computes C = op(A) op(B) (+ beta C)."""
+    batch = C.shape[0]
+    M, N = C.shape[1], C.shape[2]
+    Kd = A.shape[1] if tA else A.shape[2]
+    K().gemm(A, B, C, M, N, Kd, tA, tB, A.shape[2], B.shape[2], N, 1.0, beta, None, batch,
+             A.shape[1] * A.shape[2], B.shape[1] * B.shape[2], M * N)
+
+
+class _BMatmul(Function):
+    @staticmethod
+    def forward(ctx, A, B, tA, tB):
+        A, B = _f32c(A), _f32c(B)
+        M = A.shape[2] if tA else A.shape[1]
+        N = B.shape[1] if tB else B.shape[2]
+        C = torch.empty(A.shape[0], M, N, dtype=torch.float32, device=A.device)
+        _bgemm(A, B, C, tA, tB)
+        ctx.save_for_backward(A, B)
+        ctx.t = (tA, tB)
+        return C
+
+    @staticmethod
+    def backward(ctx, dC):
+        A, B = ctx.saved_tensors
+        tA, tB = ctx.t
+        dC = _f32c(dC)
+        dA = dB = None
+        if ctx.needs_input_grad[0]:
+            dA = torch.empty_like(A)
+            if not tA:
+                _bgemm(dC, B, dA, False, not tB)        # dA = dC op(B)^T
+            else:
+                _bgemm(B, dC, dA, tB, True)             # dA = op(B) dC^T
+        if ctx.needs_input_grad[1]:
+            dB = torch.empty_like(B)
+            if not tB:
+                _bgemm(A, dC, dB, not tA, False)        # dB = op(A)^T dC
+            else:
+                _bgemm(dC, A, dB, True, tA)             # dB = dC^T op(A)
+        return dA, dB, None, None
+
+
+def bmatmul(A, B, tA=False, tB=False):
+    assert not (tA and tB)
+    return _BMatmul.apply(A, B, tA, tB)
+
+
+def diff_pool_dense(embed, adj, s):
+    """_diff_pool on dense tensors (levels >= 2): (S^T X, S^T (A S))."""
+    return bmatmul(s, embed, tA=True), bmatmul(s, bmatmul(adj, s), tA=True)
+
+
+# ----------------------------------------------------------------------------------------------
+# dense adjacency transforms with gradient (levels 2-3)
+# ----------------------------------------------------------------------------------------------
+class _RowNormClamp(Function):
+    @staticmethod
+    def forward(ctx, A):
+        A = _f32c(A)
+        b, c, _ = A.shape
+        out = torch.empty_like(A)
+        invd = torch.empty(b * c, dtype=torch.float32, device=A.device)
+        ge1 = torch.empty(b * c, dtype=torch.float32, device=A.device)
+        K().dense_rownorm_fwd(A, b * c, c, out, invd, ge1)
+        ctx.save_for_backward(out, invd, ge1)
+        return out
+
+    @staticmethod
+    def backward(ctx, dOut):
+        out, invd, ge1 = ctx.saved_tensors
+        b, c, _ = out.shape
+        dA = torch.empty_like(out)
+        K().dense_rownorm_bwd(_f32c(dOut), out, invd, ge1, b * c, c, dA)
+        return dA
+
+
+def rownorm_clamp(A):
+    """A / clamp(rowsum(A), min=1): DenseSAGEConv's mean divisor folded into the adjacency, computed once per level."""
+    return _RowNormClamp.apply(A)
+
+
+class _ReNormDense(Function):
+    @staticmethod
+    def forward(ctx, A, p):
+        A = _f32c(A)
+        b, c, _ = A.shape
+        out = torch.empty_like(A)
+        K().dense_renorm_fwd(A, b * c, c, p, out)
+        ctx.save_for_backward(A)
+        ctx.p = p
+        return out
+
+    @staticmethod
+    def backward(ctx, dOut):
+        A, = ctx.saved_tensors
+        b, c, _ = A.shape
+        dA = torch.empty_like(A)
+        K().dense_renorm_bwd(A, _f32c(dOut), b * c, c, ctx.p, dA)
+        return dA, None
+
+
+def renorm_dense(A, p):
+    """_re_norm_adj (model/network.py:183-191) on a dense [B,C,C] adjacency that requires grad."""
+    return _ReNormDense.apply(A, float(p))

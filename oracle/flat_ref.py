@@ -1,0 +1,260 @@
+"""Op-level checker for the HIP kernels: the KernelSpec contract in plain torch (CPU or any device).
+
+TEST INFRASTRUCTURE (see oracle/__init__.py).  Each method restates, on the flat / CSR layout the
+kernels use, the arithmetic the reference performs on padded dense tensors; the reference lines are
+cited in cgc-net_amd/kernels.py::KernelSpec next to each entry.  tests/ use it in two ways:
+
+* GPU: every ``HipKernels`` method is compared with the method of the same name here;
+* CPU: monkeypatched in place of the kernel table, it lets the product's autograd layer and modules
+  (ops.py, network.py) run end to end so that the flat formulation -- including the hand-derived
+  backward passes -- is checked against oracle/dense_ref.py and the golden fixtures without a GPU.
+
+It is never selected by the product.
+"""
+import torch
+import torch.nn.functional as F
+
+import cgc_net_amd  # noqa: F401
+from cgc_net_amd.kernels import KernelSpec, L2_EPS, RENORM_EPS
+
+
+def _act(x, code):
+    if code == 0:
+        return x
+    if code == 1:
+        return torch.relu(x)
+    if code == 2:
+        return F.elu(x)
+    if code == 3:
+        return F.leaky_relu(x, 0.01)
+    raise ValueError(code)
+
+
+def _dact(x, code):
+    if code == 0:
+        return torch.ones_like(x)
+    if code == 1:
+        return (x > 0).to(x.dtype)
+    if code == 2:
+        return torch.where(x > 0, torch.ones_like(x), torch.exp(x))
+    if code == 3:
+        return torch.where(x > 0, torch.ones_like(x), torch.full_like(x, 0.01))
+    raise ValueError(code)
+
+
+def _mat(t, rows, cols, ld, offset=0):
+    """[rows, cols] window with leading dimension ld starting ``offset`` elements after t's first element."""
+    return t.as_strided((rows, cols), (ld, 1), t.storage_offset() + offset)
+
+
+class TorchKernels(KernelSpec):
+    # ------------------------------------------------------------------ graph structure
+    def csr_build(self, edge_index, n, add_diag):
+        row, col = edge_index[0], edge_index[1]
+        if add_diag:
+            ar = torch.arange(n, dtype=torch.int64, device=row.device)
+            row, col = torch.cat([row, ar]), torch.cat([col, ar])
+        cap = row.numel()
+        key = torch.unique(row * n + col)            # sorted + de-duplicated
+        row, col = key // n, key % n
+        nnz = key.numel()
+        i32 = torch.int32
+
+        def ptr_of(idx):
+            return torch.cat([idx.new_zeros(1), torch.bincount(idx, minlength=n).cumsum(0)]).to(i32)
+
+        def padded(v):
+            out = torch.zeros(max(cap, 1), dtype=i32, device=v.device)
+            out[:nnz] = v.to(i32)
+            return out
+        tkey, tperm = torch.sort(col * n + row)      # transposed order: by col, then by row
+        return {'rowptr': ptr_of(row), 'col': padded(col), 'rowidx': padded(row),
+                't_rowptr': ptr_of(col), 't_col': padded(tkey % n), 't_perm': padded(tperm), 'cap': cap}
+
+    @staticmethod
+    def _rows(rowptr, n):
+        cnt = (rowptr[1:] - rowptr[:-1]).long()
+        return torch.repeat_interleave(torch.arange(n, device=rowptr.device), cnt), int(rowptr[n])
+
+    def edge_renorm(self, rowptr, col, n, p, val_out):
+        rows, nnz = self._rows(rowptr, n)
+        c = col[:nnz].long()
+        off = (c != rows).to(torch.float32)
+        cnt = torch.zeros(n, device=col.device).index_add_(0, rows, off)
+        w = (1.0 / (cnt + RENORM_EPS)) * (1 - p)
+        val_out[:nnz] = torch.where(c == rows, torch.full_like(off, p), w[rows])
+
+    def csr_invdeg(self, rowptr, val, n, out):
+        rows, nnz = self._rows(rowptr, n)
+        v = val[:nnz] if val is not None else torch.ones(nnz, device=rowptr.device)
+        s = torch.zeros(n, device=rowptr.device).index_add_(0, rows, v)
+        out.copy_(1.0 / s.clamp(min=1))
+
+    def spmm(self, rowptr, col, perm, val, pre, post, x, out, n, width):
+        rows, nnz = self._rows(rowptr, n)
+        c = col[:nnz].long()
+        w = torch.ones(nnz, device=x.device)
+        if val is not None:
+            w = val[perm[:nnz].long()] if perm is not None else val[:nnz]
+        if pre is not None:
+            w = w * pre[c]
+        acc = torch.zeros(n, width, device=x.device).index_add_(0, rows, w.unsqueeze(1) * x[c])
+        if post is not None:
+            acc = acc * post.unsqueeze(1)
+        out.copy_(acc)
+
+    # ------------------------------------------------------------------ dense contractions
+    def gemm(self, A, B, C, M, N, K, transA, transB, lda, ldb, ldc, alpha=1.0, beta=0.0, bias=None,
+             batch=1, strideA=0, strideB=0, strideC=0, gptr=None, ragged=0, max_ragged=0):
+        if ragged == 1:
+            assert not transA
+        if ragged == 2:
+            assert transA and not transB
+        g = gptr.tolist() if gptr is not None else None
+        for b in range(batch):
+            m, k = M, K
+            oa, ob, oc = b * strideA, b * strideB, b * strideC
+            if ragged == 1:
+                m = g[b + 1] - g[b]
+                assert m <= max_ragged
+                oa += g[b] * lda
+                oc += g[b] * ldc
+            elif ragged == 2:
+                k = g[b + 1] - g[b]
+                assert k <= max_ragged
+                oa += g[b] * lda
+                ob += g[b] * ldb
+            a = _mat(A, k, m, lda, oa).t() if transA else _mat(A, m, k, lda, oa)
+            bm = _mat(B, N, k, ldb, ob).t() if transB else _mat(B, k, N, ldb, ob)
+            c = _mat(C, m, N, ldc, oc)
+            r = alpha * (a @ bm)
+            if beta != 0.0:
+                r = r + beta * c
+            if bias is not None:
+                r = r + bias
+            c.copy_(r)
+
+    def reduce_batch_sum(self, ws, out, parts, numel, beta=0.0):
+        s = ws.reshape(-1)[:parts * numel].view(parts, numel).sum(0)
+        o = out.view(-1)
+        o.copy_(s + beta * o if beta != 0.0 else s)
+
+    # ------------------------------------------------------------------ conv epilogue
+    def l2norm_act_stats(self, h, n, F_, normalize, act, hn_out, rinv_out, stats_out):
+        if normalize:
+            r = 1.0 / h.norm(dim=1).clamp(min=L2_EPS)
+        else:
+            r = torch.ones(n, device=h.device)
+        hn = h * r.unsqueeze(1)
+        hn_out.copy_(hn)
+        rinv_out.copy_(r)
+        if stats_out is not None:
+            o = _act(hn, act)
+            stats_out[0] = o.sum(0)
+            stats_out[1] = (o * o).sum(0)
+
+    def bn_finalize(self, stats, count, eps, momentum, running_mean, running_var, mean_out, istd_out):
+        mean = stats[0].double() / count
+        var = (stats[1].double() / count - mean * mean).clamp(min=0)
+        mean_out.copy_(mean.float())
+        istd_out.copy_((1.0 / torch.sqrt(var + eps)).float())
+        if running_mean is not None:
+            running_mean.mul_(1 - momentum).add_(momentum * mean.float())
+            running_var.mul_(1 - momentum).add_(momentum * (var * count / max(count - 1, 1)).float())
+
+    def bn_act_apply(self, hn, n, F_, act, mean, istd, gamma, beta, y_out, ldy):
+        o = _act(hn, act)
+        if mean is not None:
+            o = (o - mean) * istd * gamma + beta
+        _mat(y_out, n, F_, ldy).copy_(o)
+
+    def bn_bwd_reduce(self, dy, ldy, hn, n, F_, act, mean, istd, sums_out):
+        d = _mat(dy, n, F_, ldy)
+        xhat = (_act(hn, act) - mean) * istd
+        sums_out[0] = d.sum(0)
+        sums_out[1] = (d * xhat).sum(0)
+
+    def bn_act_l2_bwd(self, dy, ldy, hn, rinv, n, F_, act, normalize, mode, mean, istd, gamma, sums, count, dh_out):
+        d = _mat(dy, n, F_, ldy)
+        if mode == 2:
+            xhat = (_act(hn, act) - mean) * istd
+            do = gamma * istd * (d - sums[0] / count - xhat * sums[1] / count)
+        elif mode == 1:
+            do = gamma * istd * d
+        else:
+            do = d
+        dhn = do * _dact(hn, act)
+        if normalize:
+            dot = (hn * dhn).sum(1, keepdim=True)
+            r = rinv.unsqueeze(1)
+            dh = torch.where(r < 1.0 / L2_EPS, r * (dhn - hn * dot), dhn / L2_EPS)
+        else:
+            dh = dhn
+        dh_out.copy_(dh)
+
+    def colsum(self, x, ld, n, F_, out):
+        out.copy_(_mat(x, n, F_, ld).sum(0))
+
+    # ------------------------------------------------------------------ softmax / readout
+    def softmax_fwd(self, x, n, C, out):
+        out.copy_(torch.softmax(x, dim=1))
+
+    def softmax_bwd(self, S, dS, n, C, dx_out):
+        dx_out.copy_(S * (dS - (dS * S).sum(1, keepdim=True)))
+
+    def segment_max_fwd(self, x, gptr, B, D, nmax, out, arg_out):
+        g = gptr.tolist()
+        for b in range(B):
+            lo, hi = g[b], g[b + 1]
+            if hi > lo:
+                v, a = x[lo:hi].max(dim=0)      # first index on ties (CPU semantics of torch.max)
+                a = a + lo
+            else:
+                v = torch.full((D,), float('-inf'), device=x.device)
+                a = torch.full((D,), -1, dtype=torch.long, device=x.device)
+            if hi - lo < nmax:
+                pad_wins = v < 0
+                v = torch.where(pad_wins, torch.zeros_like(v), v)
+                a = torch.where(pad_wins, torch.full_like(a, -1), a)
+            out[b] = v
+            arg_out[b] = a.to(arg_out.dtype)
+
+    def segment_max_bwd(self, dout, arg, B, D, dx_zeroed):
+        a = arg.long()
+        cols = torch.arange(D, device=dout.device).expand(B, D)
+        ok = a >= 0
+        dx_zeroed[a[ok], cols[ok]] = dout[ok]
+
+    # ------------------------------------------------------------------ dense adjacency ops
+    def dense_rownorm_fwd(self, A, R, C, out, invd_out, ge1_out):
+        a = A.reshape(R, C)
+        s = a.sum(1)
+        d = s.clamp(min=1)
+        out.view(R, C).copy_(a / d.unsqueeze(1))
+        invd_out.copy_(1.0 / d)
+        ge1_out.copy_((s >= 1).float())
+
+    def dense_rownorm_bwd(self, dOut, Anorm, invd, ge1, R, C, dA_out):
+        g, an = dOut.reshape(R, C), Anorm.reshape(R, C)
+        t = (g * an).sum(1)
+        dA_out.view(R, C).copy_(invd.unsqueeze(1) * (g - (ge1 * t).unsqueeze(1)))
+
+    @staticmethod
+    def _offdiag(R, C, device):
+        m = torch.ones(R, C, device=device)
+        m[torch.arange(R, device=device), torch.arange(R, device=device) % C] = 0
+        return m
+
+    def dense_renorm_fwd(self, A, R, C, p, out):
+        a = A.reshape(R, C)
+        m = self._offdiag(R, C, a.device)
+        a0 = a * m
+        q = 1.0 / (a0.sum(1, keepdim=True) + RENORM_EPS)
+        out.view(R, C).copy_(a0 * q * (1 - p) + (1 - m) * p)
+
+    def dense_renorm_bwd(self, A, dOut, R, C, p, dA_out):
+        a, g = A.reshape(R, C), dOut.reshape(R, C)
+        m = self._offdiag(R, C, a.device)
+        q = 1.0 / ((a * m).sum(1, keepdim=True) + RENORM_EPS)
+        t = (g * a * m).sum(1, keepdim=True)
+        dA_out.view(R, C).copy_((1 - p) * q * (g - q * t) * m)

@@ -1,0 +1,45 @@
+"""Shared helpers for the parity tests."""
+import json
+import os
+
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+CASES = ['tiny_plain', 'tiny_shipped', 'tiny_elu', 'medium_plain', 'medium_shipped']
+
+
+class Bag(object):
+    pass
+
+
+def load_case(name, device='cpu'):
+    z = np.load(os.path.join(GOLDEN, name + '.npz'))
+    cfg = json.loads(str(z['cfg']))
+    batch = Bag()
+    batch.x = torch.from_numpy(z['in/x']).to(device)
+    batch.edge_index = torch.from_numpy(z['in/edge_index']).to(device)
+    batch.batch = torch.from_numpy(z['in/batch']).to(device)
+    batch.y = torch.from_numpy(z['in/y']).to(device)
+    batch._node_counts = np.bincount(z['in/batch']).tolist()
+    group = lambda p: {k[len(p):]: torch.from_numpy(np.asarray(z[k])) for k in z.files if k.startswith(p)}
+    return cfg, batch, group('sd/'), group('out/'), group('grad/'), group('sd3/')
+
+
+def build_model(cls, cfg, **over):
+    kw = dict(cfg)
+    kw.update(over)
+    return cls(kw['max_num_nodes'], kw['input_dim'], kw['hidden_dim'], kw['embedding_dim'], True, True,
+               kw['hidden_dim'], 3, kw['assign_ratio'], [50], concat=True, gcn_name=kw.get('gcn_name', 'SAGE'),
+               collect_assign=kw.get('collect_assign', False), load_data_sparse=True,
+               norm_adj=kw.get('norm_adj', False), activation=kw.get('activation', 'relu'),
+               drop_out=kw.get('drop_out', 0.), jk=kw.get('jk', False))
+
+
+def rel_err(a, b, atol=1e-7):
+    """max|a-b| / (max|b| + atol/1e-4): the 'within 1e-4 relative, fp32' yardstick of the north star.
+    The atol term only matters for tensors that are mathematically zero (e.g. the gradient of the
+    attention bias, to which the softmax is invariant): there 1e-4 * rel_err is an absolute error."""
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float((a - b).abs().max() / (float(b.abs().max()) + atol / 1e-4))
