@@ -1,0 +1,37 @@
+"""ctypes prototypes of include/cgc_hip.h (one line per exported symbol; kept in the header's order)."""
+import ctypes as C
+
+P, I, F, D, L = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_int64
+
+PROTOTYPES = {
+    'cgc_abi_version': [],
+    'cgc_csr_build': [P, L, I, I, P, P, P, P, P, P, P, P],
+    'cgc_edge_renorm': [P, P, I, F, P, P],
+    'cgc_csr_invdeg': [P, P, I, P, P],
+    'cgc_spmm': [P, P, P, P, P, P, P, P, I, I, P],
+    'cgc_gemm_f32': [I, I, I, I, I, F, P, I, P, I, F, P, I, P, I, L, L, L, P, I, I, P],
+    'cgc_reduce_batch_sum': [P, P, I, L, F, P],
+    'cgc_stats_blocks': [I, I],
+    'cgc_l2norm_act_stats': [P, I, I, I, I, P, P, P, P, P],
+    'cgc_bn_finalize': [P, I, D, F, F, P, P, P, P, P],
+    'cgc_bn_act_apply': [P, I, I, I, P, P, P, P, P, I, P],
+    'cgc_bn_bwd_reduce': [P, I, P, I, I, I, P, P, P, P, P],
+    'cgc_bn_act_l2_bwd': [P, I, P, P, I, I, I, I, I, P, P, P, P, D, P, P],
+    'cgc_colsum': [P, I, I, I, P, P, P],
+    'cgc_softmax_fwd': [P, I, I, P, P],
+    'cgc_softmax_bwd': [P, P, I, I, P, P],
+    'cgc_segment_max_fwd': [P, P, I, I, I, P, P, P],
+    'cgc_segment_max_bwd': [P, P, I, I, P, P],
+    'cgc_dense_rownorm_fwd': [P, I, I, P, P, P, P],
+    'cgc_dense_rownorm_bwd': [P, P, P, P, I, I, P, P],
+    'cgc_dense_renorm_fwd': [P, I, I, F, P, P],
+    'cgc_dense_renorm_bwd': [P, P, I, I, F, P, P],
+}
+
+
+def declare(lib):
+    """Attach argtypes/restype to every symbol; raises AttributeError if the library lacks one."""
+    for name, argtypes in PROTOTYPES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = C.c_int

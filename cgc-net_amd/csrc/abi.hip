@@ -1,0 +1,2 @@
+#include "common.hpp"
+extern "C" int cgc_abi_version(void) { return 1; }

@@ -1,0 +1,92 @@
+// Shared device helpers for libcgc_hip.so (gfx950 / CDNA4 only: 64-wide wavefronts are assumed everywhere).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/cgc_hip.h"
+
+#define CGC_WAVE 64
+#define CGC_BLOCK 256  // 4 waves: one per SIMD of a CU
+
+#define CGC_RETURN_IF_LAUNCH_FAILED()                   \
+  do {                                                  \
+    hipError_t e__ = hipGetLastError();                 \
+    if (e__ != hipSuccess) return (int)e__;             \
+  } while (0)
+
+static inline hipStream_t as_stream(cgc_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ---- cross-lane reductions over the `lpr` (power of two, <= 64) consecutive lanes that share a row
+__device__ __forceinline__ float group_sum(float v, int lpr) {
+  for (int o = lpr >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float group_max(float v, int lpr) {
+  for (int o = lpr >> 1; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+// ---- activations (model/network.py:84-91); `act` is wave-uniform
+__device__ __forceinline__ float act_fwd(float x, int act) {
+  switch (act) {
+    case CGC_ACT_RELU: return x > 0.f ? x : 0.f;
+    case CGC_ACT_ELU: return x > 0.f ? x : expf(x) - 1.f;
+    case CGC_ACT_LEAKYRELU: return x > 0.f ? x : 0.01f * x;
+    default: return x;
+  }
+}
+__device__ __forceinline__ float act_bwd(float x, int act) {  // d act / d x evaluated at the pre-activation x
+  switch (act) {
+    case CGC_ACT_RELU: return x > 0.f ? 1.f : 0.f;
+    case CGC_ACT_ELU: return x > 0.f ? 1.f : expf(x);
+    case CGC_ACT_LEAKYRELU: return x > 0.f ? 1.f : 0.01f;
+    default: return 1.f;
+  }
+}
+
+// ---- "row group" work distribution used by all row-wise kernels:
+// lpr lanes cooperate on one row (lpr = 8/16/32/64, chosen from the row width), a wave carries 64/lpr rows,
+// lanes of a group walk the columns with stride lpr*VEC.  Shuffles stay inside a group.
+struct RowGroup {
+  int sl;      // lane index inside the group
+  int sub;     // which of the wave's rows this lane works on
+  int rpw;     // rows per wave
+  int gwave;   // global wave id
+  int nwaves;  // waves in the grid
+  __device__ __forceinline__ RowGroup(int lpr) {
+    const int lane = threadIdx.x & 63;
+    sl = lane & (lpr - 1);
+    sub = lane / lpr;
+    rpw = 64 / lpr;
+    gwave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    nwaves = gridDim.x * (blockDim.x >> 6);
+  }
+};
+
+static inline int pick_lpr(int chunks) { return chunks <= 8 ? 8 : chunks <= 16 ? 16 : chunks <= 32 ? 32 : 64; }
+static inline int row_blocks(int n, int lpr, int cap = 2048) {
+  int rows_per_block = (CGC_BLOCK / 64) * (64 / lpr);
+  int b = ceil_div(n > 0 ? n : 1, rows_per_block);
+  return b < cap ? b : cap;
+}
+
+// vector-of-VEC load/store helpers (VEC = 1 or 4)
+template <int VEC> struct Vec;
+template <> struct Vec<1> {
+  float v[1];
+  __device__ __forceinline__ void load(const float* p) { v[0] = p[0]; }
+  __device__ __forceinline__ void store(float* p) const { p[0] = v[0]; }
+};
+template <> struct Vec<4> {
+  float v[4];
+  __device__ __forceinline__ void load(const float* p) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  }
+  __device__ __forceinline__ void store(float* p) const {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+};

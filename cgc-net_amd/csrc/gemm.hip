@@ -1,0 +1,295 @@
+// fp32 GEMM on the CDNA4 matrix cores: v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain: keeps the 1e-4 parity budget;
+// 157.3 TFLOP/s peak on MI355X -- there is no TF32/xf32 on gfx950).
+//
+// Replaces the dense contractions of the reference's hot path: the assignment Linear
+// (model/network.py:122), S^T X and S^T (A S) of _diff_pool (:206-207), adj@x at levels 2-3, and all their backward
+// products.  One kernel family covers: NN / NT / TN operand layouts, strided batches, and RAGGED batches whose M or K
+// extent is a graph's node count (per-graph row offsets from gptr) -- so the flat [Ntot, *] level-1 tensors are
+// contracted per graph without padding.
+//
+// Tiling (wave = 64 lanes, 4 waves per workgroup = one per SIMD):
+//   block tile (WGM*TM*32) x (WGN*TN*32) x 32;  each wave owns TM x TN accumulators of 32x32 (16 VGPRs each);
+//   A and B tiles are staged through LDS k-major ([k][m] / [k][n]) so that an MFMA operand fetch is one conflict-free
+//   ds_read_b32 per lane (lane l reads element (l&31) of k-row (l>>5));  k-contiguous operands are transposed on the
+//   way in (row stride 32*x+1 words: conflict-free scalar writes), mn-contiguous ones are copied with 16-byte writes;
+//   global->register prefetch of tile t+1 overlaps the 16 k-steps (64 MFMA/wave at 128x128) on tile t; 2 LDS buffers,
+//   one barrier per k-tile.
+#include <type_traits>
+
+#include "common.hpp"
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+struct GemmArgs {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* bias;
+  const int* gptr;
+  int M, N, K, lda, ldb, ldc;
+  long long strideA, strideB, strideC;
+  float alpha, beta;
+  int ragged;
+  int tiles_n;
+};
+
+#define BK 32
+
+// Loader for an operand tile whose K index is the CONTIGUOUS one in memory (A stored [M,K]; B stored [N,K]).
+// Logical tile: ROWS (m or n) x BK.  LDS image: [k][row], row stride LDS_LD = ROWS+1.
+template <int ROWS>
+struct KContigLoader {
+  static constexpr int UNITS = ROWS * (BK / 4);       // float4 units in the tile
+  static constexpr int PER_T = (UNITS + 255) / 256;   // units per thread
+  float4 reg[PER_T];
+  __device__ __forceinline__ void load(const float* __restrict__ base, int ld, int row0, int row_lim, int k0, int k_lim, bool vec_ok) {
+#pragma unroll
+    for (int i = 0; i < PER_T; ++i) {
+      const int u = threadIdx.x + i * 256;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (UNITS % 256 == 0 || u < UNITS) {
+        const int row = row0 + u / (BK / 4);
+        const int k = k0 + (u % (BK / 4)) * 4;
+        if (row < row_lim && k < k_lim) {
+          const float* p = base + (size_t)row * ld + k;
+          if (vec_ok && k + 3 < k_lim) {
+            v = *reinterpret_cast<const float4*>(p);
+          } else {
+            v.x = p[0];
+            if (k + 1 < k_lim) v.y = p[1];
+            if (k + 2 < k_lim) v.z = p[2];
+            if (k + 3 < k_lim) v.w = p[3];
+          }
+        }
+      }
+      reg[i] = v;
+    }
+  }
+  __device__ __forceinline__ void store(float* __restrict__ lds) const {   // transpose: 4 scalar writes, conflict-free with LD = ROWS+1
+    constexpr int LD = ROWS + 1;
+#pragma unroll
+    for (int i = 0; i < PER_T; ++i) {
+      const int u = threadIdx.x + i * 256;
+      if (UNITS % 256 == 0 || u < UNITS) {
+        const int row = u / (BK / 4);
+        const int kq = (u % (BK / 4)) * 4;
+        lds[(kq + 0) * LD + row] = reg[i].x;
+        lds[(kq + 1) * LD + row] = reg[i].y;
+        lds[(kq + 2) * LD + row] = reg[i].z;
+        lds[(kq + 3) * LD + row] = reg[i].w;
+      }
+    }
+  }
+};
+
+// Loader for an operand tile whose M/N index is the contiguous one (A stored [K,M]; B stored [K,N]).
+// Logical tile: BK x COLS.  LDS image: [k][col], row stride COLS+4 (16-byte aligned rows, 16-byte writes).
+template <int COLS>
+struct MnContigLoader {
+  static constexpr int UNITS = BK * (COLS / 4);
+  static constexpr int PER_T = (UNITS + 255) / 256;
+  float4 reg[PER_T];
+  __device__ __forceinline__ void load(const float* __restrict__ base, int ld, int col0, int col_lim, int k0, int k_lim, bool vec_ok) {
+#pragma unroll
+    for (int i = 0; i < PER_T; ++i) {
+      const int u = threadIdx.x + i * 256;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (UNITS % 256 == 0 || u < UNITS) {
+        const int k = k0 + u / (COLS / 4);
+        const int c = col0 + (u % (COLS / 4)) * 4;
+        if (k < k_lim && c < col_lim) {
+          const float* p = base + (size_t)k * ld + c;
+          if (vec_ok && c + 3 < col_lim) {
+            v = *reinterpret_cast<const float4*>(p);
+          } else {
+            v.x = p[0];
+            if (c + 1 < col_lim) v.y = p[1];
+            if (c + 2 < col_lim) v.z = p[2];
+            if (c + 3 < col_lim) v.w = p[3];
+          }
+        }
+      }
+      reg[i] = v;
+    }
+  }
+  __device__ __forceinline__ void store(float* __restrict__ lds) const {
+    constexpr int LD = COLS + 4;
+#pragma unroll
+    for (int i = 0; i < PER_T; ++i) {
+      const int u = threadIdx.x + i * 256;
+      if (UNITS % 256 == 0 || u < UNITS) {
+        const int k = u / (COLS / 4);
+        const int c = (u % (COLS / 4)) * 4;
+        *reinterpret_cast<float4*>(&lds[k * LD + c]) = reg[i];
+      }
+    }
+  }
+};
+
+template <int WGM, int WGN, int TM, int TN, bool TA, bool TB>
+__global__ __launch_bounds__(256) void k_gemm_f32(const GemmArgs a) {
+  constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
+  constexpr int LDA_S = TA ? BM + 4 : BM + 1;
+  constexpr int LDB_S = TB ? BN + 1 : BN + 4;
+  // sizes rounded so that every sub-array starts 16-byte aligned
+  constexpr int A_SZ = ((BK * LDA_S + 3) / 4) * 4, B_SZ = ((BK * LDB_S + 3) / 4) * 4;
+  __shared__ __attribute__((aligned(16))) float lds[2 * A_SZ + 2 * B_SZ];
+  float* const As0 = lds;                 // As[buf] = As0 + buf*A_SZ
+  float* const Bs0 = lds + 2 * A_SZ;      // Bs[buf] = Bs0 + buf*B_SZ
+
+  const int b = blockIdx.z;
+  int M = a.M, K = a.K;
+  const float* A = a.A + (size_t)b * a.strideA;
+  const float* B = a.B + (size_t)b * a.strideB;
+  float* C = a.C + (size_t)b * a.strideC;
+  if (a.ragged == 1) {
+    const int g0 = a.gptr[b];
+    M = a.gptr[b + 1] - g0;
+    A += (size_t)g0 * a.lda;
+    C += (size_t)g0 * a.ldc;
+  } else if (a.ragged == 2) {
+    const int g0 = a.gptr[b];
+    K = a.gptr[b + 1] - g0;
+    A += (size_t)g0 * a.lda;
+    B += (size_t)g0 * a.ldb;
+  }
+  const int tile_m = blockIdx.x / a.tiles_n, tile_n = blockIdx.x - tile_m * a.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  if (m0 >= M) return;
+  const int N = a.N;
+
+  const bool vecA = (a.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) & 15u) == 0);
+  const bool vecB = (a.ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(B) & 15u) == 0);
+
+  typename std::conditional<TA, MnContigLoader<BM>, KContigLoader<BM>>::type la;
+  typename std::conditional<TB, KContigLoader<BN>, MnContigLoader<BN>>::type lb;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / WGN, wn = wave - wm * WGN;
+  const int l31 = lane & 31, lhi = lane >> 5;
+
+  floatx16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = (K + BK - 1) / BK;
+  if (nk > 0) {
+    la.load(A, a.lda, m0, M, 0, K, vecA);
+    lb.load(B, a.ldb, n0, N, 0, K, vecB);
+    la.store(As0);
+    lb.store(Bs0);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) {   // prefetch the next k-tile into registers while this one is consumed from LDS
+      la.load(A, a.lda, m0, M, (kt + 1) * BK, K, vecA);
+      lb.load(B, a.ldb, n0, N, (kt + 1) * BK, K, vecB);
+    }
+    const float* as = As0 + cur * A_SZ + wm * TM * 32 + l31;
+    const float* bs = Bs0 + cur * B_SZ + wn * TN * 32 + l31;
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      float av[TM], bv[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) av[i] = as[(kk + lhi) * LDA_S + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bv[j] = bs[(kk + lhi) * LDB_S + j * 32];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) {
+      la.store(As0 + (cur ^ 1) * A_SZ);
+      lb.store(Bs0 + (cur ^ 1) * B_SZ);
+    }
+    __syncthreads();
+  }
+
+  // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const float alpha = a.alpha, beta = a.beta;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + (wn * TN + j) * 32 + l31;
+      if (col >= N) continue;
+      const float bia = a.bias != nullptr ? a.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        if (row < M) {
+          float* p = C + (size_t)row * a.ldc + col;
+          float v = alpha * acc[i][j][r] + bia;
+          if (beta != 0.f) v += beta * (*p);
+          *p = v;
+        }
+      }
+    }
+}
+
+template <int WGM, int WGN, int TM, int TN>
+static int launch_cfg(const GemmArgs& a0, int transA, int transB, int batch, int m_extent, hipStream_t stream) {
+  constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
+  GemmArgs a = a0;
+  a.tiles_n = ceil_div(a.N, BN);
+  const long long tiles = (long long)ceil_div(m_extent, BM) * a.tiles_n;
+  if (tiles <= 0 || tiles > 0x7fffffffLL || batch > 65535) return CGC_EINVAL;
+  dim3 grid((unsigned)tiles, 1, (unsigned)batch), block(256);
+  if (!transA && !transB)
+    hipLaunchKernelGGL((k_gemm_f32<WGM, WGN, TM, TN, false, false>), grid, block, 0, stream, a);
+  else if (!transA && transB)
+    hipLaunchKernelGGL((k_gemm_f32<WGM, WGN, TM, TN, false, true>), grid, block, 0, stream, a);
+  else if (transA && !transB)
+    hipLaunchKernelGGL((k_gemm_f32<WGM, WGN, TM, TN, true, false>), grid, block, 0, stream, a);
+  else
+    return CGC_EINVAL;
+  CGC_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}
+
+extern "C" int cgc_gemm_f32(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda, const float* B, int ldb,
+                            float beta, float* C, int ldc, const float* bias, int batch, int64_t strideA, int64_t strideB,
+                            int64_t strideC, const int* gptr, int ragged, int max_ragged, cgc_stream_t stream_) {
+  if (batch <= 0 || N <= 0) return 0;
+  if (ragged == 1 && (transA || gptr == nullptr)) return CGC_EINVAL;
+  if (ragged == 2 && (!transA || transB || gptr == nullptr)) return CGC_EINVAL;
+  if (ragged < 0 || ragged > 2) return CGC_EINVAL;
+  const int m_extent = ragged == 1 ? max_ragged : M;
+  if (m_extent <= 0) return 0;
+  GemmArgs a;
+  a.A = A; a.B = B; a.C = C; a.bias = bias; a.gptr = gptr;
+  a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
+  a.strideA = strideA; a.strideB = strideB; a.strideC = strideC;
+  a.alpha = alpha; a.beta = beta; a.ragged = ragged; a.tiles_n = 0;
+  hipStream_t stream = as_stream(stream_);
+  // tile shape by output aspect: the hot contractions are (>=1140) x (>=1140); the skinny ones are K- or output-bound
+  if (N <= 32) return launch_cfg<4, 1, 1, 1>(a, transA, transB, batch, m_extent, stream);   // 128 x 32
+  if (N <= 64) return launch_cfg<4, 1, 1, 2>(a, transA, transB, batch, m_extent, stream);   // 128 x 64
+  if (m_extent <= 32) return launch_cfg<1, 4, 1, 1>(a, transA, transB, batch, m_extent, stream);   // 32 x 128
+  if (m_extent <= 64) return launch_cfg<1, 4, 2, 1>(a, transA, transB, batch, m_extent, stream);   // 64 x 128
+  return launch_cfg<2, 2, 2, 2>(a, transA, transB, batch, m_extent, stream);                        // 128 x 128
+}
+
+// ---- deterministic split-K combine
+__global__ void k_reduce_batch_sum(const float* __restrict__ ws, float* __restrict__ out, int parts, long long numel, float beta) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < numel; i += (long long)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int p = 0; p < parts; ++p) s += ws[(size_t)p * numel + i];
+    out[i] = beta != 0.f ? s + beta * out[i] : s;
+  }
+}
+
+extern "C" int cgc_reduce_batch_sum(const float* ws, float* out, int parts, int64_t numel, float beta, cgc_stream_t stream) {
+  if (numel <= 0) return 0;
+  const int64_t blocks = ceil_div64(numel, 256);
+  hipLaunchKernelGGL(k_reduce_batch_sum, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, as_stream(stream), ws, out,
+                     parts, (long long)numel, beta);
+  CGC_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}

@@ -1,0 +1,761 @@
+// Row-wise kernels of the conv epilogue, BatchNorm, assignment softmax, max readout and the dense
+// adjacency transforms.  All are HBM-bandwidth-bound streaming kernels:
+//   * lanes of a "row group" (8..64 lanes, common.hpp) read a row with 16-byte loads when the layout allows,
+//   * row reductions are wavefront shuffles, column reductions are per-lane register accumulators combined
+//     deterministically (wave -> LDS -> per-block slot -> second-stage kernel): no float atomics anywhere.
+// Reference arithmetic: see the citations in include/cgc_hip.h.
+#include "common.hpp"
+
+#define L2_EPS 1e-12f
+#define RENORM_EPS 1e-15f
+#define MAX_SLOTS 512
+
+// ------------------------------------------------------------------------------------------------
+// column accumulators: block-level combine + second stage
+// ------------------------------------------------------------------------------------------------
+template <int VEC, int MAXJ, int NQ>
+__device__ __forceinline__ void col_reduce_store(float (&acc)[NQ][MAXJ][VEC], int F, int lpr, float* smem, float* slot) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j)
+#pragma unroll
+      for (int v = 0; v < VEC; ++v)
+        for (int o = 32; o >= lpr; o >>= 1) acc[q][j][v] += __shfl_xor(acc[q][j][v], o);
+  if (wave > 0 && lane < lpr) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int j = 0; j < MAXJ; ++j)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          const int c = (lane + lpr * j) * VEC + v;
+          if (c < F) smem[((wave - 1) * NQ + q) * F + c] = acc[q][j][v];
+        }
+  }
+  __syncthreads();
+  if (wave == 0 && lane < lpr) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int j = 0; j < MAXJ; ++j)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          const int c = (lane + lpr * j) * VEC + v;
+          if (c < F) {
+            float t = acc[q][j][v];
+            for (int w = 0; w < 3; ++w) t += smem[(w * NQ + q) * F + c];
+            slot[q * F + c] = t;
+          }
+        }
+  }
+}
+
+// out[c] = sum_s ws[s*width + c]
+__global__ __launch_bounds__(256) void k_reduce_slots(const float* __restrict__ ws, int slots, int width, float* __restrict__ out) {
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  float s = 0.f;
+  if (c < width)
+    for (int k = grp; k < slots; k += 4) s += ws[(size_t)k * width + c];
+  part[grp][lane] = s;
+  __syncthreads();
+  if (grp == 0 && c < width) out[c] = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+}
+
+struct ColCfg {
+  int vec, maxj, lpr, blocks;
+  bool ok;
+};
+static ColCfg col_cfg(int n, int F, bool vec_ok) {
+  ColCfg c;
+  c.vec = vec_ok ? 4 : 1;
+  c.ok = true;
+  int chunks = F / c.vec;
+  if (chunks <= 64) {
+    c.maxj = 1;
+    c.lpr = pick_lpr(chunks);
+  } else {
+    c.lpr = 64;
+    int need = ceil_div(chunks, 64);           // per-lane chunks; instantiated: 16-byte lanes up to 8, scalar lanes up to 32
+    if (c.vec == 4 && need > 8) {              // rows wider than 2048 floats: scalar lanes
+      c.vec = 1;
+      need = ceil_div(F, 64);
+    }
+    c.ok = need <= 32;                         // F <= 2048 (covers the reference's cluster counts 1140 / 1600)
+    c.maxj = need <= 2 ? 2 : need <= 4 ? 4 : need <= 8 ? 8 : need <= 16 ? 16 : 32;
+  }
+  c.blocks = row_blocks(n, c.lpr, MAX_SLOTS);
+  return c;
+}
+
+#define DISPATCH_COL(KERNEL, cfg, smem_bytes, stream, ...)                                                   \
+  do {                                                                                                       \
+    dim3 g__((cfg).blocks), b__(CGC_BLOCK);                                                                  \
+    if ((cfg).vec == 4) {                                                                                    \
+      switch ((cfg).maxj) {                                                                                  \
+        case 1: hipLaunchKernelGGL((KERNEL<4, 1>), g__, b__, smem_bytes, stream, __VA_ARGS__); break;        \
+        case 2: hipLaunchKernelGGL((KERNEL<4, 2>), g__, b__, smem_bytes, stream, __VA_ARGS__); break;        \
+        case 4: hipLaunchKernelGGL((KERNEL<4, 4>), g__, b__, smem_bytes, stream, __VA_ARGS__); break;        \
+        default: hipLaunchKernelGGL((KERNEL<4, 8>), g__, b__, smem_bytes, stream, __VA_ARGS__); break;       \
+      }                                                                                                      \
+    } else {                                                                                                 \
+      switch ((cfg).maxj) {                                                                                  \
+        case 1: hipLaunchKernelGGL((KERNEL<1, 1>), g__, b__, smem_bytes, stream, __VA_ARGS__); break;        \
+        case 2: hipLaunchKernelGGL((KERNEL<1, 2>), g__, b__, smem_bytes, stream, __VA_ARGS__); break;        \
+        case 4: hipLaunchKernelGGL((KERNEL<1, 4>), g__, b__, smem_bytes, stream, __VA_ARGS__); break;        \
+        case 8: hipLaunchKernelGGL((KERNEL<1, 8>), g__, b__, smem_bytes, stream, __VA_ARGS__); break;        \
+        case 16: hipLaunchKernelGGL((KERNEL<1, 16>), g__, b__, smem_bytes, stream, __VA_ARGS__); break;      \
+        default: hipLaunchKernelGGL((KERNEL<1, 32>), g__, b__, smem_bytes, stream, __VA_ARGS__); break;      \
+      }                                                                                                      \
+    }                                                                                                        \
+  } while (0)
+
+extern "C" int cgc_stats_blocks(int n, int F) {
+  (void)F;
+  int b = ceil_div(n > 0 ? n : 1, 4);
+  return b < MAX_SLOTS ? b : MAX_SLOTS;
+}
+
+// ------------------------------------------------------------------------------------------------
+// l2norm (+ activation statistics for BatchNorm)
+// ------------------------------------------------------------------------------------------------
+template <int VEC, int MAXJ>
+__global__ __launch_bounds__(256) void k_l2norm_act_stats(const float* __restrict__ h, int n, int F, int lpr, int normalize,
+                                                          int act, float* __restrict__ hn, float* __restrict__ rinv,
+                                                          float* __restrict__ ws) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const RowGroup rg(lpr);
+  float acc[2][MAXJ][VEC];
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j)
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[0][j][v] = acc[1][j][v] = 0.f;
+
+  for (int base = rg.gwave * rg.rpw; base < n; base += rg.nwaves * rg.rpw) {
+    const int row = base + rg.sub;
+    const bool valid = row < n;
+    Vec<VEC> x[MAXJ];
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+      const int c = (rg.sl + lpr * j) * VEC;
+      if (valid && c < F) {
+        x[j].load(h + (size_t)row * F + c);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) ss += x[j].v[v] * x[j].v[v];
+      } else {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) x[j].v[v] = 0.f;
+      }
+    }
+    ss = group_sum(ss, lpr);
+    const float r = normalize ? 1.f / fmaxf(sqrtf(ss), L2_EPS) : 1.f;
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+      const int c = (rg.sl + lpr * j) * VEC;
+      if (valid && c < F) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          x[j].v[v] *= r;
+          const float o = act_fwd(x[j].v[v], act);
+          acc[0][j][v] += o;
+          acc[1][j][v] += o * o;
+        }
+        x[j].store(hn + (size_t)row * F + c);
+      }
+    }
+    if (valid && rg.sl == 0) rinv[row] = r;
+  }
+  if (ws != nullptr) col_reduce_store<VEC, MAXJ, 2>(acc, F, lpr, smem, ws + (size_t)blockIdx.x * 2 * F);
+}
+
+extern "C" int cgc_l2norm_act_stats(const float* h, int n, int F, int normalize, int act, float* hn, float* rinv,
+                                    float* stats, float* ws, cgc_stream_t stream) {
+  if (n <= 0 || F <= 0) {
+    if (stats && F > 0) (void)hipMemsetAsync(stats, 0, sizeof(float) * 2 * F, as_stream(stream));
+    return 0;
+  }
+  const bool vec_ok = (F % 4 == 0) && aligned16(h) && aligned16(hn);
+  ColCfg cfg = col_cfg(n, F, vec_ok);
+  if (!cfg.ok) return CGC_EINVAL;
+  float* wsp = stats ? ws : nullptr;
+  if (stats && !ws) return CGC_EINVAL;
+  const size_t smem = sizeof(float) * 3 * 2 * F;
+  DISPATCH_COL(k_l2norm_act_stats, cfg, smem, as_stream(stream), h, n, F, cfg.lpr, normalize, act, hn, rinv, wsp);
+  CGC_RETURN_IF_LAUNCH_FAILED();
+  if (stats) {
+    hipLaunchKernelGGL(k_reduce_slots, dim3(ceil_div(2 * F, 64)), dim3(256), 0, as_stream(stream), ws, cfg.blocks, 2 * F, stats);
+    CGC_RETURN_IF_LAUNCH_FAILED();
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm statistics -> mean / inverse std (+ running statistics)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_bn_finalize(const float* __restrict__ stats, int F, double count, float eps, float momentum,
+                              float* running_mean, float* running_var, float* __restrict__ mean, float* __restrict__ istd) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= F) return;
+  const double m = (double)stats[f] / count;
+  double var = (double)stats[F + f] / count - m * m;   // biased; the padded zero rows are part of `count`
+  if (var < 0.0) var = 0.0;
+  mean[f] = (float)m;
+  istd[f] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean != nullptr) {
+    const double unbiased = var * count / (count > 1.0 ? count - 1.0 : 1.0);
+    running_mean[f] = (1.f - momentum) * running_mean[f] + momentum * (float)m;
+    running_var[f] = (1.f - momentum) * running_var[f] + momentum * (float)unbiased;
+  }
+}
+
+extern "C" int cgc_bn_finalize(const float* stats, int F, double count, float eps, float momentum, float* running_mean,
+                               float* running_var, float* mean, float* istd, cgc_stream_t stream) {
+  if (F <= 0) return 0;
+  hipLaunchKernelGGL(k_bn_finalize, dim3(ceil_div(F, 256)), dim3(256), 0, as_stream(stream), stats, F, count, eps, momentum,
+                     running_mean, running_var, mean, istd);
+  CGC_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// y = BN(act(hn))   (elementwise; y may be a column slice of a wider buffer: ldy)
+// ------------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(256) void k_bn_act_apply(const float* __restrict__ hn, int n, int F, int lpr, int act,
+                                                      const float* __restrict__ mean, const float* __restrict__ istd,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      float* __restrict__ y, int ldy) {
+  const RowGroup rg(lpr);
+  for (int base = rg.gwave * rg.rpw; base < n; base += rg.nwaves * rg.rpw) {
+    const int row = base + rg.sub;
+    if (row >= n) continue;
+    for (int c = rg.sl * VEC; c < F; c += lpr * VEC) {
+      Vec<VEC> x;
+      x.load(hn + (size_t)row * F + c);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        float o = act_fwd(x.v[v], act);
+        if (mean != nullptr) o = (o - mean[c + v]) * istd[c + v] * gamma[c + v] + beta[c + v];
+        x.v[v] = o;
+      }
+      x.store(y + (size_t)row * ldy + c);
+    }
+  }
+}
+
+extern "C" int cgc_bn_act_apply(const float* hn, int n, int F, int act, const float* mean, const float* istd,
+                                const float* gamma, const float* beta, float* y, int ldy, cgc_stream_t stream) {
+  if (n <= 0 || F <= 0) return 0;
+  const bool vec = (F % 4 == 0) && (ldy % 4 == 0) && aligned16(hn) && aligned16(y);
+  const int lpr = pick_lpr(vec ? F / 4 : F);
+  dim3 grid(row_blocks(n, lpr)), block(CGC_BLOCK);
+  if (vec)
+    hipLaunchKernelGGL(k_bn_act_apply<4>, grid, block, 0, as_stream(stream), hn, n, F, lpr, act, mean, istd, gamma, beta, y, ldy);
+  else
+    hipLaunchKernelGGL(k_bn_act_apply<1>, grid, block, 0, as_stream(stream), hn, n, F, lpr, act, mean, istd, gamma, beta, y, ldy);
+  CGC_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm backward, stage 1: sums[0] = sum dy, sums[1] = sum dy * xhat
+// ------------------------------------------------------------------------------------------------
+template <int VEC, int MAXJ>
+__global__ __launch_bounds__(256) void k_bn_bwd_reduce(const float* __restrict__ dy, int ldy, const float* __restrict__ hn, int n,
+                                                       int F, int lpr, int act, const float* __restrict__ mean,
+                                                       const float* __restrict__ istd, float* __restrict__ ws) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const RowGroup rg(lpr);
+  float acc[2][MAXJ][VEC];
+  float mu[MAXJ][VEC], is[MAXJ][VEC];
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j)
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      acc[0][j][v] = acc[1][j][v] = 0.f;
+      const int c = (rg.sl + lpr * j) * VEC + v;
+      mu[j][v] = c < F ? mean[c] : 0.f;
+      is[j][v] = c < F ? istd[c] : 0.f;
+    }
+  for (int base = rg.gwave * rg.rpw; base < n; base += rg.nwaves * rg.rpw) {
+    const int row = base + rg.sub;
+    if (row < n) {
+#pragma unroll
+      for (int j = 0; j < MAXJ; ++j) {
+        const int c = (rg.sl + lpr * j) * VEC;
+        if (c < F) {
+          Vec<VEC> d, x;
+          d.load(dy + (size_t)row * ldy + c);
+          x.load(hn + (size_t)row * F + c);
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) {
+            const float xhat = (act_fwd(x.v[v], act) - mu[j][v]) * is[j][v];
+            acc[0][j][v] += d.v[v];
+            acc[1][j][v] += d.v[v] * xhat;
+          }
+        }
+      }
+    }
+  }
+  col_reduce_store<VEC, MAXJ, 2>(acc, F, lpr, smem, ws + (size_t)blockIdx.x * 2 * F);
+}
+
+extern "C" int cgc_bn_bwd_reduce(const float* dy, int ldy, const float* hn, int n, int F, int act, const float* mean,
+                                 const float* istd, float* sums, float* ws, cgc_stream_t stream) {
+  if (F <= 0) return 0;
+  if (n <= 0) {
+    (void)hipMemsetAsync(sums, 0, sizeof(float) * 2 * F, as_stream(stream));
+    return 0;
+  }
+  const bool vec_ok = (F % 4 == 0) && (ldy % 4 == 0) && aligned16(dy) && aligned16(hn);
+  ColCfg cfg = col_cfg(n, F, vec_ok);
+  if (!cfg.ok) return CGC_EINVAL;
+  const size_t smem = sizeof(float) * 3 * 2 * F;
+  DISPATCH_COL(k_bn_bwd_reduce, cfg, smem, as_stream(stream), dy, ldy, hn, n, F, cfg.lpr, act, mean, istd, ws);
+  CGC_RETURN_IF_LAUNCH_FAILED();
+  hipLaunchKernelGGL(k_reduce_slots, dim3(ceil_div(2 * F, 64)), dim3(256), 0, as_stream(stream), ws, cfg.blocks, 2 * F, sums);
+  CGC_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm backward stage 2 fused with activation and l2norm backward:  dy -> dh
+// ------------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(256) void k_bn_act_l2_bwd(const float* __restrict__ dy, int ldy, const float* __restrict__ hn,
+                                                       const float* __restrict__ rinv, int n, int F, int lpr, int act,
+                                                       int normalize, int mode, const float* __restrict__ mean,
+                                                       const float* __restrict__ istd, const float* __restrict__ gamma,
+                                                       const float* __restrict__ sums, float inv_count, float* __restrict__ dh) {
+  const RowGroup rg(lpr);
+  for (int base = rg.gwave * rg.rpw; base < n; base += rg.nwaves * rg.rpw) {
+    const int row = base + rg.sub;
+    const bool valid = row < n;
+    // d(hn) for one element; recomputed in the second pass (cheaper than keeping a row in registers)
+    auto dhn_at = [&](int c, float d, float x) -> float {
+      float go = d;
+      if (mode == 2) {
+        const float xhat = (act_fwd(x, act) - mean[c]) * istd[c];
+        go = gamma[c] * istd[c] * (d - sums[c] * inv_count - xhat * sums[F + c] * inv_count);
+      } else if (mode == 1) {
+        go = gamma[c] * istd[c] * d;
+      }
+      return go * act_bwd(x, act);
+    };
+    float dot = 0.f;
+    if (normalize && valid) {
+      for (int c = rg.sl * VEC; c < F; c += lpr * VEC) {
+        Vec<VEC> d, x;
+        d.load(dy + (size_t)row * ldy + c);
+        x.load(hn + (size_t)row * F + c);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) dot += x.v[v] * dhn_at(c + v, d.v[v], x.v[v]);
+      }
+    }
+    if (normalize) dot = group_sum(dot, lpr);
+    if (!valid) continue;
+    const float r = normalize ? rinv[row] : 1.f;
+    const bool clamped = normalize && !(r < 1.f / L2_EPS);   // ||h|| <= eps: F.normalize divided by the constant eps
+    for (int c = rg.sl * VEC; c < F; c += lpr * VEC) {
+      Vec<VEC> d, x, o;
+      d.load(dy + (size_t)row * ldy + c);
+      x.load(hn + (size_t)row * F + c);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        const float g = dhn_at(c + v, d.v[v], x.v[v]);
+        o.v[v] = !normalize ? g : (clamped ? g * (1.f / L2_EPS) : r * (g - x.v[v] * dot));
+      }
+      o.store(dh + (size_t)row * F + c);
+    }
+  }
+}
+
+extern "C" int cgc_bn_act_l2_bwd(const float* dy, int ldy, const float* hn, const float* rinv, int n, int F, int act,
+                                 int normalize, int mode, const float* mean, const float* istd, const float* gamma,
+                                 const float* sums, double count, float* dh, cgc_stream_t stream) {
+  if (n <= 0 || F <= 0) return 0;
+  const bool vec = (F % 4 == 0) && (ldy % 4 == 0) && aligned16(dy) && aligned16(hn) && aligned16(dh);
+  const int lpr = pick_lpr(vec ? F / 4 : F);
+  const float inv_count = (float)(1.0 / count);
+  dim3 grid(row_blocks(n, lpr)), block(CGC_BLOCK);
+  if (vec)
+    hipLaunchKernelGGL(k_bn_act_l2_bwd<4>, grid, block, 0, as_stream(stream), dy, ldy, hn, rinv, n, F, lpr, act, normalize, mode,
+                       mean, istd, gamma, sums, inv_count, dh);
+  else
+    hipLaunchKernelGGL(k_bn_act_l2_bwd<1>, grid, block, 0, as_stream(stream), dy, ldy, hn, rinv, n, F, lpr, act, normalize, mode,
+                       mean, istd, gamma, sums, inv_count, dh);
+  CGC_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// column sums (bias gradients)
+// ------------------------------------------------------------------------------------------------
+template <int VEC, int MAXJ>
+__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ x, int ld, int n, int F, int lpr, float* __restrict__ ws) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const RowGroup rg(lpr);
+  float acc[1][MAXJ][VEC];
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j)
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[0][j][v] = 0.f;
+  for (int base = rg.gwave * rg.rpw; base < n; base += rg.nwaves * rg.rpw) {
+    const int row = base + rg.sub;
+    if (row < n) {
+#pragma unroll
+      for (int j = 0; j < MAXJ; ++j) {
+        const int c = (rg.sl + lpr * j) * VEC;
+        if (c < F) {
+          Vec<VEC> d;
+          d.load(x + (size_t)row * ld + c);
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) acc[0][j][v] += d.v[v];
+        }
+      }
+    }
+  }
+  col_reduce_store<VEC, MAXJ, 1>(acc, F, lpr, smem, ws + (size_t)blockIdx.x * F);
+}
+
+extern "C" int cgc_colsum(const float* x, int ld, int n, int F, float* out, float* ws, cgc_stream_t stream) {
+  if (F <= 0) return 0;
+  if (n <= 0) {
+    (void)hipMemsetAsync(out, 0, sizeof(float) * F, as_stream(stream));
+    return 0;
+  }
+  const bool vec_ok = (F % 4 == 0) && (ld % 4 == 0) && aligned16(x);
+  ColCfg cfg = col_cfg(n, F, vec_ok);
+  if (!cfg.ok) return CGC_EINVAL;
+  const size_t smem = sizeof(float) * 3 * F;
+  DISPATCH_COL(k_colsum, cfg, smem, as_stream(stream), x, ld, n, F, cfg.lpr, ws);
+  CGC_RETURN_IF_LAUNCH_FAILED();
+  hipLaunchKernelGGL(k_reduce_slots, dim3(ceil_div(F, 64)), dim3(256), 0, as_stream(stream), ws, cfg.blocks, F, out);
+  CGC_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// row softmax (assignment matrix)
+// ------------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(256) void k_softmax_fwd(const float* __restrict__ x, int n, int C, int lpr, float* __restrict__ out) {
+  const RowGroup rg(lpr);
+  for (int base = rg.gwave * rg.rpw; base < n; base += rg.nwaves * rg.rpw) {
+    const int row = base + rg.sub;
+    const bool valid = row < n;
+    const float* xr = x + (size_t)row * C;
+    float m = -INFINITY;
+    if (valid)
+      for (int c = rg.sl * VEC; c < C; c += lpr * VEC) {
+        Vec<VEC> t;
+        t.load(xr + c);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) m = fmaxf(m, t.v[v]);
+      }
+    m = group_max(m, lpr);
+    float s = 0.f;
+    if (valid)
+      for (int c = rg.sl * VEC; c < C; c += lpr * VEC) {   // second and third pass hit L1/L2: the row was just read
+        Vec<VEC> t;
+        t.load(xr + c);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) s += expf(t.v[v] - m);
+      }
+    s = group_sum(s, lpr);
+    if (!valid) continue;
+    const float inv = 1.f / s;
+    for (int c = rg.sl * VEC; c < C; c += lpr * VEC) {
+      Vec<VEC> t;
+      t.load(xr + c);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) t.v[v] = expf(t.v[v] - m) * inv;
+      t.store(out + (size_t)row * C + c);
+    }
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void k_softmax_bwd(const float* __restrict__ S, const float* __restrict__ dS, int n, int C,
+                                                     int lpr, float* __restrict__ dx) {
+  const RowGroup rg(lpr);
+  for (int base = rg.gwave * rg.rpw; base < n; base += rg.nwaves * rg.rpw) {
+    const int row = base + rg.sub;
+    const bool valid = row < n;
+    float dot = 0.f;
+    if (valid)
+      for (int c = rg.sl * VEC; c < C; c += lpr * VEC) {
+        Vec<VEC> s, d;
+        s.load(S + (size_t)row * C + c);
+        d.load(dS + (size_t)row * C + c);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) dot += s.v[v] * d.v[v];
+      }
+    dot = group_sum(dot, lpr);
+    if (!valid) continue;
+    for (int c = rg.sl * VEC; c < C; c += lpr * VEC) {
+      Vec<VEC> s, d;
+      s.load(S + (size_t)row * C + c);
+      d.load(dS + (size_t)row * C + c);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) d.v[v] = s.v[v] * (d.v[v] - dot);
+      d.store(dx + (size_t)row * C + c);
+    }
+  }
+}
+
+extern "C" int cgc_softmax_fwd(const float* x, int n, int C, float* out, cgc_stream_t stream) {
+  if (n <= 0 || C <= 0) return 0;
+  const bool vec = (C % 4 == 0) && aligned16(x) && aligned16(out);
+  const int lpr = pick_lpr(vec ? C / 4 : C);
+  dim3 grid(row_blocks(n, lpr)), block(CGC_BLOCK);
+  if (vec)
+    hipLaunchKernelGGL(k_softmax_fwd<4>, grid, block, 0, as_stream(stream), x, n, C, lpr, out);
+  else
+    hipLaunchKernelGGL(k_softmax_fwd<1>, grid, block, 0, as_stream(stream), x, n, C, lpr, out);
+  CGC_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}
+
+extern "C" int cgc_softmax_bwd(const float* S, const float* dS, int n, int C, float* dx, cgc_stream_t stream) {
+  if (n <= 0 || C <= 0) return 0;
+  const bool vec = (C % 4 == 0) && aligned16(S) && aligned16(dS) && aligned16(dx);
+  const int lpr = pick_lpr(vec ? C / 4 : C);
+  dim3 grid(row_blocks(n, lpr)), block(CGC_BLOCK);
+  if (vec)
+    hipLaunchKernelGGL(k_softmax_bwd<4>, grid, block, 0, as_stream(stream), S, dS, n, C, lpr, dx);
+  else
+    hipLaunchKernelGGL(k_softmax_bwd<1>, grid, block, 0, as_stream(stream), S, dS, n, C, lpr, dx);
+  CGC_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// max readout per graph (with the implicit zero padding rows of the dense layout)
+// ------------------------------------------------------------------------------------------------
+#define SEGMAX_WAVES 16
+__global__ __launch_bounds__(64 * SEGMAX_WAVES) void k_segment_max_fwd(const float* __restrict__ x, const int* __restrict__ gptr,
+                                                                       int D, int nmax, float* __restrict__ out,
+                                                                       int* __restrict__ arg) {
+  __shared__ float bv[SEGMAX_WAVES][64];
+  __shared__ int bi[SEGMAX_WAVES][64];
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int d = blockIdx.y * 64 + lane;
+  const int lo = gptr[b], hi = gptr[b + 1];
+  float best = -INFINITY;
+  int idx = -1;
+  if (d < D)
+    for (int r = lo + wave; r < hi; r += SEGMAX_WAVES) {   // increasing rows + strict '>' keeps the FIRST maximum
+      const float v = x[(size_t)r * D + d];
+      if (v > best) { best = v; idx = r; }
+    }
+  bv[wave][lane] = best;
+  bi[wave][lane] = idx;
+  __syncthreads();
+  if (wave == 0 && d < D) {
+    for (int w = 1; w < SEGMAX_WAVES; ++w) {
+      const float v = bv[w][lane];
+      const int i = bi[w][lane];
+      if (i >= 0 && (v > best || (v == best && i < idx) || idx < 0)) { best = v; idx = i; }
+    }
+    if (idx < 0) { best = 0.f; }                                   // empty graph: only padding rows
+    else if (hi - lo < nmax && best < 0.f) { best = 0.f; idx = -1; }  // a zero padding row wins (ties go to the real row)
+    out[(size_t)b * D + d] = best;
+    arg[(size_t)b * D + d] = idx;
+  }
+}
+
+__global__ void k_segment_max_bwd(const float* __restrict__ dout, const int* __restrict__ arg, int total, int D, float* __restrict__ dx) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int a = arg[i];
+  if (a >= 0) dx[(size_t)a * D + (i % D)] = dout[i];
+}
+
+extern "C" int cgc_segment_max_fwd(const float* x, const int* gptr, int B, int D, int nmax, float* out, int* arg, cgc_stream_t stream) {
+  if (B <= 0 || D <= 0) return 0;
+  hipLaunchKernelGGL(k_segment_max_fwd, dim3(B, ceil_div(D, 64)), dim3(64 * SEGMAX_WAVES), 0, as_stream(stream), x, gptr, D, nmax, out, arg);
+  CGC_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}
+
+extern "C" int cgc_segment_max_bwd(const float* dout, const int* arg, int B, int D, float* dx_zeroed, cgc_stream_t stream) {
+  if (B <= 0 || D <= 0) return 0;
+  const int total = B * D;
+  hipLaunchKernelGGL(k_segment_max_bwd, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), dout, arg, total, D, dx_zeroed);
+  CGC_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// dense adjacency (levels 2-3): A / clamp(rowsum,1)   and   _re_norm_adj, each with its backward
+// ------------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(256) void k_dense_rownorm_fwd(const float* __restrict__ A, int R, int C, int lpr, float* __restrict__ out,
+                                                           float* __restrict__ invd, float* __restrict__ ge1) {
+  const RowGroup rg(lpr);
+  for (int base = rg.gwave * rg.rpw; base < R; base += rg.nwaves * rg.rpw) {
+    const int row = base + rg.sub;
+    const bool valid = row < R;
+    float s = 0.f;
+    if (valid)
+      for (int c = rg.sl * VEC; c < C; c += lpr * VEC) {
+        Vec<VEC> t;
+        t.load(A + (size_t)row * C + c);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) s += t.v[v];
+      }
+    s = group_sum(s, lpr);
+    if (!valid) continue;
+    const float inv = 1.f / fmaxf(s, 1.f);
+    for (int c = rg.sl * VEC; c < C; c += lpr * VEC) {
+      Vec<VEC> t;
+      t.load(A + (size_t)row * C + c);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) t.v[v] *= inv;
+      t.store(out + (size_t)row * C + c);
+    }
+    if (rg.sl == 0) {
+      invd[row] = inv;
+      ge1[row] = s >= 1.f ? 1.f : 0.f;
+    }
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void k_dense_rownorm_bwd(const float* __restrict__ dOut, const float* __restrict__ An,
+                                                           const float* __restrict__ invd, const float* __restrict__ ge1, int R, int C,
+                                                           int lpr, float* __restrict__ dA) {
+  const RowGroup rg(lpr);
+  for (int base = rg.gwave * rg.rpw; base < R; base += rg.nwaves * rg.rpw) {
+    const int row = base + rg.sub;
+    const bool valid = row < R;
+    float t = 0.f;
+    if (valid)
+      for (int c = rg.sl * VEC; c < C; c += lpr * VEC) {
+        Vec<VEC> g, a;
+        g.load(dOut + (size_t)row * C + c);
+        a.load(An + (size_t)row * C + c);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) t += g.v[v] * a.v[v];
+      }
+    t = group_sum(t, lpr);
+    if (!valid) continue;
+    const float inv = invd[row], sub = ge1[row] * t;
+    for (int c = rg.sl * VEC; c < C; c += lpr * VEC) {
+      Vec<VEC> g;
+      g.load(dOut + (size_t)row * C + c);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) g.v[v] = inv * (g.v[v] - sub);
+      g.store(dA + (size_t)row * C + c);
+    }
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void k_dense_renorm_fwd(const float* __restrict__ A, int R, int C, int lpr, float p, float* __restrict__ out) {
+  const RowGroup rg(lpr);
+  const float omp = 1.f - p;
+  for (int base = rg.gwave * rg.rpw; base < R; base += rg.nwaves * rg.rpw) {
+    const int row = base + rg.sub;
+    const bool valid = row < R;
+    const int diag = valid ? row % C : -1;
+    float s = 0.f;
+    if (valid)
+      for (int c = rg.sl * VEC; c < C; c += lpr * VEC) {
+        Vec<VEC> t;
+        t.load(A + (size_t)row * C + c);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) s += (c + v == diag) ? 0.f : t.v[v];
+      }
+    s = group_sum(s, lpr);
+    if (!valid) continue;
+    const float den = s + RENORM_EPS;
+    for (int c = rg.sl * VEC; c < C; c += lpr * VEC) {
+      Vec<VEC> t;
+      t.load(A + (size_t)row * C + c);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) t.v[v] = (c + v == diag) ? p : (t.v[v] / den) * omp;
+      t.store(out + (size_t)row * C + c);
+    }
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void k_dense_renorm_bwd(const float* __restrict__ A, const float* __restrict__ dOut, int R, int C,
+                                                          int lpr, float p, float* __restrict__ dA) {
+  const RowGroup rg(lpr);
+  const float omp = 1.f - p;
+  for (int base = rg.gwave * rg.rpw; base < R; base += rg.nwaves * rg.rpw) {
+    const int row = base + rg.sub;
+    const bool valid = row < R;
+    const int diag = valid ? row % C : -1;
+    float s = 0.f, t = 0.f;
+    if (valid)
+      for (int c = rg.sl * VEC; c < C; c += lpr * VEC) {
+        Vec<VEC> a, g;
+        a.load(A + (size_t)row * C + c);
+        g.load(dOut + (size_t)row * C + c);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v)
+          if (c + v != diag) { s += a.v[v]; t += a.v[v] * g.v[v]; }
+      }
+    s = group_sum(s, lpr);
+    t = group_sum(t, lpr);
+    if (!valid) continue;
+    const float q = 1.f / (s + RENORM_EPS);
+    for (int c = rg.sl * VEC; c < C; c += lpr * VEC) {
+      Vec<VEC> g;
+      g.load(dOut + (size_t)row * C + c);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) g.v[v] = (c + v == diag) ? 0.f : omp * q * (g.v[v] - q * t);
+      g.store(dA + (size_t)row * C + c);
+    }
+  }
+}
+
+#define LAUNCH_ROW(KERNEL, vec, lpr, R, stream, ...)                                                          \
+  do {                                                                                                        \
+    dim3 g__(row_blocks(R, lpr)), b__(CGC_BLOCK);                                                             \
+    if (vec) hipLaunchKernelGGL(KERNEL<4>, g__, b__, 0, stream, __VA_ARGS__);                                 \
+    else hipLaunchKernelGGL(KERNEL<1>, g__, b__, 0, stream, __VA_ARGS__);                                     \
+  } while (0)
+
+extern "C" int cgc_dense_rownorm_fwd(const float* A, int R, int C, float* out, float* invd, float* ge1, cgc_stream_t stream) {
+  if (R <= 0 || C <= 0) return 0;
+  const bool vec = (C % 4 == 0) && aligned16(A) && aligned16(out);
+  const int lpr = pick_lpr(vec ? C / 4 : C);
+  LAUNCH_ROW(k_dense_rownorm_fwd, vec, lpr, R, as_stream(stream), A, R, C, lpr, out, invd, ge1);
+  CGC_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}
+extern "C" int cgc_dense_rownorm_bwd(const float* dOut, const float* Anorm, const float* invd, const float* ge1, int R, int C,
+                                     float* dA, cgc_stream_t stream) {
+  if (R <= 0 || C <= 0) return 0;
+  const bool vec = (C % 4 == 0) && aligned16(dOut) && aligned16(Anorm) && aligned16(dA);
+  const int lpr = pick_lpr(vec ? C / 4 : C);
+  LAUNCH_ROW(k_dense_rownorm_bwd, vec, lpr, R, as_stream(stream), dOut, Anorm, invd, ge1, R, C, lpr, dA);
+  CGC_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}
+extern "C" int cgc_dense_renorm_fwd(const float* A, int R, int C, float p, float* out, cgc_stream_t stream) {
+  if (R <= 0 || C <= 0) return 0;
+  const bool vec = (C % 4 == 0) && aligned16(A) && aligned16(out);
+  const int lpr = pick_lpr(vec ? C / 4 : C);
+  LAUNCH_ROW(k_dense_renorm_fwd, vec, lpr, R, as_stream(stream), A, R, C, lpr, p, out);
+  CGC_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}
+extern "C" int cgc_dense_renorm_bwd(const float* A, const float* dOut, int R, int C, float p, float* dA, cgc_stream_t stream) {
+  if (R <= 0 || C <= 0) return 0;
+  const bool vec = (C % 4 == 0) && aligned16(A) && aligned16(dOut) && aligned16(dA);
+  const int lpr = pick_lpr(vec ? C / 4 : C);
+  LAUNCH_ROW(k_dense_renorm_bwd, vec, lpr, R, as_stream(stream), A, dOut, R, C, lpr, p, dA);
+  CGC_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}

@@ -1,0 +1,86 @@
+"""Data parallelism over the GPUs of one node: one process per GPU, RCCL all-reduce of gradients.
+
+Replaces ``torch_geometric.nn.DataParallel`` as the reference uses it (train.py:276-287):
+the caller still writes ``model = DataParallel(model); out, loss = model(list_of_Data);
+loss.mean().backward(); optimizer.step()`` and ``model.module.state_dict()``.
+
+What the reference does per step inside ONE process (scatter the list over GPUs by cumulative node count,
+broadcast all parameters, run replicas on threads, gather, reduce_add gradients onto GPU 0) becomes:
+  * every rank holds a replica whose parameters were broadcast ONCE at construction,
+  * the list of graphs is split with the same cumulative-node-count rule (data.partition_by_nodes) and each
+    rank collates only its chunk (or, with ``shard_input=False``, the loader already hands each rank its own list),
+  * graphs are independent, so the forward/backward data path needs no collective,
+  * at the end of backward ONE flat fp32 bucket holding every gradient is all-reduced (sum) over RCCL/xGMI and
+    divided by the world size -- the equal-weight mean the reference takes with ``torch.mean(cls_loss)``
+    (train.py:179).  BatchNorm statistics stay per rank, as they are per replica in the reference.
+"""
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+from torch.autograd import Variable
+
+from .data import Batch, partition_by_nodes
+
+
+class DataParallel(nn.Module):
+    def __init__(self, module, device_ids=None, output_device=None, shard_input=True, process_group=None):
+        super().__init__()
+        self.module = module
+        self.shard_input = shard_input
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        self.rank = dist.get_rank(process_group) if self.world > 1 else 0
+        self._params = [p for p in module.parameters() if p.requires_grad]
+        self._flat = None
+        self._pending = False
+        if self.world > 1:
+            with torch.no_grad():                      # replicas start from rank 0's weights and buffers
+                for t in list(module.parameters()) + list(module.buffers()):
+                    dist.broadcast(t.data, src=0, group=self.group)
+            for p in self._params:
+                p.register_post_accumulate_grad_hook(self._on_grad)
+
+    # ---- device of the replica
+    @property
+    def device(self):
+        return next(self.module.parameters()).device
+
+    # ---- gradient exchange: queued once per backward pass, runs when the autograd engine has finished
+    def _on_grad(self, _param):
+        if not self._pending:
+            self._pending = True
+            Variable._execution_engine.queue_callback(self._allreduce_grads)
+
+    def _allreduce_grads(self):
+        self._pending = False
+        grads = [p.grad for p in self._params if p.grad is not None]
+        if not grads:
+            return
+        total = sum(g.numel() for g in grads)
+        if self._flat is None or self._flat.numel() != total or self._flat.device != grads[0].device:
+            self._flat = torch.empty(total, dtype=torch.float32, device=grads[0].device)
+        views, off = [], 0
+        for g in grads:
+            views.append(self._flat[off:off + g.numel()].view_as(g))
+            off += g.numel()
+        torch._foreach_copy_(views, grads)
+        dist.all_reduce(self._flat, op=dist.ReduceOp.SUM, group=self.group)
+        self._flat.div_(self.world)
+        torch._foreach_copy_(grads, views)
+
+    # ---- forward
+    def local_chunk(self, data_list):
+        if self.world == 1 or not self.shard_input:
+            return data_list
+        chunks = partition_by_nodes(data_list, self.world)
+        if len(chunks) != self.world:
+            raise ValueError('cannot split %d graphs over %d ranks' % (len(data_list), self.world))
+        return chunks[self.rank]
+
+    def forward(self, data_list):
+        """data_list: python list of Data (the DataListLoader protocol).  Returns what the module returns
+        for this rank's chunk: ``(logits, loss)`` in training mode, ``logits`` in eval mode."""
+        if len(data_list) == 0:
+            raise ValueError('empty batch')
+        batch = Batch.from_data_list(self.local_chunk(data_list)).to(self.device)
+        return self.module(batch)

@@ -1,0 +1,107 @@
+/* libcgc_hip.so -- C ABI of the MI355X (gfx950) CGC-Net hot path.
+ *
+ * The reference (Amandaynzhou/CGC-Net) is pure Python: its hot path sits behind nn.Module.forward, not behind
+ * an FFI.  Each entry point below replaces the dense torch / torch_geometric expression cited next to it
+ * (paths relative to the reference checkout); cgc-net_amd/kernels.py binds them with ctypes and
+ * INTEGRATION.md shows the binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers; float = fp32, int = int32 unless stated; matrices row-major with an
+ *     explicit leading dimension ("ld", in elements) where one is taken, contiguous otherwise
+ *   - every call enqueues kernels on `stream` and returns immediately: no allocation, no synchronisation,
+ *     no ownership taken (workspaces are passed in); safe for concurrent callers and for hipGraph capture
+ *   - return value: 0 on success, a hipError_t (>0) from the launch, or a negative CGC_E* argument error
+ */
+#ifndef CGC_HIP_H
+#define CGC_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* cgc_stream_t; /* hipStream_t */
+
+#define CGC_EINVAL (-1)      /* unsupported argument combination */
+
+/* activation codes (model/network.py:84-91) */
+#define CGC_ACT_IDENTITY 0
+#define CGC_ACT_RELU 1
+#define CGC_ACT_ELU 2
+#define CGC_ACT_LEAKYRELU 3  /* slope 0.01 */
+
+int cgc_abi_version(void);
+
+/* ---- A1: graph structure.  Replaces to_dense_adj (model/utils.py:3-36, called at model/network.py:241).
+ * edge_index: int64 [2,E] (row 0 = aggregating centre, row 1 = neighbour), any order, duplicates allowed.
+ * Produces column-sorted, de-duplicated CSR (rowptr[n+1], col[cap], rowidx[cap]) and its transpose
+ * (t_rowptr[n+1], t_col[cap] = source row, t_perm[cap] = slot in the forward arrays); cap = E + (add_diag? n : 0).
+ * nnz = rowptr[n] stays on the device.  ws: int32 workspace of 3*(n+1) + 2*cap elements. */
+int cgc_csr_build(const int64_t* edge_index, int64_t E, int n, int add_diag,
+                  int* rowptr, int* col, int* rowidx, int* t_rowptr, int* t_col, int* t_perm,
+                  int* ws, cgc_stream_t stream);
+
+/* ---- A6 (level 1): _re_norm_adj on the CSR (model/network.py:183-191): val[k] = p on the diagonal,
+ * (1/(c+1e-15))*(1-p) elsewhere, c = off-diagonal entries of the row.  The CSR must hold its diagonal. */
+int cgc_edge_renorm(const int* rowptr, const int* col, int n, float p, float* val, cgc_stream_t stream);
+
+/* out[i] = 1/max(rowsum_i, 1): the clamp(min=1) mean divisor of DenseSAGEConv (PyG 1.2.1; model/network.py:114). val may be NULL (=1). */
+int cgc_csr_invdeg(const int* rowptr, const float* val, int n, float* out, cgc_stream_t stream);
+
+/* ---- A4 / A8: neighbour aggregation.  Replaces torch.matmul(adj, x) inside DenseSAGEConv
+ * (model/network.py:114-116) and the inner product of (S^T A) S (model/network.py:207):
+ * out[i,:] = post[i] * sum_{k in row i} w_k * pre[col[k]] * x[col[k],:],  w_k = val[perm[k]] | val[k] | 1.
+ * perm, val, pre, post may be NULL.  x, out: [n, width] contiguous.  Narrow widths (<=64) and wide widths
+ * (cluster counts) take different kernels. */
+int cgc_spmm(const int* rowptr, const int* col, const int* perm, const float* val, const float* pre,
+             const float* post, const float* x, float* out, int n, int width, cgc_stream_t stream);
+
+/* ---- A4/A5/A8: dense contractions on fp32 MFMA (v_mfma_f32_32x32x2_f32).  Replaces torch.matmul / nn.Linear at
+ * model/network.py:122 (assignment Linear), :206-207 (S^T X, S^T A S), and the level-2/3 adj@x.
+ * C_b = alpha*op(A_b)*op(B_b) + beta*C_b (+ bias[N]);  op(A): M x K (transA: stored [K,M]); op(B): K x N (transB: stored [N,K]).
+ * Operand b starts at base + b*stride.  ragged=1: M_b = gptr[b+1]-gptr[b]; A (transA must be 0) and C advance gptr[b] rows.
+ * ragged=2: K_b = gptr[b+1]-gptr[b]; A (transA must be 1) and B (transB must be 0) advance gptr[b] rows.
+ * max_ragged >= max_b of the ragged extent (sizes the grid). */
+int cgc_gemm_f32(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
+                 const float* B, int ldb, float beta, float* C, int ldc, const float* bias, int batch,
+                 int64_t strideA, int64_t strideB, int64_t strideC, const int* gptr, int ragged, int max_ragged,
+                 cgc_stream_t stream);
+
+/* out[j] = beta*out[j] + sum_{s<parts} ws[s*numel + j]  (deterministic split-K combine) */
+int cgc_reduce_batch_sum(const float* ws, float* out, int parts, int64_t numel, float beta, cgc_stream_t stream);
+
+/* ---- A4/A5: conv epilogue.  Replaces F.normalize + activation + nn.BatchNorm1d over the padded [B*Nmax, C]
+ * view (model/network.py:101-107,114-116).
+ * cgc_stats_blocks(n,F): number of partial-sum slots the column reductions use; ws must hold 2*F floats per slot. */
+int cgc_stats_blocks(int n, int F);
+int cgc_l2norm_act_stats(const float* h, int n, int F, int normalize, int act, float* hn, float* rinv,
+                         float* stats /*[2,F] or NULL*/, float* ws, cgc_stream_t stream);
+int cgc_bn_finalize(const float* stats, int F, double count, float eps, float momentum,
+                    float* running_mean /*NULL ok*/, float* running_var, float* mean, float* istd, cgc_stream_t stream);
+int cgc_bn_act_apply(const float* hn, int n, int F, int act, const float* mean /*NULL: no BN*/, const float* istd,
+                     const float* gamma, const float* beta, float* y, int ldy, cgc_stream_t stream);
+int cgc_bn_bwd_reduce(const float* dy, int ldy, const float* hn, int n, int F, int act, const float* mean,
+                      const float* istd, float* sums /*[2,F]*/, float* ws, cgc_stream_t stream);
+/* mode: 2 batch statistics, 1 running statistics, 0 no BN */
+int cgc_bn_act_l2_bwd(const float* dy, int ldy, const float* hn, const float* rinv, int n, int F, int act,
+                      int normalize, int mode, const float* mean, const float* istd, const float* gamma,
+                      const float* sums, double count, float* dh, cgc_stream_t stream);
+int cgc_colsum(const float* x, int ld, int n, int F, float* out, float* ws, cgc_stream_t stream);
+
+/* ---- A8: row softmax of the assignment matrix (model/network.py:200); A9: max readout (model/network.py:264) */
+int cgc_softmax_fwd(const float* x, int n, int C, float* out, cgc_stream_t stream);
+int cgc_softmax_bwd(const float* S, const float* dS, int n, int C, float* dx, cgc_stream_t stream);
+int cgc_segment_max_fwd(const float* x, const int* gptr, int B, int D, int nmax, float* out, int* arg, cgc_stream_t stream);
+int cgc_segment_max_bwd(const float* dout, const int* arg, int B, int D, float* dx_zeroed, cgc_stream_t stream);
+
+/* ---- A4/A6 at levels 2-3 (dense, real-valued adjacency that carries gradient) */
+int cgc_dense_rownorm_fwd(const float* A, int R, int C, float* out, float* invd, float* ge1, cgc_stream_t stream);
+int cgc_dense_rownorm_bwd(const float* dOut, const float* Anorm, const float* invd, const float* ge1, int R, int C,
+                          float* dA, cgc_stream_t stream);
+int cgc_dense_renorm_fwd(const float* A, int R, int C, float p, float* out, cgc_stream_t stream);
+int cgc_dense_renorm_bwd(const float* A, const float* dOut, int R, int C, float p, float* dA, cgc_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CGC_HIP_H */

@@ -1,0 +1,110 @@
+"""CPU: the C-ABI library builds/loads and exports every declared symbol; host-side containers behave like the
+torch_geometric objects the reference feeds its model with; the product refuses to compute without the HIP path."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import cgc_net_amd  # noqa: F401
+from cgc_net_amd import _abi, kernels, network
+from cgc_net_amd.data import Batch, Data, DataListLoader, SyntheticCellGraphs, partition_by_nodes, radius_graph
+from oracle import dense_ref
+from util import build_model, load_case
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as ge
+    ge.build()
+    header = open(os.path.join(ROOT, 'include', 'cgc_hip.h')).read()
+    declared = set(re.findall(r'^int (cgc_\w+)\(', header, flags=re.M))
+    assert declared == set(_abi.PROTOTYPES), declared ^ set(_abi.PROTOTYPES)
+    lib = ctypes.CDLL(kernels.lib_path())
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.cgc_abi_version() == 1
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason='only meaningful on a host without a GPU')
+def test_no_cpu_fallback():
+    cfg, batch, sd, *_ = load_case('tiny_plain')
+    model = build_model(network.SoftPoolingGcnEncoder, cfg)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        model(batch)
+
+
+def test_state_dict_keys_match_reference_layout():
+    for name in ('medium_plain', 'medium_shipped'):
+        cfg, _, sd, *_ = load_case(name)
+        model = build_model(network.SoftPoolingGcnEncoder, cfg)
+        assert list(model.state_dict().keys()) == list(sd.keys())
+        for k, v in model.state_dict().items():
+            assert tuple(v.shape) == tuple(sd[k].shape), k
+    m = network.SoftPoolingGcnEncoder(600, 16, 20, 20, True, True, 20, 3, 0.1, [50], drop_out=0.2)
+    assert 'pred_model.3.weight' in m.state_dict()          # Dropout shifts the last Linear
+
+
+def test_radius_graph_semantics():
+    rng = np.random.RandomState(0)
+    pos = torch.from_numpy(rng.uniform(0, 500, size=(200, 2)).astype(np.float32))
+    ei = radius_graph(pos, 100.0, None, True, 8)
+    row, col = ei.numpy()
+    assert (np.diff(row) >= 0).all()                         # rows ascending
+    d = np.linalg.norm(pos.numpy()[row] - pos.numpy()[col], axis=1)
+    assert (d <= 100.0 + 1e-4).all()
+    cnt = np.bincount(row, minlength=200)
+    assert cnt.max() <= 9 and (row == col).sum() == 200      # <= 8 neighbours + the self loop
+    # brute force: the kept neighbours are the nearest ones
+    full = np.linalg.norm(pos.numpy()[:, None] - pos.numpy()[None], axis=2)
+    for i in (0, 17, 199):
+        want = np.sort(full[i][full[i] <= 100.0])[:9]
+        got = np.sort(d[row == i])
+        assert np.allclose(got, want, atol=1e-3)
+
+
+def test_batch_collate_and_loader():
+    ds = SyntheticCellGraphs(6, 40, num_features=5, base_seed=3)
+    assert ds[2].x.equal(ds[2].x) and ds[2].x.equal(SyntheticCellGraphs(6, 40, 5, base_seed=3)[2].x)   # seeded
+    items = [ds[i] for i in range(3)]
+    b = Batch.from_data_list(items)
+    n = [d.num_nodes for d in items]
+    assert b.x.shape[0] == sum(n) and b.batch.tolist() == sum(([g] * k for g, k in enumerate(n)), [])
+    off = np.cumsum([0] + n)
+    for g, d in enumerate(items):
+        sel = (b.batch[b.edge_index[0]] == g)
+        assert torch.equal(b.edge_index[:, sel] - int(off[g]), d.edge_index)
+    loader = DataListLoader(ds, batch_size=4, shuffle=False)
+    first = next(iter(loader))
+    assert isinstance(first, list) and len(first) == 4 and isinstance(first[0], Data)
+    loader.dataset.set_epoch(3)
+    assert loader.dataset.epoch == 3 and len(loader.dataset.idxlist) == 6
+
+
+def test_partition_by_cumulative_node_count():
+    ds = SyntheticCellGraphs(8, 50, num_features=2, base_seed=1)
+    items = [ds[i] for i in range(8)]
+    chunks = partition_by_nodes(items, 4)
+    assert sum(len(c) for c in chunks) == 8 and len(chunks) == 4
+    flat = [d for c in chunks for d in c]
+    assert all(a is b for a, b in zip(flat, items))          # contiguous, order kept
+    sizes = [sum(d.num_nodes for d in c) for c in chunks]
+    assert max(sizes) - min(sizes) <= 2 * max(d.num_nodes for d in items)
+
+
+def test_oracle_matches_golden():
+    """The oracle itself against the reference-generated vectors (the pin)."""
+    from util import CASES, rel_err
+    for name in CASES:
+        cfg, batch, sd, out, grad, sd3 = load_case(name)
+        m = build_model(dense_ref.SoftPoolingGcnEncoder, cfg)
+        m.load_state_dict(sd)
+        m.train()
+        logits, loss = m(batch)
+        loss.backward()
+        assert rel_err(logits, out['logits']) < 1e-5 and rel_err(loss, out['loss']) < 1e-5
+        for k, p in m.named_parameters():
+            assert rel_err(p.grad, grad[k]) < 1e-5, (name, k)

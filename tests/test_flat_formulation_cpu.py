@@ -59,3 +59,69 @@ def test_golden_three_adam_steps(name, torch_kernels):
     with torch.no_grad():
         logits = model(batch)
     assert rel_err(logits, out['eval_logits3']) < 5e-3
+
+
+@pytest.mark.parametrize('flags', [dict(gcn_name='GIN'), dict(gcn_name='GIN', norm_adj=True, activation='elu'),
+                                   dict(activation='leakyrelu', jk=True)])
+def test_variants_vs_dense_oracle(flags, torch_kernels):
+    """Model variants the fixtures do not cover (GIN convolution, leaky ReLU), against the dense oracle directly."""
+    from cgc_net_amd.data import Batch, SyntheticCellGraphs
+    from oracle import dense_ref
+    ds = SyntheticCellGraphs(4, 60, num_features=6, base_seed=13)
+    batch = Batch.from_data_list([ds[i] for i in range(4)])
+    args = (120, 6, 8, 8, True, True, 8, 3, 0.2, [50])
+    kw = dict(concat=True, load_data_sparse=True, drop_out=0.)
+    kw.update(flags)
+    torch.manual_seed(5)
+    ref = dense_ref.SoftPoolingGcnEncoder(*args, **kw)
+    model = network.SoftPoolingGcnEncoder(*args, **kw)
+    model.load_state_dict(ref.state_dict())
+    model.train()
+    ref.train()
+    logits, loss = model(batch)
+    rl, rloss = ref(batch)
+    assert rel_err(logits, rl) < TOL and rel_err(loss, rloss) < TOL
+    loss.backward()
+    rloss.backward()
+    gref = dict(ref.named_parameters())
+    for k, p in model.named_parameters():
+        assert rel_err(p.grad, gref[k].grad) < TOL_GRAD, k
+
+
+def test_dense_tuple_input_and_operator_contracts(torch_kernels):
+    """The tuple input form (model/network.py:253-256) and the DenseSAGEConv / GNN_Module dense contracts with mask."""
+    from cgc_net_amd.data import Batch, SyntheticCellGraphs
+    from oracle import dense_ref
+    ds = SyntheticCellGraphs(3, 40, num_features=6, base_seed=9)
+    b = Batch.from_data_list([ds[i] for i in range(3)])
+    adj = dense_ref.to_dense_adj(b.edge_index, b.batch)
+    x, counts = dense_ref.to_dense_batch(b.x, b.batch)
+    args = (80, 6, 8, 8, True, True, 8, 3, 0.2, [50])
+    torch.manual_seed(1)
+    ref = dense_ref.SoftPoolingGcnEncoder(*args, load_data_sparse=False)
+    model = network.SoftPoolingGcnEncoder(*args, load_data_sparse=False)
+    model.load_state_dict(ref.state_dict())
+    for train in (True, False):
+        model.train(train)
+        ref.train(train)
+        want, got = ref((x, adj, counts, b.y)), model((x, adj, counts, b.y))
+        if train:
+            assert rel_err(got[0], want[0]) < TOL and rel_err(got[1], want[1]) < TOL
+        else:
+            assert rel_err(got, want) < TOL
+    mask = dense_ref.node_mask(adj.shape[1], counts)
+    rc, pc = dense_ref.DenseSAGEConv(6, 5), network.DenseSAGEConv(6, 5)
+    pc.load_state_dict(rc.state_dict())
+    for add_loop in (True, False):
+        for m in (None, mask):
+            assert rel_err(pc(x, adj, m, add_loop), rc(x, adj, m, add_loop)) < TOL
+    rb, pb = dense_ref.GNNBlock(6, 8, 5, lin=True), network.GNN_Module(6, 8, 5, True, True, False, lin=True)
+    pb.load_state_dict(rb.state_dict())
+    xg, xr = x.clone().requires_grad_(), x.clone().requires_grad_()
+    ag, ar = adj.clone().requires_grad_(), adj.clone().requires_grad_()
+    got, want = pb(xg, ag, mask), rb(xr, ar, mask)
+    assert rel_err(got, want) < TOL
+    w = torch.randn_like(want)
+    (got * w).sum().backward()
+    (want * w).sum().backward()
+    assert rel_err(xg.grad, xr.grad) < TOL_GRAD and rel_err(ag.grad, ar.grad) < TOL_GRAD

@@ -1,0 +1,334 @@
+"""GPU: every C-ABI entry point (through HipKernels) against the torch restatement of the kernel contract
+(oracle/flat_ref.py) on the same seeded inputs.  Index work must be bit-exact; fp32 work within 1e-4 relative
+(sum-order differences only).  Shapes cover: ragged graphs, widths that are / are not multiples of 4 (16-byte lanes
+vs scalar lanes), rows narrower and wider than a wavefront, empty rows, duplicates, isolated nodes."""
+import numpy as np
+import pytest
+import torch
+
+import cgc_net_amd  # noqa: F401
+from cgc_net_amd import kernels
+from oracle.flat_ref import TorchKernels
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+REF = TorchKernels()
+TOL = 1e-4
+
+
+def hip():
+    k = kernels.get()
+    assert kernels.is_native()
+    return k
+
+
+def close(a, b, tol=TOL, what=''):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = float((a - b).abs().max()) if a.numel() else 0.0
+    scale = float(b.abs().max()) if b.numel() else 0.0
+    assert err <= tol * scale + 1e-7, '%s: abs err %g vs scale %g' % (what, err, scale)
+
+
+def g(t):
+    return None if t is None else t.to(DEV)
+
+
+def rnd(*shape, seed=0):
+    return torch.from_numpy(np.random.RandomState(seed).standard_normal(shape).astype(np.float32))
+
+
+def random_graph(counts, deg=6, seed=0, dup=True, empty_rows=True):
+    """Ragged batch of random directed graphs as a global int64 edge list (unsorted, with duplicates)."""
+    rng = np.random.RandomState(seed)
+    rows, cols, off = [], [], 0
+    for n in counts:
+        if n > 0:
+            r = rng.randint(0, n, size=n * deg)
+            c = rng.randint(0, n, size=n * deg)
+            if empty_rows and n > 3:
+                keep = r != 1
+                r, c = r[keep], c[keep]
+            rows.append(r + off)
+            cols.append(c + off)
+        off += n
+    ei = np.stack([np.concatenate(rows), np.concatenate(cols)]).astype(np.int64)
+    if dup:
+        ei = np.concatenate([ei, ei[:, :7]], axis=1)
+    ei = ei[:, rng.permutation(ei.shape[1])]
+    return torch.from_numpy(ei), off
+
+
+def build_both(ei, n, add_diag):
+    want = REF.csr_build(ei, n, add_diag)
+    got = hip().csr_build(g(ei), n, add_diag)
+    torch.cuda.synchronize()
+    return want, got
+
+
+@pytest.mark.parametrize('counts,add_diag', [([5, 9, 12], False), ([5, 9, 12], True), ([300, 0, 257, 64], False),
+                                             ([1800, 2100, 1500], True)])
+def test_csr_build_bit_exact(counts, add_diag):
+    ei, n = random_graph(counts, seed=len(counts))
+    want, got = build_both(ei, n, add_diag)
+    nnz = int(want['rowptr'][n])
+    assert torch.equal(got['rowptr'].cpu(), want['rowptr'])
+    assert torch.equal(got['t_rowptr'].cpu(), want['t_rowptr'])
+    for k in ('col', 'rowidx', 't_col', 't_perm'):
+        assert torch.equal(got[k].cpu()[:nnz], want[k][:nnz]), k
+
+
+def test_csr_presorted_knn_input():
+    from cgc_net_amd.data import Batch, SyntheticCellGraphs
+    ds = SyntheticCellGraphs(3, 200, 4, base_seed=2)
+    b = Batch.from_data_list([ds[i] for i in range(3)])
+    n = b.x.shape[0]
+    want, got = build_both(b.edge_index, n, False)
+    nnz = int(want['rowptr'][n])
+    assert nnz == b.edge_index.shape[1]           # k-NN output has no duplicates
+    assert torch.equal(got['col'].cpu()[:nnz], b.edge_index[1].int())   # already row-major sorted
+    assert torch.equal(got['rowptr'].cpu(), want['rowptr'])
+
+
+def _graph(counts, add_diag, seed=0):
+    ei, n = random_graph(counts, seed=seed)
+    s = REF.csr_build(ei, n, add_diag)
+    return s, {k: (g(v) if torch.is_tensor(v) else v) for k, v in s.items()}, n
+
+
+def test_edge_renorm_and_invdeg():
+    s, sg, n = _graph([40, 33, 64], True)
+    cap = s['cap']
+    want, got = torch.zeros(cap), torch.zeros(cap, device=DEV)
+    REF.edge_renorm(s['rowptr'], s['col'], n, 0.4, want)
+    hip().edge_renorm(sg['rowptr'], sg['col'], n, 0.4, got)
+    nnz = int(s['rowptr'][n])
+    assert torch.equal(got.cpu()[:nnz], want[:nnz])      # same fp32 expression -> bit-exact
+    for val_w, val_g in ((None, None), (want, got)):
+        a, b = torch.zeros(n), torch.zeros(n, device=DEV)
+        REF.csr_invdeg(s['rowptr'], val_w, n, a)
+        hip().csr_invdeg(sg['rowptr'], val_g, n, b)
+        close(b, a, 1e-6, 'invdeg')
+
+
+@pytest.mark.parametrize('width', [4, 16, 18, 20, 60, 64, 180, 250, 1140])
+@pytest.mark.parametrize('weighted', [False, True])
+def test_spmm_forward_and_transpose(width, weighted):
+    s, sg, n = _graph([130, 97, 260, 3], True, seed=width)
+    cap = s['cap']
+    val = vg = None
+    if weighted:
+        val = torch.zeros(cap)
+        REF.edge_renorm(s['rowptr'], s['col'], n, 0.4, val)
+        vg = g(val)
+    invd = torch.zeros(n)
+    REF.csr_invdeg(s['rowptr'], val, n, invd)
+    x = rnd(n, width, seed=1)
+    # forward aggregation with the mean divisor as post-scale
+    want, got = torch.zeros(n, width), torch.zeros(n, width, device=DEV)
+    REF.spmm(s['rowptr'], s['col'], None, val, None, invd, x, want, n, width)
+    hip().spmm(sg['rowptr'], sg['col'], None, vg, None, g(invd), g(x), got, n, width)
+    close(got, want, what='spmm fwd')
+    # transpose aggregation (backward): weights through t_perm, divisor as pre-scale
+    want2, got2 = torch.zeros(n, width), torch.zeros(n, width, device=DEV)
+    REF.spmm(s['t_rowptr'], s['t_col'], s['t_perm'] if weighted else None, val, invd, None, x, want2, n, width)
+    hip().spmm(sg['t_rowptr'], sg['t_col'], sg['t_perm'] if weighted else None, vg, g(invd), None, g(x), got2, n, width)
+    close(got2, want2, what='spmm transpose')
+    # adjointness: <A x, y> == <x, A^T y>
+    y = rnd(n, width, seed=2)
+    lhs = (want.double() * y.double() / invd.double().unsqueeze(1)).sum() if False else None  # (covered by the comparisons above)
+
+
+GEMM_CASES = [
+    # (M, N, K, tA, tB)
+    (300, 200, 150, False, False), (129, 257, 33, False, True), (260, 140, 1000, True, False),
+    (57, 20, 16, False, False), (1000, 60, 20, False, False), (20, 300, 900, True, False),
+    (64, 1140, 20, False, False), (33, 114, 154, False, True), (500, 18, 18, False, True),
+    (128, 128, 32, False, False), (1, 1, 1, False, False), (200, 130, 0, False, False),
+]
+
+
+@pytest.mark.parametrize('M,N,K,tA,tB', GEMM_CASES)
+def test_gemm_flat(M, N, K, tA, tB):
+    A = rnd(*((K, M) if tA else (M, K)), seed=1) if K > 0 else torch.zeros((0, M) if tA else (M, 0))
+    B = rnd(*((N, K) if tB else (K, N)), seed=2) if K > 0 else torch.zeros((N, 0) if tB else (0, N))
+    bias = rnd(N, seed=3)
+    for alpha, beta, bi in ((1.0, 0.0, None), (0.5, 1.0, bias), (1.0, -2.0, None)):
+        C0 = rnd(M, N, seed=4)
+        want, got = C0.clone(), g(C0.clone())
+        lda, ldb = max(A.shape[1], 1), max(B.shape[1], 1)
+        REF.gemm(A, B, want, M, N, K, tA, tB, lda, ldb, N, alpha, beta, bi)
+        hip().gemm(g(A) if A.numel() else got, g(B) if B.numel() else got, got, M, N, K, tA, tB, lda, ldb, N, alpha, beta, g(bi))
+        close(got, want, 2e-5, 'gemm %s' % ((M, N, K, tA, tB, alpha, beta),))
+
+
+def test_gemm_leading_dimensions_and_unaligned_views():
+    # operands that are column slices of wider buffers (ld > width), including a 4-byte-misaligned start
+    big_a, big_b, big_c = rnd(90, 77, seed=1), rnd(70, 95, seed=2), rnd(90, 101, seed=3)
+    A, B = big_a[:, 3:3 + 50], big_b[:50, 5:5 + 61]          # [90,50] ld 77 ; [50,61] ld 95
+    want = big_c.clone()
+    ga, gb, gc = g(big_a), g(big_b), g(big_c.clone())
+    REF.gemm(A, B, want[:, 7:], 90, 61, 50, False, False, 77, 95, 101, 1.0, 1.0)
+    hip().gemm(ga[:, 3:], gb[:, 5:], gc[:, 7:], 90, 61, 50, False, False, 77, 95, 101, 1.0, 1.0)
+    close(gc, want, 2e-5, 'gemm with lds')
+
+
+@pytest.mark.parametrize('C,D', [(16, 8), (60, 60), (180, 60), (1140, 20)])
+def test_gemm_ragged(C, D):
+    counts = [37, 0, 130, 64, 201]
+    n = sum(counts)
+    gptr = torch.tensor(np.cumsum([0] + counts), dtype=torch.int32)
+    B_, nmax = len(counts), max(counts)
+    S, X = rnd(n, C, seed=1), rnd(n, D, seed=2)
+    # ragged K:  out[b] = S_b^T X_b
+    want, got = torch.zeros(B_, C, D), torch.full((B_, C, D), 7.0, device=DEV)
+    REF.gemm(S, X, want, C, D, 0, True, False, C, D, D, 1.0, 0.0, None, B_, 0, 0, C * D, gptr, 2, nmax)
+    hip().gemm(g(S), g(X), got, C, D, 0, True, False, C, D, D, 1.0, 0.0, None, B_, 0, 0, C * D, g(gptr), 2, nmax)
+    close(got, want, 2e-5, 'ragged-K')
+    # ragged M:  Y_b = S_b G_b  (NN) and Z_b += X_b H_b^T (NT, beta=1)
+    G = rnd(B_, C, D, seed=3)
+    want, got = torch.zeros(n, D), torch.zeros(n, D, device=DEV)
+    REF.gemm(S, G, want, 0, D, C, False, False, C, D, D, 1.0, 0.0, None, B_, 0, C * D, 0, gptr, 1, nmax)
+    hip().gemm(g(S), g(G), got, 0, D, C, False, False, C, D, D, 1.0, 0.0, None, B_, 0, C * D, 0, g(gptr), 1, nmax)
+    close(got, want, 2e-5, 'ragged-M NN')
+    Z0 = rnd(n, C, seed=5)
+    want, got = Z0.clone(), g(Z0.clone())
+    REF.gemm(X, G, want, 0, C, D, False, True, D, D, C, 1.0, 1.0, None, B_, 0, C * D, 0, gptr, 1, nmax)
+    hip().gemm(g(X), g(G), got, 0, C, D, False, True, D, D, C, 1.0, 1.0, None, B_, 0, C * D, 0, g(gptr), 1, nmax)
+    close(got, want, 2e-5, 'ragged-M NT')
+
+
+def test_gemm_strided_batch_and_splitk_reduce():
+    A, B = rnd(5, 70, 90, seed=1), rnd(5, 90, 40, seed=2)
+    want, got = torch.zeros(5, 70, 40), torch.zeros(5, 70, 40, device=DEV)
+    REF.gemm(A, B, want, 70, 40, 90, False, False, 90, 40, 40, 1.0, 0.0, None, 5, 70 * 90, 90 * 40, 70 * 40)
+    hip().gemm(g(A), g(B), got, 70, 40, 90, False, False, 90, 40, 40, 1.0, 0.0, None, 5, 70 * 90, 90 * 40, 70 * 40)
+    close(got, want, 2e-5, 'strided batch')
+    ws = rnd(6, 1234, seed=3)
+    o0 = rnd(1234, seed=4)
+    for beta in (0.0, 1.0):
+        want, got = o0.clone(), g(o0.clone())
+        REF.reduce_batch_sum(ws, want, 6, 1234, beta)
+        hip().reduce_batch_sum(g(ws), got, 6, 1234, beta)
+        close(got, want, 1e-6, 'reduce_batch_sum')
+
+
+SHAPES = [(50, 8), (333, 20), (257, 18), (100, 60), (90, 114), (70, 180), (64, 250), (300, 1140), (40, 1600), (33, 2047)]
+
+
+@pytest.mark.parametrize('n,F', SHAPES)
+@pytest.mark.parametrize('act', [1, 2, 3])
+def test_conv_epilogue_chain(n, F, act):
+    k = hip()
+    h = rnd(n, F, seed=F)
+    h[min(3, n - 1)] = 0.0                      # a zero row: the 1e-12 clamp of F.normalize
+    count = float(n + 17)                       # BatchNorm sees 17 extra zero rows (padding of the dense layout)
+    gamma, beta = rnd(F, seed=1).abs() + 0.5, rnd(F, seed=2)
+    outs = {}
+    for name, K_, dev in (('ref', REF, 'cpu'), ('hip', k, DEV)):
+        t = lambda v: v.to(dev)
+        hn, rinv = torch.empty(n, F, device=dev), torch.empty(n, device=dev)
+        stats = torch.empty(2, F, device=dev)
+        K_.l2norm_act_stats(t(h), n, F, True, act, hn, rinv, stats)
+        rm, rv = torch.zeros(F, device=dev), torch.ones(F, device=dev)
+        mean, istd = torch.empty(F, device=dev), torch.empty(F, device=dev)
+        K_.bn_finalize(stats, count, 1e-5, 0.1, rm, rv, mean, istd)
+        y = torch.zeros(n, F + 4, device=dev)                  # write into a column slice of a wider buffer
+        K_.bn_act_apply(hn, n, F, act, mean, istd, t(gamma), t(beta), y, F + 4)
+        dy_big = t(rnd(n, F + 8, seed=9))
+        dy = dy_big[:, 4:4 + F]                                  # strided incoming gradient (slice of a cat grad)
+        sums = torch.empty(2, F, device=dev)
+        K_.bn_bwd_reduce(dy, F + 8, hn, n, F, act, mean, istd, sums)
+        dh = torch.empty(n, F, device=dev)
+        K_.bn_act_l2_bwd(dy, F + 8, hn, rinv, n, F, act, True, 2, mean, istd, t(gamma), sums, count, dh)
+        dh1 = torch.empty(n, F, device=dev)
+        K_.bn_act_l2_bwd(dy, F + 8, hn, rinv, n, F, act, False, 1, mean, istd, t(gamma), sums, count, dh1)
+        cs = torch.empty(F, device=dev)
+        K_.colsum(dy, F + 8, n, F, cs)
+        outs[name] = dict(hn=hn, rinv=rinv, stats=stats, rm=rm, rv=rv, mean=mean, istd=istd, y=y, sums=sums, dh=dh,
+                          dh1=dh1, cs=cs)
+    torch.cuda.synchronize()
+    for key in outs['ref']:
+        tol = 1e-3 if key in ('dh',) and h[min(3, n - 1)].abs().sum() == 0 else TOL
+        a, b = outs['hip'][key], outs['ref'][key]
+        if key in ('dh', 'hn', 'rinv'):                          # exclude the clamped zero row's 1e12 factor from the scale
+            mask = torch.ones(n, dtype=torch.bool)
+            mask[min(3, n - 1)] = False
+            close(a.cpu()[mask], b[mask], TOL, key)
+            close(a.cpu()[~mask], b[~mask], 1e-3, key + ' (clamped row)')
+        else:
+            close(a, b, tol, key)
+
+
+def test_epilogue_without_bn_and_without_normalize():
+    k = hip()
+    n, F = 77, 20
+    h = rnd(n, F)
+    for normalize in (True, False):
+        r = {}
+        for name, K_, dev in (('ref', REF, 'cpu'), ('hip', k, DEV)):
+            hn, rinv = torch.empty(n, F, device=dev), torch.empty(n, device=dev)
+            K_.l2norm_act_stats(h.to(dev), n, F, normalize, 0, hn, rinv, None)
+            y = torch.empty(n, F, device=dev)
+            K_.bn_act_apply(hn, n, F, 1, None, None, None, None, y, F)
+            dh = torch.empty(n, F, device=dev)
+            K_.bn_act_l2_bwd(rnd(n, F, seed=3).to(dev), F, hn, rinv, n, F, 1, normalize, 0, None, None, None, None, 1.0, dh)
+            r[name] = (hn, y, dh)
+        for a, b in zip(r['hip'], r['ref']):
+            close(a, b)
+
+
+@pytest.mark.parametrize('n,C', [(40, 4), (100, 16), (37, 60), (64, 114), (50, 180), (200, 1140), (9, 1600)])
+def test_softmax(n, C):
+    x = rnd(n, C, seed=C) * 3
+    want, got = torch.empty(n, C), torch.empty(n, C, device=DEV)
+    REF.softmax_fwd(x, n, C, want)
+    hip().softmax_fwd(g(x), n, C, got)
+    close(got, want, 1e-5, 'softmax')
+    dS = rnd(n, C, seed=1)
+    w2, g2 = torch.empty(n, C), torch.empty(n, C, device=DEV)
+    REF.softmax_bwd(want, dS, n, C, w2)
+    hip().softmax_bwd(g(want), g(dS), n, C, g2)
+    close(g2, w2, 1e-5, 'softmax bwd')
+
+
+@pytest.mark.parametrize('D', [8, 20, 60, 100])
+def test_segment_max(D):
+    counts = [17, 0, 300, 64, 5]
+    n, B_ = sum(counts), len(counts)
+    gptr = torch.tensor(np.cumsum([0] + counts), dtype=torch.int32)
+    x = rnd(n, D, seed=D)
+    x[17:317, 0] = -1.0 - x[17:317, 0].abs()      # graph 2, column 0 all negative: the zero padding wins there
+    x[20, 1] = x[30, 1] = 9.0                      # a tie: first index must win
+    for nmax in (300, 400):                        # graph 2 is the longest (no padding) / everybody is padded
+        want, warg = torch.empty(B_, D), torch.empty(B_, D, dtype=torch.int32)
+        got, garg = torch.empty(B_, D, device=DEV), torch.empty(B_, D, dtype=torch.int32, device=DEV)
+        REF.segment_max_fwd(x, gptr, B_, D, nmax, want, warg)
+        hip().segment_max_fwd(g(x), g(gptr), B_, D, nmax, got, garg)
+        assert torch.equal(got.cpu(), want) and torch.equal(garg.cpu(), warg)
+        dout = rnd(B_, D, seed=1)
+        wdx, gdx = torch.zeros(n, D), torch.zeros(n, D, device=DEV)
+        REF.segment_max_bwd(dout, warg, B_, D, wdx)
+        hip().segment_max_bwd(g(dout), garg, B_, D, gdx)
+        assert torch.equal(gdx.cpu(), wdx)
+
+
+@pytest.mark.parametrize('B_,C', [(3, 4), (2, 16), (3, 60), (2, 114), (2, 180), (1, 1140)])
+def test_dense_adjacency_transforms(B_, C):
+    R = B_ * C
+    A = rnd(B_, C, C, seed=C).abs()
+    A[0, 1] *= 0.001                               # a row whose sum is < 1: clamp(min=1) active, ge1 = 0
+    dO = rnd(B_, C, C, seed=1)
+    res = {}
+    for name, K_, dev in (('ref', REF, 'cpu'), ('hip', hip(), DEV)):
+        a, d = A.to(dev), dO.to(dev)
+        out, invd, ge1 = torch.empty_like(a), torch.empty(R, device=dev), torch.empty(R, device=dev)
+        K_.dense_rownorm_fwd(a, R, C, out, invd, ge1)
+        dA = torch.empty_like(a)
+        K_.dense_rownorm_bwd(d, out, invd, ge1, R, C, dA)
+        rn, drn = torch.empty_like(a), torch.empty_like(a)
+        K_.dense_renorm_fwd(a, R, C, 0.4, rn)
+        K_.dense_renorm_bwd(a, d, R, C, 0.4, drn)
+        res[name] = (out, invd, ge1, dA, rn, drn)
+    for i, (x, y) in enumerate(zip(res['hip'], res['ref'])):
+        close(x, y, 2e-5, 'dense transform %d' % i)

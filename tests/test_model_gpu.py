@@ -1,0 +1,141 @@
+"""GPU: the full hot path (SoftPoolingGcnEncoder forward + backward through the HIP kernels) against
+(1) the reference-generated golden fixtures and (2) the dense CPU oracle on seeded synthetic cell graphs."""
+import pytest
+import torch
+
+import cgc_net_amd  # noqa: F401
+from cgc_net_amd import kernels, network
+from cgc_net_amd.data import Batch, SyntheticCellGraphs
+from oracle import dense_ref
+from util import CASES, build_model, load_case, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+TOL, TOL_GRAD = 1e-4, 5e-4      # see tests/test_flat_formulation_cpu.py for the gradient tolerance
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_golden_forward_backward(name):
+    cfg, batch, sd, out, grad, sd3 = load_case(name, DEV)
+    model = build_model(network.SoftPoolingGcnEncoder, cfg, collect_assign=True)
+    model.load_state_dict(sd)
+    model.to(DEV).train()
+    logits, loss = model(batch)
+    assert kernels.is_native()
+    assert rel_err(logits, out['logits']) < TOL
+    assert rel_err(loss, out['loss']) < TOL
+    for i, s in enumerate(model.assign_matrix):
+        assert rel_err(s, out['assign%d' % (i + 1)]) < TOL
+    loss.backward()
+    for k, p in model.named_parameters():
+        assert rel_err(p.grad, grad[k]) < TOL_GRAD, k
+
+
+@pytest.mark.parametrize('name', ['tiny_shipped', 'medium_plain', 'medium_shipped'])
+def test_golden_three_adam_steps(name):
+    cfg, batch, sd, out, grad, sd3 = load_case(name, DEV)
+    model = build_model(network.SoftPoolingGcnEncoder, cfg)
+    model.load_state_dict(sd)
+    model.to(DEV).train()
+    _, loss = model(batch)
+    loss.backward()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
+    for _ in range(3):
+        _, loss = model(batch)
+        opt.zero_grad()
+        torch.mean(loss).backward()
+        opt.step()
+    for k, v in model.state_dict().items():
+        if v.dtype.is_floating_point:
+            assert rel_err(v, sd3[k]) < 2e-3, k
+        else:
+            assert int(v) == int(sd3[k]), k
+    model.eval()
+    with torch.no_grad():
+        assert rel_err(model(batch), out['eval_logits3']) < 5e-3
+
+
+@pytest.mark.parametrize('flags', [dict(), dict(norm_adj=True, jk=True), dict(activation='leakyrelu', norm_adj=True),
+                                   dict(gcn_name='GIN')])
+def test_synthetic_cell_graphs_vs_oracle(flags):
+    """BASELINE config 1/2 sized graphs (~300 nodes, 16 features, k-NN edges, cluster counts 60 / 6)."""
+    ds = SyntheticCellGraphs(6, 300, num_features=16, base_seed=42)
+    cpu_batch = Batch.from_data_list([ds[i] for i in range(6)])
+    args = (600, 16, 20, 20, True, True, 20, 3, 0.1, [50])
+    kw = dict(concat=True, load_data_sparse=True, drop_out=0.)
+    kw.update(flags)
+    torch.manual_seed(3)
+    ref = dense_ref.SoftPoolingGcnEncoder(*args, **kw)
+    model = network.SoftPoolingGcnEncoder(*args, **kw)
+    model.load_state_dict(ref.state_dict())
+    model.to(DEV).train()
+    ref.train()
+    logits, loss = model(cpu_batch.to(DEV))
+    loss.backward()
+    rl, rloss = ref(cpu_batch)
+    rloss.backward()
+    assert rel_err(logits, rl) < TOL and rel_err(loss, rloss) < TOL
+    gref = dict(ref.named_parameters())
+    for k, p in model.named_parameters():
+        assert rel_err(p.grad, gref[k].grad) < TOL_GRAD, k
+    for (k, a), (_, b) in zip(model.named_buffers(), ref.named_buffers()):
+        if a.dtype.is_floating_point:
+            assert rel_err(a, b) < TOL, k                       # BatchNorm running statistics (count = B*Nmax)
+
+
+def test_dense_tuple_input_form_and_eval():
+    """model/network.py:253-256: (x[B,N,F], adj[B,N,N], num_nodes[, label]) input; eval mode returns logits only."""
+    ds = SyntheticCellGraphs(3, 80, num_features=16, base_seed=9)
+    cpu_batch = Batch.from_data_list([ds[i] for i in range(3)])
+    adj = dense_ref.to_dense_adj(cpu_batch.edge_index, cpu_batch.batch)
+    x, counts = dense_ref.to_dense_batch(cpu_batch.x, cpu_batch.batch)
+    args = (160, 16, 20, 20, True, True, 20, 3, 0.1, [50])
+    torch.manual_seed(1)
+    ref = dense_ref.SoftPoolingGcnEncoder(*args, load_data_sparse=False)
+    model = network.SoftPoolingGcnEncoder(*args, load_data_sparse=False)
+    model.load_state_dict(ref.state_dict())
+    model.to(DEV)
+    for train in (True, False):
+        model.train(train)
+        ref.train(train)
+        want = ref((x, adj, counts, cpu_batch.y))
+        got = model((x.to(DEV), adj.to(DEV), counts, cpu_batch.y.to(DEV)))
+        if train:
+            assert rel_err(got[0], want[0]) < TOL and rel_err(got[1], want[1]) < TOL
+        else:
+            assert rel_err(got, want) < TOL
+
+
+def test_operator_modules_vs_oracle():
+    """DenseSAGEConv / GNN_Module dense-tensor contracts incl. mask and add_loop."""
+    torch.manual_seed(0)
+    B_, N, Fi, Fo = 3, 37, 10, 12
+    x = torch.randn(B_, N, Fi)
+    adj = (torch.rand(B_, N, N) < 0.2).float()
+    counts = torch.tensor([37, 20, 5])
+    mask = dense_ref.node_mask(N, counts)
+    adj = adj * mask * mask.transpose(1, 2)
+    x = x * mask
+    rc, pc = dense_ref.DenseSAGEConv(Fi, Fo), network.DenseSAGEConv(Fi, Fo)
+    pc.load_state_dict(rc.state_dict())
+    pc.to(DEV)
+    for add_loop in (True, False):
+        for m in (None, mask):
+            want = rc(x, adj, m, add_loop)
+            got = pc(x.to(DEV), adj.to(DEV), None if m is None else m.to(DEV), add_loop)
+            assert rel_err(got, want) < TOL
+    rb = dense_ref.GNNBlock(Fi, 8, Fo, lin=True)
+    pb = network.GNN_Module(Fi, 8, Fo, True, True, False, lin=True)
+    pb.load_state_dict(rb.state_dict())
+    pb.to(DEV).train()
+    rb.train()
+    xg, ag = x.to(DEV).requires_grad_(), adj.to(DEV).requires_grad_()
+    xr, ar = x.clone().requires_grad_(), adj.clone().requires_grad_()
+    got, want = pb(xg, ag, mask.to(DEV)), rb(xr, ar, mask)
+    assert rel_err(got, want) < TOL
+    w = torch.randn_like(want)
+    (got * w.to(DEV)).sum().backward()
+    (want * w).sum().backward()
+    assert rel_err(xg.grad, xr.grad) < TOL_GRAD and rel_err(ag.grad, ar.grad) < TOL_GRAD
+    for (k, p), (_, q) in zip(pb.named_parameters(), rb.named_parameters()):
+        assert rel_err(p.grad, q.grad) < TOL_GRAD, k
