@@ -187,7 +187,7 @@ class HipKernels(KernelSpec):
     # -- graph structure
     def csr_build(self, edge_index, n, add_diag):
         self._dev(edge_index)
-        assert edge_index.dtype == torch.int64 and edge_index.is_contiguous()
+        edge_index = edge_index.to(torch.int64).contiguous()
         E = edge_index.shape[1]
         cap = E + (n if add_diag else 0)
         dev = edge_index.device

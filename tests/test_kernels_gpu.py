@@ -86,7 +86,8 @@ def test_csr_presorted_knn_input():
     want, got = build_both(b.edge_index, n, False)
     nnz = int(want['rowptr'][n])
     assert nnz == b.edge_index.shape[1]           # k-NN output has no duplicates
-    assert torch.equal(got['col'].cpu()[:nnz], b.edge_index[1].int())   # already row-major sorted
+    key = torch.sort(b.edge_index[0] * n + b.edge_index[1])[0]          # k-NN rows are ascending, columns by distance
+    assert torch.equal(got['col'].cpu()[:nnz].long(), key % n) and torch.equal(got['rowidx'].cpu()[:nnz].long(), key // n)
     assert torch.equal(got['rowptr'].cpu(), want['rowptr'])
 
 
