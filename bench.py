@@ -1,0 +1,230 @@
+#!/usr/bin/env python
+"""Benchmark of the CGC-Net hot path on MI355X: cell-graphs/sec, forward + backward (+ Adam step), batch 32.
+
+Contract: ``python bench.py --gpus N --steps K --warmup W`` (N>1 is launched by torch.distributed.run, one rank per
+GPU over RCCL) prints ONE JSON line on rank 0.  A "step" is one pass of the hot path over one batch of synthetic
+cell graphs that is already resident in HBM: CSR build from ``edge_index`` (the reference densifies here), the full
+SoftPoolingGcnEncoder forward, cross-entropy, backward through every kernel, gradient all-reduce (N>1), Adam.
+
+Workload (BASELINE.json configs[2], SURVEY.md 8(d) "C3"): 32 graphs per GPU, ~1800 nodes / ~16k edges / 16 features
+each, cluster counts fixed by the reference's ``setting.max_num_nodes`` = 11404 -> C1 = 1140, C2 = 114
+(setting.py:15, train.py:254).  ``--maxn 1800`` gives the "clusters proportional to the graph" variant (C1 = 180).
+
+Extra objects on the line:
+  roofline            dominant kernel = the 128x128 fp32-MFMA GEMM (bound "mfma", peak 157.3 TFLOP/s): algorithmic
+                      flops of each launch / HIP-event duration of that launch, measured inside the timed region
+  roofline_aggregation  the wide neighbour-aggregation SpMM A*S ("K4", bound "hbm", peak 8000 GB/s): algorithmic
+                      bytes 4(n+1) + 4 nnz (+4 nnz weighted) + 8 n W per launch / HIP-event duration
+  cpu_baseline        the dense CPU oracle (the reference's algorithm incl. densification; oracle/dense_ref.py)
+                      timed on the host cores, rank 0, N=1 only, on a bounded sample of the same workload
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MFMA_F32_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: peak FP32 (matrix)
+HBM_PEAK_GBS = 8000.0            # HBM3E spec peak (6.29 TB/s measured float4 copy)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument('--gpus', type=int, default=1)
+    p.add_argument('--steps', type=int, default=20)
+    p.add_argument('--warmup', type=int, default=5)
+    p.add_argument('--batch', type=int, default=32, help='graphs per GPU per step')
+    p.add_argument('--nodes', type=int, default=1800, help='mean nodes per graph')
+    p.add_argument('--feat', type=int, default=16)
+    p.add_argument('--maxn', type=int, default=11404, help="the reference's setting.max_num_nodes (fixes cluster counts)")
+    p.add_argument('--flags', choices=['plain', 'shipped'], default='plain',
+                   help="'shipped' = parallel_train.sh: --jk --norm_adj --drop 0.2")
+    p.add_argument('--pool', type=int, default=4, help='distinct resident batches cycled through')
+    p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--cpu-seconds', type=float, default=12.0, help='CPU baseline: stop after this much timed work')
+    p.add_argument('--no-kernel-timing', action='store_true', help='do not record per-launch HIP events')
+    return p.parse_args()
+
+
+def make_model(args, module):
+    kw = dict(concat=True, gcn_name='SAGE', load_data_sparse=True)
+    if args.flags == 'shipped':
+        kw.update(norm_adj=True, jk=True, drop_out=0.2)
+    return module.SoftPoolingGcnEncoder(args.maxn, args.feat, 20, 20, True, True, 20, 3, 0.1, [50], **kw)
+
+
+def usable_cores():
+    """Host cores this process may actually use: min(online CPUs, affinity mask, cgroup CPU quota)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+        try:
+            txt = open(path).read().split()
+            if path.endswith('cpu.max'):
+                if txt[0] != 'max':
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    period = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+                    n = min(n, max(1, q // period))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
+def cpu_baseline(args, batches):
+    """The dense oracle = the reference's algorithm on the host: densify -> dense convs -> DiffPool -> CE,
+    fwd + bwd + Adam, same seeded graphs, all host cores."""
+    from oracle import dense_ref
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    model = make_model(args, dense_ref)
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
+
+    def step(b):
+        _, loss = model(b)
+        opt.zero_grad()
+        loss.mean().backward()
+        opt.step()
+    step(batches[0])                       # warm-up (allocator, thread pool)
+    t0, n_steps = time.perf_counter(), 0
+    while True:
+        step(batches[n_steps % len(batches)])
+        n_steps += 1
+        el = time.perf_counter() - t0
+        if el >= args.cpu_seconds or n_steps >= 8:
+            break
+    return {'value': round(args.batch * n_steps / el, 3), 'unit': 'graphs/s', 'cores': torch.get_num_threads(),
+            'kind': 'port', 'host': '%d logical CPUs online, %d usable (affinity/cgroup quota)' % (os.cpu_count() or 1, cores),
+            'sample': '%d timed fwd+bwd+Adam steps of batch %d after 1 warm-up (%.1f s), dense oracle/dense_ref.py, '
+                      'same workload' % (n_steps, args.batch, el)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus and world > 1:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit('launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=dev)
+
+    import cgc_net_amd  # noqa: F401
+    from cgc_net_amd import kernels, network
+    from cgc_net_amd.data import Batch, SyntheticCellGraphs
+    from cgc_net_amd.parallel import DataParallel
+
+    # ---- synthetic workload: `pool` distinct batches per rank, seeded by rank, resident in HBM
+    ds = SyntheticCellGraphs(args.pool * args.batch, args.nodes, args.feat, base_seed=100000 * rank)
+    cpu_batches = [Batch.from_data_list([ds[b * args.batch + i] for i in range(args.batch)]) for b in range(args.pool)]
+    batches = [b.to(dev) for b in cpu_batches]
+    nodes = sum(b.x.shape[0] for b in cpu_batches) / len(cpu_batches)
+    edges = sum(b.edge_index.shape[1] for b in cpu_batches) / len(cpu_batches)
+
+    torch.manual_seed(0)
+    model = make_model(args, network).to(dev)
+    model.train()
+    dp = DataParallel(model) if world > 1 else model
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
+
+    def step(b):
+        _, loss = dp(b)
+        loss = torch.mean(loss)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        return loss
+
+    for i in range(args.warmup):
+        step(batches[i % len(batches)])
+    K = kernels.get()
+    timer = None if args.no_kernel_timing else kernels.LaunchTimer()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    K.timer = timer
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(batches[i % len(batches)])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    K.timer = None
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if not torch.isfinite(loss).item():
+        raise SystemExit('non-finite loss')
+
+    if rank == 0:
+        graphs = args.batch * world * args.steps
+        c1 = int(args.maxn * 0.1)
+        out = {
+            'metric': 'cell-graphs/sec (fwd+bwd), batch=32, ~1800 nodes/16 feat',
+            'value': round(graphs / elapsed, 2), 'unit': 'graphs/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 3), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'C3: full CGC-Net (3 conv blocks + 2 DiffPool) fwd+bwd+Adam, %d graphs/GPU/step, '
+                                   '~%d nodes, ~%d edges/graph, %d feat, max_num_nodes=%d (C1=%d, C2=%d), flags=%s'
+                                   % (args.batch, round(nodes / args.batch), round(edges / args.batch), args.feat,
+                                      args.maxn, c1, int(c1 * 0.1), args.flags),
+                       'global_batch': args.batch * world, 'nodes_per_batch': round(nodes),
+                       'parallelism': 'dp%d' % world, 'includes': 'CSR build + fwd + loss + bwd + grad all-reduce + Adam'},
+        }
+        if timer is not None:
+            s = timer.summary()
+            if 'gemm_128x128' in s:
+                g = s['gemm_128x128']
+                tf = g['rate'] / 1e12
+                out['roofline'] = {'kernel': 'k_gemm_f32<2,2,2,2> (fp32 MFMA 32x32x2, 128x128x32 tile)', 'bound': 'mfma',
+                                   'achieved': round(tf, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                                   'frac': round(tf / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': None,
+                                   'launches_per_step': g['launches'] / args.steps, 'avg_launch_ms': round(g['avg_ms'], 4),
+                                   'gflop_per_launch': round(g['work_per_launch'] / 1e9, 3),
+                                   'ms_per_step': round(g['total_ms'] / args.steps, 3)}
+            if 'spmm_wide' in s:
+                g = s['spmm_wide']
+                # algorithmic bytes per launch: 8 n W (read X once, write Y once) + 4(n+1) + 4 nnz (+ 4 nnz weights)
+                idx = 4.0 * (nodes + 1) + (8.0 if args.flags == 'shipped' else 4.0) * (edges + (nodes if args.flags == 'shipped' else 0))
+                bytes_per_launch = g['work_per_launch'] + idx
+                gbs = bytes_per_launch / (g['avg_ms'] * 1e-3) / 1e9
+                out['roofline_aggregation'] = {'kernel': 'k_spmm (A*S and its transpose, width %d)' % c1, 'bound': 'hbm',
+                                               'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                               'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': None,
+                                               'launches_per_step': g['launches'] / args.steps,
+                                               'avg_launch_ms': round(g['avg_ms'], 4),
+                                               'mb_per_launch': round(bytes_per_launch / 1e6, 2)}
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(args, cpu_batches)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

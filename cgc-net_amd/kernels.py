@@ -50,13 +50,14 @@ class KernelSpec(object):
 
     # ------------------------------------------------------------------ dense contractions (MFMA fp32)
     def gemm(self, A, B, C, M, N, K, transA, transB, lda, ldb, ldc, alpha=1.0, beta=0.0, bias=None,
-             batch=1, strideA=0, strideB=0, strideC=0, gptr=None, ragged=0, max_ragged=0):
+             batch=1, strideA=0, strideB=0, strideC=0, gptr=None, ragged=0, max_ragged=0, ragged_total=0):
         """C_b = alpha * op(A_b) op(B_b) + beta * C_b (+ bias[N]),  b = 0..batch-1, row-major.
 
         op(A) is M x K (stored [M,K] or, transA, [K,M]); op(B) is K x N (stored [K,N] or, transB, [N,K]).
         Operand b starts at base + b*stride (+ ragged offset).  ragged=1: M_b = gptr[b+1]-gptr[b], A
         (not transposed) and C advance by gptr[b] rows.  ragged=2: K_b = gptr[b+1]-gptr[b], A (transposed)
-        and B (not transposed) advance by gptr[b] rows.  max_ragged bounds the ragged extent (grid size).
+        and B (not transposed) advance by gptr[b] rows.  max_ragged bounds the ragged extent (grid size);
+        ragged_total = sum of the ragged extents (host-side flop accounting only).
         """
         raise NotImplementedError
 
@@ -155,7 +156,38 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr() if t is not None else 0)
 
 
+class LaunchTimer(object):
+    """Optional HIP-event timing of selected launches (bench.py): events are recorded on the stream the
+    kernels are launched on (torch's current stream) and read back after the timed region."""
+
+    def __init__(self):
+        self.records = {}       # tag -> list of (start_event, end_event, work) ; work = flops or bytes of the launch
+
+    def begin(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def end(self, tag, start, work):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.records.setdefault(tag, []).append((start, e, work))
+
+    def summary(self):
+        """tag -> dict(launches, total_ms, avg_ms, work_per_launch, rate = work/s) (call after synchronize)."""
+        out = {}
+        for tag, recs in self.records.items():
+            ms = [s.elapsed_time(e) for s, e, _ in recs]
+            work = sum(w for _, _, w in recs)
+            tot = sum(ms)
+            out[tag] = dict(launches=len(recs), total_ms=tot, avg_ms=tot / len(recs), work_per_launch=work / len(recs),
+                            rate=work / (tot * 1e-3) if tot > 0 else 0.0)
+        return out
+
+
 class HipKernels(KernelSpec):
+    timer = None   # set to a LaunchTimer by bench.py during the timed region
+
     def __init__(self):
         path = lib_path()
         if not os.path.exists(path):
@@ -215,18 +247,32 @@ class HipKernels(KernelSpec):
     def spmm(self, rowptr, col, perm, val, pre, post, x, out, n, width):
         self._dev(rowptr, col, perm, val, pre, post, x, out)
         assert x.is_contiguous() and out.is_contiguous()
+        t0 = self.timer.begin() if (self.timer is not None and width > 64) else None
         self._chk(self.lib.cgc_spmm(_ptr(rowptr), _ptr(col), _ptr(perm), _ptr(val), _ptr(pre), _ptr(post),
                                     _ptr(x), _ptr(out), n, width, self._stream()), 'cgc_spmm')
+        if t0 is not None:      # work = (width, weighted): bench.py turns it into algorithmic bytes with the batch's nnz
+            self.timer.end('spmm_wide', t0, 8.0 * n * width)
 
     # -- dense contractions
     def gemm(self, A, B, C, M, N, K, transA, transB, lda, ldb, ldc, alpha=1.0, beta=0.0, bias=None,
-             batch=1, strideA=0, strideB=0, strideC=0, gptr=None, ragged=0, max_ragged=0):
+             batch=1, strideA=0, strideB=0, strideC=0, gptr=None, ragged=0, max_ragged=0, ragged_total=0):
         self._dev(A, B, C, bias, gptr)
+        t0 = None
+        if self.timer is not None and N > 64 and (max_ragged if ragged == 1 else M) > 64:
+            # algorithmic flops of this launch: 2*M*N*K summed over the batch (ragged extents sum to the row count)
+            if ragged:
+                flops = 2.0 * (M if ragged == 2 else K) * N * ragged_total
+            else:
+                flops = 2.0 * M * N * K * batch
+            if flops >= 1e9:
+                t0 = self.timer.begin()
         rc = self.lib.cgc_gemm_f32(int(transA), int(transB), M, N, K, ctypes.c_float(alpha), _ptr(A), lda,
                                    _ptr(B), ldb, ctypes.c_float(beta), _ptr(C), ldc, _ptr(bias), batch,
                                    ctypes.c_int64(strideA), ctypes.c_int64(strideB), ctypes.c_int64(strideC),
                                    _ptr(gptr), ragged, max_ragged, self._stream())
         self._chk(rc, 'cgc_gemm_f32')
+        if t0 is not None:
+            self.timer.end('gemm_128x128', t0, flops)
 
     def reduce_batch_sum(self, ws, out, parts, numel, beta=0.0):
         self._dev(ws, out)

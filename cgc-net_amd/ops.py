@@ -59,7 +59,7 @@ def gemm_tn_rows(A, lda, Fa, B, ldb, Fb, n, out, ldc=None, beta=0.0):
     ptr, chunk = _split_ptr(n, parts, A.device)
     ws = torch.empty(parts, Fa * Fb, dtype=torch.float32, device=A.device)
     K().gemm(A, B, ws, Fa, Fb, 0, True, False, lda, ldb, Fb, 1.0, 0.0, None,
-             parts, 0, 0, Fa * Fb, ptr, 2, chunk)
+             parts, 0, 0, Fa * Fb, ptr, 2, chunk, n)
     K().reduce_batch_sum(ws, out, parts, Fa * Fb, beta)
 
 
@@ -263,8 +263,8 @@ class _DiffPoolSparse(Function):
         xo = torch.empty(g.B, c, dx, dtype=torch.float32, device=dev)
         ao = torch.empty(g.B, c, c, dtype=torch.float32, device=dev)
         # ragged-K, transposed-A contractions: per graph  [c x N_b] . [N_b x (dx | c)]
-        K().gemm(s, embed, xo, c, dx, 0, True, False, c, dx, dx, 1.0, 0.0, None, g.B, 0, 0, c * dx, g.gptr, 2, g.nmax)
-        K().gemm(s, p, ao, c, c, 0, True, False, c, c, c, 1.0, 0.0, None, g.B, 0, 0, c * c, g.gptr, 2, g.nmax)
+        K().gemm(s, embed, xo, c, dx, 0, True, False, c, dx, dx, 1.0, 0.0, None, g.B, 0, 0, c * dx, g.gptr, 2, g.nmax, n)
+        K().gemm(s, p, ao, c, c, 0, True, False, c, c, c, 1.0, 0.0, None, g.B, 0, 0, c * c, g.gptr, 2, g.nmax, n)
         ctx.save_for_backward(embed, s, p)
         ctx.g = g
         return xo, ao
@@ -278,15 +278,15 @@ class _DiffPoolSparse(Function):
         dxo, dao = _f32c(dxo), _f32c(dao)
         # dP = S dA'   (ragged-M, NN)
         dp = torch.empty_like(s)
-        K().gemm(s, dao, dp, 0, c, c, False, False, c, c, c, 1.0, 0.0, None, g.B, 0, c * c, 0, g.gptr, 1, g.nmax)
+        K().gemm(s, dao, dp, 0, c, c, False, False, c, c, c, 1.0, 0.0, None, g.B, 0, c * c, 0, g.gptr, 1, g.nmax, n)
         # dS = A^T dP  (transpose SpMM) + P dA'^T + X dX'^T
         ds = torch.empty_like(s)
         K().spmm(g.t_rowptr, g.t_col, g.t_perm if g.val is not None else None, g.val, None, None, dp, ds, n, c)
-        K().gemm(p, dao, ds, 0, c, c, False, True, c, c, c, 1.0, 1.0, None, g.B, 0, c * c, 0, g.gptr, 1, g.nmax)
-        K().gemm(embed, dxo, ds, 0, c, dx, False, True, dx, dx, c, 1.0, 1.0, None, g.B, 0, c * dx, 0, g.gptr, 1, g.nmax)
+        K().gemm(p, dao, ds, 0, c, c, False, True, c, c, c, 1.0, 1.0, None, g.B, 0, c * c, 0, g.gptr, 1, g.nmax, n)
+        K().gemm(embed, dxo, ds, 0, c, dx, False, True, dx, dx, c, 1.0, 1.0, None, g.B, 0, c * dx, 0, g.gptr, 1, g.nmax, n)
         # dX = S dX'
         de = torch.empty_like(embed)
-        K().gemm(s, dxo, de, 0, dx, c, False, False, c, dx, dx, 1.0, 0.0, None, g.B, 0, c * dx, 0, g.gptr, 1, g.nmax)
+        K().gemm(s, dxo, de, 0, dx, c, False, False, c, dx, dx, 1.0, 0.0, None, g.B, 0, c * dx, 0, g.gptr, 1, g.nmax, n)
         return de, ds, None
 
 

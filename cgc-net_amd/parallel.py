@@ -80,6 +80,8 @@ class DataParallel(nn.Module):
     def forward(self, data_list):
         """data_list: python list of Data (the DataListLoader protocol).  Returns what the module returns
         for this rank's chunk: ``(logits, loss)`` in training mode, ``logits`` in eval mode."""
+        if hasattr(data_list, 'edge_index'):          # an already collated (device-resident) Batch of THIS rank
+            return self.module(data_list)
         if len(data_list) == 0:
             raise ValueError('empty batch')
         batch = Batch.from_data_list(self.local_chunk(data_list)).to(self.device)

@@ -105,7 +105,7 @@ class TorchKernels(KernelSpec):
 
     # ------------------------------------------------------------------ dense contractions
     def gemm(self, A, B, C, M, N, K, transA, transB, lda, ldb, ldc, alpha=1.0, beta=0.0, bias=None,
-             batch=1, strideA=0, strideB=0, strideC=0, gptr=None, ragged=0, max_ragged=0):
+             batch=1, strideA=0, strideB=0, strideC=0, gptr=None, ragged=0, max_ragged=0, ragged_total=0):
         if ragged == 1:
             assert not transA
         if ragged == 2:
