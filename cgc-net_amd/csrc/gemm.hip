@@ -9,11 +9,13 @@
 //
 // Tiling (wave = 64 lanes, 4 waves per workgroup = one per SIMD):
 //   block tile (WGM*TM*32) x (WGN*TN*32) x 32;  each wave owns TM x TN accumulators of 32x32 (16 VGPRs each);
-//   A and B tiles are staged through LDS k-major ([k][m] / [k][n]) so that an MFMA operand fetch is one conflict-free
-//   ds_read_b32 per lane (lane l reads element (l&31) of k-row (l>>5));  k-contiguous operands are transposed on the
-//   way in (row stride 32*x+1 words: conflict-free scalar writes), mn-contiguous ones are copied with 16-byte writes;
-//   global->register prefetch of tile t+1 overlaps the 16 k-steps (64 MFMA/wave at 128x128) on tile t; 2 LDS buffers,
-//   one barrier per k-tile.
+//   both operand tiles are copied into LDS with 16-byte writes in the orientation they have in memory -- no transposing
+//   scalar writes: an mn-contiguous operand (A stored [K,M], B stored [K,N]) lands k-major ([k][mn], row stride mn+4) and
+//   is fetched with four ds_read_b32 per 8 k; a k-contiguous operand (A stored [M,K], B stored [N,K]) lands row-major
+//   ([mn][k], row stride 36 words: conflict-free for ds_read_b128's 16-lane groups) and is fetched with ONE ds_read_b128
+//   per 8 k.  Both fetches hand lane l the k values 8*kb + 4*(l>>5) + {0,1,2,3}; MFMA t of the group consumes element t,
+//   i.e. the k-pair {8kb+t, 8kb+4+t} -- a permutation of the k order that A and B share, so the product is unchanged;
+//   global->register prefetch of tile t+1 overlaps the 64 MFMA/wave (128x128) on tile t; 2 LDS buffers, 1 barrier/k-tile.
 #include <type_traits>
 
 #include "common.hpp"
@@ -34,9 +36,10 @@ struct GemmArgs {
 };
 
 #define BK 32
+#define KC_LD 36   // LDS row stride (words) of a row-major [mn][k] tile: 16-byte aligned rows, conflict-free ds_read_b128
 
 // Loader for an operand tile whose K index is the CONTIGUOUS one in memory (A stored [M,K]; B stored [N,K]).
-// Logical tile: ROWS (m or n) x BK.  LDS image: [k][row], row stride LDS_LD = ROWS+1.
+// Logical tile: ROWS (m or n) x BK.  LDS image: [row][k], row stride KC_LD = 36 words.
 template <int ROWS>
 struct KContigLoader {
   static constexpr int UNITS = ROWS * (BK / 4);       // float4 units in the tile
@@ -65,19 +68,22 @@ struct KContigLoader {
       reg[i] = v;
     }
   }
-  __device__ __forceinline__ void store(float* __restrict__ lds) const {   // transpose: 4 scalar writes, conflict-free with LD = ROWS+1
-    constexpr int LD = ROWS + 1;
+  // Fast path for interior k-tiles: every unit is one aligned 16-byte load, no predication.  Rows beyond the matrix
+  // edge are CLAMPED to the last valid row: they only feed output rows/columns that are never stored.
+  __device__ __forceinline__ void load_fast(const float* __restrict__ base, int ld, int row0, int row_last, int k0) {
 #pragma unroll
     for (int i = 0; i < PER_T; ++i) {
       const int u = threadIdx.x + i * 256;
-      if (UNITS % 256 == 0 || u < UNITS) {
-        const int row = u / (BK / 4);
-        const int kq = (u % (BK / 4)) * 4;
-        lds[(kq + 0) * LD + row] = reg[i].x;
-        lds[(kq + 1) * LD + row] = reg[i].y;
-        lds[(kq + 2) * LD + row] = reg[i].z;
-        lds[(kq + 3) * LD + row] = reg[i].w;
-      }
+      const int row = min(row0 + u / (BK / 4), row_last);
+      reg[i] = *reinterpret_cast<const float4*>(base + (size_t)row * ld + k0 + (u % (BK / 4)) * 4);
+    }
+  }
+  __device__ __forceinline__ void store(float* __restrict__ lds) const {   // same orientation as memory: one 16-byte write per unit
+#pragma unroll
+    for (int i = 0; i < PER_T; ++i) {
+      const int u = threadIdx.x + i * 256;
+      if (UNITS % 256 == 0 || u < UNITS)
+        *reinterpret_cast<float4*>(&lds[(u / (BK / 4)) * KC_LD + (u % (BK / 4)) * 4]) = reg[i];
     }
   }
 };
@@ -112,6 +118,15 @@ struct MnContigLoader {
       reg[i] = v;
     }
   }
+  // Fast path (interior k-tile, extent % 4 == 0): columns beyond the edge are clamped to the last valid 16-byte group.
+  __device__ __forceinline__ void load_fast(const float* __restrict__ base, int ld, int col0, int col_last4, int k0) {
+#pragma unroll
+    for (int i = 0; i < PER_T; ++i) {
+      const int u = threadIdx.x + i * 256;
+      const int c = min(col0 + (u % (COLS / 4)) * 4, col_last4);
+      reg[i] = *reinterpret_cast<const float4*>(base + (size_t)(k0 + u / (COLS / 4)) * ld + c);
+    }
+  }
   __device__ __forceinline__ void store(float* __restrict__ lds) const {
     constexpr int LD = COLS + 4;
 #pragma unroll
@@ -126,13 +141,24 @@ struct MnContigLoader {
   }
 };
 
+// MFMA operand fragment for the 8 k's of group kb: lane (l31 = l&31, lhi = l>>5) gets k = 8*kb + 4*lhi + {0..3} of row/col l31.
+template <bool KMAJOR, int LD>
+__device__ __forceinline__ void fetch_frag(const float* __restrict__ tile, int kb, int l31, int lhi, float (&f)[4]) {
+  if (KMAJOR) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) f[t] = tile[(kb * 8 + lhi * 4 + t) * LD + l31];
+  } else {
+    const float4 v = *reinterpret_cast<const float4*>(&tile[l31 * LD + kb * 8 + lhi * 4]);
+    f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+  }
+}
+
 template <int WGM, int WGN, int TM, int TN, bool TA, bool TB>
 __global__ __launch_bounds__(256) void k_gemm_f32(const GemmArgs a) {
   constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
-  constexpr int LDA_S = TA ? BM + 4 : BM + 1;
-  constexpr int LDB_S = TB ? BN + 1 : BN + 4;
-  // sizes rounded so that every sub-array starts 16-byte aligned
-  constexpr int A_SZ = ((BK * LDA_S + 3) / 4) * 4, B_SZ = ((BK * LDB_S + 3) / 4) * 4;
+  constexpr int LDA_S = TA ? BM + 4 : KC_LD;   // TA: A stored [K,M] -> k-major tile; else row-major [m][k]
+  constexpr int LDB_S = TB ? KC_LD : BN + 4;   // TB: B stored [N,K] -> row-major [n][k]; else k-major
+  constexpr int A_SZ = TA ? BK * LDA_S : BM * KC_LD, B_SZ = TB ? BN * KC_LD : BK * LDB_S;   // multiples of 4 words
   __shared__ __attribute__((aligned(16))) float lds[2 * A_SZ + 2 * B_SZ];
   float* const As0 = lds;                 // As[buf] = As0 + buf*A_SZ
   float* const Bs0 = lds + 2 * A_SZ;      // Bs[buf] = Bs0 + buf*B_SZ
@@ -176,33 +202,41 @@ __global__ __launch_bounds__(256) void k_gemm_f32(const GemmArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nk = (K + BK - 1) / BK;
+  const int nk = (K + BK - 1) / BK, nk_full = K / BK;
+  // unguarded 16-byte loads for full k-tiles when the layout allows (block-uniform decision)
+  const bool fastA = vecA && (TA ? (M % 4 == 0 && M >= 4) : true);
+  const bool fastB = vecB && (TB ? true : (N % 4 == 0 && N >= 4));
+  const int a_last = TA ? M - 4 : M - 1, b_last = TB ? N - 1 : N - 4;
+  auto fetch = [&](int kt) {
+    if (fastA && kt < nk_full) la.load_fast(A, a.lda, m0, a_last, kt * BK);
+    else la.load(A, a.lda, m0, M, kt * BK, K, vecA);
+    if (fastB && kt < nk_full) lb.load_fast(B, a.ldb, n0, b_last, kt * BK);
+    else lb.load(B, a.ldb, n0, N, kt * BK, K, vecB);
+  };
   if (nk > 0) {
-    la.load(A, a.lda, m0, M, 0, K, vecA);
-    lb.load(B, a.ldb, n0, N, 0, K, vecB);
+    fetch(0);
     la.store(As0);
     lb.store(Bs0);
   }
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nk) {   // prefetch the next k-tile into registers while this one is consumed from LDS
-      la.load(A, a.lda, m0, M, (kt + 1) * BK, K, vecA);
-      lb.load(B, a.ldb, n0, N, (kt + 1) * BK, K, vecB);
-    }
-    const float* as = As0 + cur * A_SZ + wm * TM * 32 + l31;
-    const float* bs = Bs0 + cur * B_SZ + wn * TN * 32 + l31;
+    if (kt + 1 < nk) fetch(kt + 1);   // prefetch the next k-tile into registers while this one is consumed from LDS
+    const float* as = As0 + cur * A_SZ + (TA ? wm * TM * 32 : wm * TM * 32 * KC_LD);
+    const float* bs = Bs0 + cur * B_SZ + (TB ? wn * TN * 32 * KC_LD : wn * TN * 32);
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      float av[TM], bv[TN];
+    for (int kb = 0; kb < BK / 8; ++kb) {
+      float av[TM][4], bv[TN][4];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) av[i] = as[(kk + lhi) * LDA_S + i * 32];
+      for (int i = 0; i < TM; ++i) fetch_frag<TA, LDA_S>(as + (TA ? i * 32 : i * 32 * KC_LD), kb, l31, lhi, av[i]);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bv[j] = bs[(kk + lhi) * LDB_S + j * 32];
+      for (int j = 0; j < TN; ++j) fetch_frag<!TB, LDB_S>(bs + (TB ? j * 32 * KC_LD : j * 32), kb, l31, lhi, bv[j]);
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][t], bv[j][t], acc[i][j], 0, 0, 0);
     }
     if (kt + 1 < nk) {
       la.store(As0 + (cur ^ 1) * A_SZ);

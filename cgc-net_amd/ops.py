@@ -47,11 +47,32 @@ def _split_ptr(n, parts, device):
     return _SPLIT_CACHE[key]
 
 
+_RESIDENT_BLOCKS = 512      # 256 CUs x 2 workgroups (the GEMM's ~70 KB of LDS admits two per CU)
+
+
+def _split_parts(Fa, Fb, n, _cache={}):
+    """How many row slices to cut the reduction into: fill whole rounds of resident workgroups, >= 512 rows per slice."""
+    key = (Fa, Fb, n)
+    if key not in _cache:
+        tm = 32 if Fa <= 32 else 64 if Fa <= 64 else 128
+        tn = 32 if Fb <= 32 else 64 if Fb <= 64 else 128
+        tiles = (-(-Fa // tm)) * (-(-Fb // tn))
+        best, best_score = 1, -1.0
+        for parts in range(1, max(1, min(128, n // 512)) + 1):
+            blocks = tiles * parts
+            rounds = -(-blocks // _RESIDENT_BLOCKS)
+            fill = blocks / float(rounds * _RESIDENT_BLOCKS)          # occupancy of the rounds it takes
+            score = fill - 0.02 * rounds - (0.5 if blocks < 256 else 0.0)
+            if score > best_score + 1e-9:
+                best, best_score = parts, score
+        _cache[key] = best
+    return _cache[key]
+
+
 def gemm_tn_rows(A, lda, Fa, B, ldb, Fb, n, out, ldc=None, beta=0.0):
     """out[Fa,Fb] (ld ldc) = beta*out + A[:n,:Fa]^T @ B[:n,:Fb]; rows split over workgroups, combined deterministically."""
     ldc = Fb if ldc is None else ldc
-    tiles = (-(-Fa // 128)) * (-(-Fb // 128))
-    parts = max(1, min(-(-1024 // tiles), -(-n // 512)))
+    parts = _split_parts(Fa, Fb, n)
     if parts == 1 or ldc != Fb:
         # (strided destinations take the direct path; they only occur for small slices)
         K().gemm(A, B, out, Fa, Fb, n, True, False, lda, ldb, ldc, 1.0, beta)
