@@ -22,7 +22,8 @@ __global__ __launch_bounds__(1024) void k_exclusive_scan(const int* __restrict__
   const int per = (n + 1023) / 1024;
   const int lo = min(t * per, n), hi = min(lo + per, n);
   int s = 0;
-  for (int i = lo; i < hi; ++i) s += in[i];
+#pragma unroll 8
+  for (int i = lo; i < hi; ++i) s += in[i];     // independent loads: unrolled so that 8 are in flight
   // inclusive scan of the 1024 slice totals: wave scan, then scan of wave totals
   int incl = s;
   for (int o = 1; o < 64; o <<= 1) {
@@ -34,6 +35,7 @@ __global__ __launch_bounds__(1024) void k_exclusive_scan(const int* __restrict__
   int wbase = 0;
   for (int w = 0; w < wave; ++w) wbase += wave_tot[w];
   int run = wbase + incl - s;   // exclusive prefix of this thread's slice
+#pragma unroll 8
   for (int i = lo; i < hi; ++i) {
     const int v = in[i];
     out[i] = run;

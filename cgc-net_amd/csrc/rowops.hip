@@ -52,18 +52,37 @@ __device__ __forceinline__ void col_reduce_store(float (&acc)[NQ][MAXJ][VEC], in
   }
 }
 
-// out[c] = sum_s ws[s*width + c]
-__global__ __launch_bounds__(256) void k_reduce_slots(const float* __restrict__ ws, int slots, int width, float* __restrict__ out) {
-  __shared__ float part[4][64];
-  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + lane;
-  float s = 0.f;
-  if (c < width)
-    for (int k = grp; k < slots; k += 4) s += ws[(size_t)k * width + c];
-  part[grp][lane] = s;
+// out[c] = sum_s ws[s*width + c]   (fixed summation order: deterministic; accumulated in fp64 so that the
+// BatchNorm variance E[x^2] - E[x]^2 formed from these sums keeps ~1e-7 accuracy even when |mean| >> std).
+// 256 threads = 8 slot groups x 32 columns; every thread keeps 8 independent loads in flight.
+template <typename OUT>
+__global__ __launch_bounds__(256) void k_reduce_slots(const float* __restrict__ ws, int slots, int width, OUT* __restrict__ out) {
+  __shared__ double part[8][32];
+  const int cl = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  double s = 0.0;
+  if (c < width) {
+    double a[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] = 0.0;
+    int k = grp;
+    for (; k + 56 < slots; k += 64) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] += (double)ws[(size_t)(k + 8 * u) * width + c];
+    }
+    for (; k < slots; k += 8) a[0] += (double)ws[(size_t)k * width + c];
+    s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  }
+  part[grp][cl] = s;
   __syncthreads();
-  if (grp == 0 && c < width) out[c] = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+  if (grp == 0 && c < width) {
+    double t = part[0][cl];
+#pragma unroll
+    for (int g = 1; g < 8; ++g) t += part[g][cl];
+    out[c] = (OUT)t;
+  }
 }
+#define REDUCE_SLOTS_GRID(width) dim3(ceil_div((width), 32))
 
 struct ColCfg {
   int vec, maxj, lpr, blocks;
@@ -173,9 +192,9 @@ __global__ __launch_bounds__(256) void k_l2norm_act_stats(const float* __restric
 }
 
 extern "C" int cgc_l2norm_act_stats(const float* h, int n, int F, int normalize, int act, float* hn, float* rinv,
-                                    float* stats, float* ws, cgc_stream_t stream) {
+                                    double* stats, float* ws, cgc_stream_t stream) {
   if (n <= 0 || F <= 0) {
-    if (stats && F > 0) (void)hipMemsetAsync(stats, 0, sizeof(float) * 2 * F, as_stream(stream));
+    if (stats && F > 0) (void)hipMemsetAsync(stats, 0, sizeof(double) * 2 * F, as_stream(stream));
     return 0;
   }
   const bool vec_ok = (F % 4 == 0) && aligned16(h) && aligned16(hn);
@@ -187,7 +206,7 @@ extern "C" int cgc_l2norm_act_stats(const float* h, int n, int F, int normalize,
   DISPATCH_COL(k_l2norm_act_stats, cfg, smem, as_stream(stream), h, n, F, cfg.lpr, normalize, act, hn, rinv, wsp);
   CGC_RETURN_IF_LAUNCH_FAILED();
   if (stats) {
-    hipLaunchKernelGGL(k_reduce_slots, dim3(ceil_div(2 * F, 64)), dim3(256), 0, as_stream(stream), ws, cfg.blocks, 2 * F, stats);
+    hipLaunchKernelGGL(k_reduce_slots<double>, REDUCE_SLOTS_GRID(2 * F), dim3(256), 0, as_stream(stream), ws, cfg.blocks, 2 * F, stats);
     CGC_RETURN_IF_LAUNCH_FAILED();
   }
   return 0;
@@ -196,12 +215,12 @@ extern "C" int cgc_l2norm_act_stats(const float* h, int n, int F, int normalize,
 // ------------------------------------------------------------------------------------------------
 // BatchNorm statistics -> mean / inverse std (+ running statistics)
 // ------------------------------------------------------------------------------------------------
-__global__ void k_bn_finalize(const float* __restrict__ stats, int F, double count, float eps, float momentum,
+__global__ void k_bn_finalize(const double* __restrict__ stats, int F, double count, float eps, float momentum,
                               float* running_mean, float* running_var, float* __restrict__ mean, float* __restrict__ istd) {
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= F) return;
-  const double m = (double)stats[f] / count;
-  double var = (double)stats[F + f] / count - m * m;   // biased; the padded zero rows are part of `count`
+  const double m = stats[f] / count;
+  double var = stats[F + f] / count - m * m;   // biased; the padded zero rows are part of `count`
   if (var < 0.0) var = 0.0;
   mean[f] = (float)m;
   istd[f] = (float)(1.0 / sqrt(var + (double)eps));
@@ -212,7 +231,7 @@ __global__ void k_bn_finalize(const float* __restrict__ stats, int F, double cou
   }
 }
 
-extern "C" int cgc_bn_finalize(const float* stats, int F, double count, float eps, float momentum, float* running_mean,
+extern "C" int cgc_bn_finalize(const double* stats, int F, double count, float eps, float momentum, float* running_mean,
                                float* running_var, float* mean, float* istd, cgc_stream_t stream) {
   if (F <= 0) return 0;
   hipLaunchKernelGGL(k_bn_finalize, dim3(ceil_div(F, 256)), dim3(256), 0, as_stream(stream), stats, F, count, eps, momentum,
@@ -224,25 +243,43 @@ extern "C" int cgc_bn_finalize(const float* stats, int F, double count, float ep
 // ------------------------------------------------------------------------------------------------
 // y = BN(act(hn))   (elementwise; y may be a column slice of a wider buffer: ldy)
 // ------------------------------------------------------------------------------------------------
-template <int VEC>
+template <int VEC, int MAXJ>
 __global__ __launch_bounds__(256) void k_bn_act_apply(const float* __restrict__ hn, int n, int F, int lpr, int act,
                                                       const float* __restrict__ mean, const float* __restrict__ istd,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       float* __restrict__ y, int ldy) {
   const RowGroup rg(lpr);
+  // y = (act(hn) - mu) * sc + sh with sc = istd*gamma: the lane's columns never change, so the constants live in
+  // registers.  (o - mu) is formed first, as nn.BatchNorm1d does: folding mu into the shift would cancel catastrophically
+  // when |mean| >> std, e.g. after the un-normalised GIN convolution.)
+  float mu[MAXJ][VEC], sc[MAXJ][VEC], sh[MAXJ][VEC];
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j)
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      const int c = (rg.sl + lpr * j) * VEC + v;
+      mu[j][v] = 0.f;
+      sc[j][v] = 1.f;
+      sh[j][v] = 0.f;
+      if (mean != nullptr && c < F) {
+        mu[j][v] = mean[c];
+        sc[j][v] = istd[c] * gamma[c];
+        sh[j][v] = beta[c];
+      }
+    }
   for (int base = rg.gwave * rg.rpw; base < n; base += rg.nwaves * rg.rpw) {
     const int row = base + rg.sub;
     if (row >= n) continue;
-    for (int c = rg.sl * VEC; c < F; c += lpr * VEC) {
-      Vec<VEC> x;
-      x.load(hn + (size_t)row * F + c);
 #pragma unroll
-      for (int v = 0; v < VEC; ++v) {
-        float o = act_fwd(x.v[v], act);
-        if (mean != nullptr) o = (o - mean[c + v]) * istd[c + v] * gamma[c + v] + beta[c + v];
-        x.v[v] = o;
+    for (int j = 0; j < MAXJ; ++j) {
+      const int c = (rg.sl + lpr * j) * VEC;
+      if (c < F) {
+        Vec<VEC> x;
+        x.load(hn + (size_t)row * F + c);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) x.v[v] = fmaf(act_fwd(x.v[v], act) - mu[j][v], sc[j][v], sh[j][v]);
+        x.store(y + (size_t)row * ldy + c);
       }
-      x.store(y + (size_t)row * ldy + c);
     }
   }
 }
@@ -251,12 +288,10 @@ extern "C" int cgc_bn_act_apply(const float* hn, int n, int F, int act, const fl
                                 const float* gamma, const float* beta, float* y, int ldy, cgc_stream_t stream) {
   if (n <= 0 || F <= 0) return 0;
   const bool vec = (F % 4 == 0) && (ldy % 4 == 0) && aligned16(hn) && aligned16(y);
-  const int lpr = pick_lpr(vec ? F / 4 : F);
-  dim3 grid(row_blocks(n, lpr)), block(CGC_BLOCK);
-  if (vec)
-    hipLaunchKernelGGL(k_bn_act_apply<4>, grid, block, 0, as_stream(stream), hn, n, F, lpr, act, mean, istd, gamma, beta, y, ldy);
-  else
-    hipLaunchKernelGGL(k_bn_act_apply<1>, grid, block, 0, as_stream(stream), hn, n, F, lpr, act, mean, istd, gamma, beta, y, ldy);
+  ColCfg cfg = col_cfg(n, F, vec);
+  if (!cfg.ok) return CGC_EINVAL;
+  cfg.blocks = row_blocks(n, cfg.lpr);
+  DISPATCH_COL(k_bn_act_apply, cfg, 0, as_stream(stream), hn, n, F, cfg.lpr, act, mean, istd, gamma, beta, y, ldy);
   CGC_RETURN_IF_LAUNCH_FAILED();
   return 0;
 }
@@ -317,7 +352,7 @@ extern "C" int cgc_bn_bwd_reduce(const float* dy, int ldy, const float* hn, int 
   const size_t smem = sizeof(float) * 3 * 2 * F;
   DISPATCH_COL(k_bn_bwd_reduce, cfg, smem, as_stream(stream), dy, ldy, hn, n, F, cfg.lpr, act, mean, istd, ws);
   CGC_RETURN_IF_LAUNCH_FAILED();
-  hipLaunchKernelGGL(k_reduce_slots, dim3(ceil_div(2 * F, 64)), dim3(256), 0, as_stream(stream), ws, cfg.blocks, 2 * F, sums);
+  hipLaunchKernelGGL(k_reduce_slots<float>, REDUCE_SLOTS_GRID(2 * F), dim3(256), 0, as_stream(stream), ws, cfg.blocks, 2 * F, sums);
   CGC_RETURN_IF_LAUNCH_FAILED();
   return 0;
 }
@@ -325,51 +360,72 @@ extern "C" int cgc_bn_bwd_reduce(const float* dy, int ldy, const float* hn, int 
 // ------------------------------------------------------------------------------------------------
 // BatchNorm backward stage 2 fused with activation and l2norm backward:  dy -> dh
 // ------------------------------------------------------------------------------------------------
-template <int VEC>
+template <int VEC, int MAXJ>
 __global__ __launch_bounds__(256) void k_bn_act_l2_bwd(const float* __restrict__ dy, int ldy, const float* __restrict__ hn,
                                                        const float* __restrict__ rinv, int n, int F, int lpr, int act,
                                                        int normalize, int mode, const float* __restrict__ mean,
                                                        const float* __restrict__ istd, const float* __restrict__ gamma,
                                                        const float* __restrict__ sums, float inv_count, float* __restrict__ dh) {
   const RowGroup rg(lpr);
+  // per-lane column constants: do = ca*dy - cb - xhat*cc  with  ca = gamma*istd, cb = ca*s0/count, cc = ca*s1/count
+  float ca[MAXJ][VEC], cb[MAXJ][VEC], cc[MAXJ][VEC], mu[MAXJ][VEC], is[MAXJ][VEC];
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j)
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      const int c = (rg.sl + lpr * j) * VEC + v;
+      ca[j][v] = 1.f; cb[j][v] = cc[j][v] = mu[j][v] = is[j][v] = 0.f;
+      if (mode != 0 && c < F) {
+        ca[j][v] = gamma[c] * istd[c];
+        if (mode == 2) {
+          cb[j][v] = ca[j][v] * sums[c] * inv_count;
+          cc[j][v] = ca[j][v] * sums[F + c] * inv_count;
+          mu[j][v] = mean[c];
+          is[j][v] = istd[c];
+        }
+      }
+    }
   for (int base = rg.gwave * rg.rpw; base < n; base += rg.nwaves * rg.rpw) {
     const int row = base + rg.sub;
     const bool valid = row < n;
-    // d(hn) for one element; recomputed in the second pass (cheaper than keeping a row in registers)
-    auto dhn_at = [&](int c, float d, float x) -> float {
-      float go = d;
-      if (mode == 2) {
-        const float xhat = (act_fwd(x, act) - mean[c]) * istd[c];
-        go = gamma[c] * istd[c] * (d - sums[c] * inv_count - xhat * sums[F + c] * inv_count);
-      } else if (mode == 1) {
-        go = gamma[c] * istd[c] * d;
-      }
-      return go * act_bwd(x, act);
-    };
+    Vec<VEC> g[MAXJ], x[MAXJ];
     float dot = 0.f;
-    if (normalize && valid) {
-      for (int c = rg.sl * VEC; c < F; c += lpr * VEC) {
-        Vec<VEC> d, x;
-        d.load(dy + (size_t)row * ldy + c);
-        x.load(hn + (size_t)row * F + c);
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) dot += x.v[v] * dhn_at(c + v, d.v[v], x.v[v]);
+    for (int j = 0; j < MAXJ; ++j) {
+      const int c = (rg.sl + lpr * j) * VEC;
+      if (valid && c < F) {
+        g[j].load(dy + (size_t)row * ldy + c);
+        x[j].load(hn + (size_t)row * F + c);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          const float xv = x[j].v[v];
+          float go = ca[j][v] * g[j].v[v];
+          if (mode == 2) go = go - cb[j][v] - (act_fwd(xv, act) - mu[j][v]) * is[j][v] * cc[j][v];
+          go *= act_bwd(xv, act);
+          g[j].v[v] = go;                 // d(hn)
+          dot += xv * go;
+        }
+      } else {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) g[j].v[v] = x[j].v[v] = 0.f;
       }
     }
     if (normalize) dot = group_sum(dot, lpr);
     if (!valid) continue;
     const float r = normalize ? rinv[row] : 1.f;
     const bool clamped = normalize && !(r < 1.f / L2_EPS);   // ||h|| <= eps: F.normalize divided by the constant eps
-    for (int c = rg.sl * VEC; c < F; c += lpr * VEC) {
-      Vec<VEC> d, x, o;
-      d.load(dy + (size_t)row * ldy + c);
-      x.load(hn + (size_t)row * F + c);
 #pragma unroll
-      for (int v = 0; v < VEC; ++v) {
-        const float g = dhn_at(c + v, d.v[v], x.v[v]);
-        o.v[v] = !normalize ? g : (clamped ? g * (1.f / L2_EPS) : r * (g - x.v[v] * dot));
+    for (int j = 0; j < MAXJ; ++j) {
+      const int c = (rg.sl + lpr * j) * VEC;
+      if (c < F) {
+        Vec<VEC> o;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          const float gv = g[j].v[v];
+          o.v[v] = !normalize ? gv : (clamped ? gv * (1.f / L2_EPS) : r * (gv - x[j].v[v] * dot));
+        }
+        o.store(dh + (size_t)row * F + c);
       }
-      o.store(dh + (size_t)row * F + c);
     }
   }
 }
@@ -379,15 +435,12 @@ extern "C" int cgc_bn_act_l2_bwd(const float* dy, int ldy, const float* hn, cons
                                  const float* sums, double count, float* dh, cgc_stream_t stream) {
   if (n <= 0 || F <= 0) return 0;
   const bool vec = (F % 4 == 0) && (ldy % 4 == 0) && aligned16(dy) && aligned16(hn) && aligned16(dh);
-  const int lpr = pick_lpr(vec ? F / 4 : F);
+  ColCfg cfg = col_cfg(n, F, vec);
+  if (!cfg.ok) return CGC_EINVAL;
+  cfg.blocks = row_blocks(n, cfg.lpr);
   const float inv_count = (float)(1.0 / count);
-  dim3 grid(row_blocks(n, lpr)), block(CGC_BLOCK);
-  if (vec)
-    hipLaunchKernelGGL(k_bn_act_l2_bwd<4>, grid, block, 0, as_stream(stream), dy, ldy, hn, rinv, n, F, lpr, act, normalize, mode,
-                       mean, istd, gamma, sums, inv_count, dh);
-  else
-    hipLaunchKernelGGL(k_bn_act_l2_bwd<1>, grid, block, 0, as_stream(stream), dy, ldy, hn, rinv, n, F, lpr, act, normalize, mode,
-                       mean, istd, gamma, sums, inv_count, dh);
+  DISPATCH_COL(k_bn_act_l2_bwd, cfg, 0, as_stream(stream), dy, ldy, hn, rinv, n, F, cfg.lpr, act, normalize, mode, mean, istd,
+               gamma, sums, inv_count, dh);
   CGC_RETURN_IF_LAUNCH_FAILED();
   return 0;
 }
@@ -434,7 +487,7 @@ extern "C" int cgc_colsum(const float* x, int ld, int n, int F, float* out, floa
   const size_t smem = sizeof(float) * 3 * F;
   DISPATCH_COL(k_colsum, cfg, smem, as_stream(stream), x, ld, n, F, cfg.lpr, ws);
   CGC_RETURN_IF_LAUNCH_FAILED();
-  hipLaunchKernelGGL(k_reduce_slots, dim3(ceil_div(F, 64)), dim3(256), 0, as_stream(stream), ws, cfg.blocks, F, out);
+  hipLaunchKernelGGL(k_reduce_slots<float>, REDUCE_SLOTS_GRID(F), dim3(256), 0, as_stream(stream), ws, cfg.blocks, F, out);
   CGC_RETURN_IF_LAUNCH_FAILED();
   return 0;
 }

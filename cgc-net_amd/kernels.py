@@ -68,7 +68,8 @@ class KernelSpec(object):
     # ------------------------------------------------------------------ conv epilogue: L2 norm, activation, BatchNorm (A4, A5)
     def l2norm_act_stats(self, h, n, F, normalize, act, hn_out, rinv_out, stats_out):
         """hn = h / max(||h||_2, 1e-12) row-wise (or hn = h), rinv = that reciprocal;
-        stats[0,f] = sum_i act(hn)[i,f], stats[1,f] = sum_i act(hn)[i,f]^2 (None to skip)."""
+        stats[0,f] = sum_i act(hn)[i,f], stats[1,f] = sum_i act(hn)[i,f]^2 (None to skip).  ``stats`` is
+        FLOAT64 [2,F]: the variance is a difference of these two sums."""
         raise NotImplementedError
 
     def bn_finalize(self, stats, count, eps, momentum, running_mean, running_var, mean_out, istd_out):

@@ -167,7 +167,7 @@ class _L2ActBN(Function):
         rinv = torch.empty(n, dtype=torch.float32, device=dev)
         mean = istd = None
         if bn_mode == 2:
-            stats = torch.empty(2, F, dtype=torch.float32, device=dev)
+            stats = torch.empty(2, F, dtype=torch.float64, device=dev)
             K().l2norm_act_stats(h, n, F, normalize, act, hn, rinv, stats)
             mean = torch.empty(F, dtype=torch.float32, device=dev)
             istd = torch.empty(F, dtype=torch.float32, device=dev)

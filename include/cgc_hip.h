@@ -75,8 +75,8 @@ int cgc_reduce_batch_sum(const float* ws, float* out, int parts, int64_t numel, 
  * cgc_stats_blocks(n,F): number of partial-sum slots the column reductions use; ws must hold 2*F floats per slot. */
 int cgc_stats_blocks(int n, int F);
 int cgc_l2norm_act_stats(const float* h, int n, int F, int normalize, int act, float* hn, float* rinv,
-                         float* stats /*[2,F] or NULL*/, float* ws, cgc_stream_t stream);
-int cgc_bn_finalize(const float* stats, int F, double count, float eps, float momentum,
+                         double* stats /*[2,F] fp64 or NULL*/, float* ws, cgc_stream_t stream);
+int cgc_bn_finalize(const double* stats /*[2,F] fp64: the variance is a difference of these sums*/, int F, double count, float eps, float momentum,
                     float* running_mean /*NULL ok*/, float* running_var, float* mean, float* istd, cgc_stream_t stream);
 int cgc_bn_act_apply(const float* hn, int n, int F, int act, const float* mean /*NULL: no BN*/, const float* istd,
                      const float* gamma, const float* beta, float* y, int ldy, cgc_stream_t stream);

@@ -150,8 +150,8 @@ class TorchKernels(KernelSpec):
         rinv_out.copy_(r)
         if stats_out is not None:
             o = _act(hn, act)
-            stats_out[0] = o.sum(0)
-            stats_out[1] = (o * o).sum(0)
+            stats_out[0] = o.double().sum(0)
+            stats_out[1] = (o.double() * o.double()).sum(0)
 
     def bn_finalize(self, stats, count, eps, momentum, running_mean, running_var, mean_out, istd_out):
         mean = stats[0].double() / count

@@ -229,7 +229,7 @@ def test_conv_epilogue_chain(n, F, act):
     for name, K_, dev in (('ref', REF, 'cpu'), ('hip', k, DEV)):
         t = lambda v: v.to(dev)
         hn, rinv = torch.empty(n, F, device=dev), torch.empty(n, device=dev)
-        stats = torch.empty(2, F, device=dev)
+        stats = torch.empty(2, F, device=dev, dtype=torch.float64)
         K_.l2norm_act_stats(t(h), n, F, True, act, hn, rinv, stats)
         rm, rv = torch.zeros(F, device=dev), torch.ones(F, device=dev)
         mean, istd = torch.empty(F, device=dev), torch.empty(F, device=dev)
