@@ -78,13 +78,16 @@ struct KContigLoader {
       reg[i] = *reinterpret_cast<const float4*>(base + (size_t)row * ld + k0 + (u % (BK / 4)) * 4);
     }
   }
-  __device__ __forceinline__ void store(float* __restrict__ lds) const {   // same orientation as memory: one 16-byte write per unit
+  // same orientation as memory: one 16-byte write per unit.  store_part(i) writes unit i only, so that the writes of the
+  // next tile can be spread between the MFMA groups of the current one.
+  __device__ __forceinline__ void store_part(int i, float* __restrict__ lds) const {
+    const int u = threadIdx.x + i * 256;
+    if (UNITS % 256 == 0 || u < UNITS)
+      *reinterpret_cast<float4*>(&lds[(u / (BK / 4)) * KC_LD + (u % (BK / 4)) * 4]) = reg[i];
+  }
+  __device__ __forceinline__ void store(float* __restrict__ lds) const {
 #pragma unroll
-    for (int i = 0; i < PER_T; ++i) {
-      const int u = threadIdx.x + i * 256;
-      if (UNITS % 256 == 0 || u < UNITS)
-        *reinterpret_cast<float4*>(&lds[(u / (BK / 4)) * KC_LD + (u % (BK / 4)) * 4]) = reg[i];
-    }
+    for (int i = 0; i < PER_T; ++i) store_part(i, lds);
   }
 };
 
@@ -127,17 +130,14 @@ struct MnContigLoader {
       reg[i] = *reinterpret_cast<const float4*>(base + (size_t)(k0 + u / (COLS / 4)) * ld + c);
     }
   }
-  __device__ __forceinline__ void store(float* __restrict__ lds) const {
+  __device__ __forceinline__ void store_part(int i, float* __restrict__ lds) const {
     constexpr int LD = COLS + 4;
+    const int u = threadIdx.x + i * 256;
+    if (UNITS % 256 == 0 || u < UNITS) *reinterpret_cast<float4*>(&lds[(u / (COLS / 4)) * LD + (u % (COLS / 4)) * 4]) = reg[i];
+  }
+  __device__ __forceinline__ void store(float* __restrict__ lds) const {
 #pragma unroll
-    for (int i = 0; i < PER_T; ++i) {
-      const int u = threadIdx.x + i * 256;
-      if (UNITS % 256 == 0 || u < UNITS) {
-        const int k = u / (COLS / 4);
-        const int c = (u % (COLS / 4)) * 4;
-        *reinterpret_cast<float4*>(&lds[k * LD + c]) = reg[i];
-      }
-    }
+    for (int i = 0; i < PER_T; ++i) store_part(i, lds);
   }
 };
 
@@ -154,7 +154,7 @@ __device__ __forceinline__ void fetch_frag(const float* __restrict__ tile, int k
 }
 
 template <int WGM, int WGN, int TM, int TN, bool TA, bool TB>
-__global__ __launch_bounds__(256) void k_gemm_f32(const GemmArgs a) {
+__global__ __launch_bounds__(256, 2) void k_gemm_f32(const GemmArgs a) {   // 2 waves per SIMD = 2 workgroups per CU (the LDS budget)
   constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
   constexpr int LDA_S = TA ? BM + 4 : KC_LD;   // TA: A stored [K,M] -> k-major tile; else row-major [m][k]
   constexpr int LDB_S = TB ? KC_LD : BN + 4;   // TB: B stored [N,K] -> row-major [n][k]; else k-major
@@ -187,8 +187,10 @@ __global__ __launch_bounds__(256) void k_gemm_f32(const GemmArgs a) {
   const bool vecA = (a.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) & 15u) == 0);
   const bool vecB = (a.ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(B) & 15u) == 0);
 
-  typename std::conditional<TA, MnContigLoader<BM>, KContigLoader<BM>>::type la;
-  typename std::conditional<TB, KContigLoader<BN>, MnContigLoader<BN>>::type lb;
+  typedef typename std::conditional<TA, MnContigLoader<BM>, KContigLoader<BM>>::type LoaderA;
+  typedef typename std::conditional<TB, KContigLoader<BN>, MnContigLoader<BN>>::type LoaderB;
+  LoaderA la0, la1;   // two register stages: one holds tile t+1 (arrived, being written to LDS), the other receives t+2
+  LoaderB lb0, lb1;
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave / WGN, wn = wave - wm * WGN;
@@ -207,42 +209,81 @@ __global__ __launch_bounds__(256) void k_gemm_f32(const GemmArgs a) {
   const bool fastA = vecA && (TA ? (M % 4 == 0 && M >= 4) : true);
   const bool fastB = vecB && (TB ? true : (N % 4 == 0 && N >= 4));
   const int a_last = TA ? M - 4 : M - 1, b_last = TB ? N - 1 : N - 4;
-  auto fetch = [&](int kt) {
+  auto fetch = [&](LoaderA& la, LoaderB& lb, int kt) {
     if (fastA && kt < nk_full) la.load_fast(A, a.lda, m0, a_last, kt * BK);
     else la.load(A, a.lda, m0, M, kt * BK, K, vecA);
     if (fastB && kt < nk_full) lb.load_fast(B, a.ldb, n0, b_last, kt * BK);
     else lb.load(B, a.ldb, n0, N, kt * BK, K, vecB);
   };
-  if (nk > 0) {
-    fetch(0);
-    la.store(As0);
-    lb.store(Bs0);
-  }
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) fetch(kt + 1);   // prefetch the next k-tile into registers while this one is consumed from LDS
+  // One k-tile: consume LDS buffer `cur` with 4 groups of TM*TN*4 MFMAs.  The fragments of group kb+1 are read from LDS
+  // before the MFMAs of group kb are issued; between the groups a quarter of the NEXT tile (already in registers `ls_*`)
+  // is written into the other LDS buffer; the tile after that is requested from memory at the top and lands in `ll_*`
+  // while all of this runs.  One barrier per k-tile.  STEADY = interior of the k loop: no conditionals at all (every
+  // load is an unguarded 16-byte load, every store happens), so the compiler can count vmcnt/lgkmcnt exactly and
+  // interleave freely.
+  auto phase = [&](auto steady, int kt, auto cur_c, LoaderA& ls_a, LoaderB& ls_b, LoaderA& ll_a, LoaderB& ll_b) {
+    constexpr bool STEADY = decltype(steady)::value;
+    constexpr int cur = decltype(cur_c)::value;
+    if (STEADY) {
+      ll_a.load_fast(A, a.lda, m0, a_last, (kt + 2) * BK);
+      ll_b.load_fast(B, a.ldb, n0, b_last, (kt + 2) * BK);
+    } else if (kt + 2 < nk) {
+      fetch(ll_a, ll_b, kt + 2);
+    }
+    const bool has_next = STEADY || kt + 1 < nk;
     const float* as = As0 + cur * A_SZ + (TA ? wm * TM * 32 : wm * TM * 32 * KC_LD);
     const float* bs = Bs0 + cur * B_SZ + (TB ? wn * TN * 32 * KC_LD : wn * TN * 32);
+    float* an = As0 + (cur ^ 1) * A_SZ;
+    float* bn = Bs0 + (cur ^ 1) * B_SZ;
+    float av[2][TM][4], bv[2][TN][4];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fetch_frag<TA, LDA_S>(as + (TA ? i * 32 : i * 32 * KC_LD), 0, l31, lhi, av[0][i]);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fetch_frag<!TB, LDB_S>(bs + (TB ? j * 32 * KC_LD : j * 32), 0, l31, lhi, bv[0][j]);
 #pragma unroll
     for (int kb = 0; kb < BK / 8; ++kb) {
-      float av[TM][4], bv[TN][4];
+      if (kb + 1 < BK / 8) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) fetch_frag<TA, LDA_S>(as + (TA ? i * 32 : i * 32 * KC_LD), kb, l31, lhi, av[i]);
+        for (int i = 0; i < TM; ++i) fetch_frag<TA, LDA_S>(as + (TA ? i * 32 : i * 32 * KC_LD), kb + 1, l31, lhi, av[(kb + 1) & 1][i]);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) fetch_frag<!TB, LDB_S>(bs + (TB ? j * 32 * KC_LD : j * 32), kb, l31, lhi, bv[j]);
+        for (int j = 0; j < TN; ++j) fetch_frag<!TB, LDB_S>(bs + (TB ? j * 32 * KC_LD : j * 32), kb + 1, l31, lhi, bv[(kb + 1) & 1][j]);
+      }
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][t], bv[j][t], acc[i][j], 0, 0, 0);
-    }
-    if (kt + 1 < nk) {
-      la.store(As0 + (cur ^ 1) * A_SZ);
-      lb.store(Bs0 + (cur ^ 1) * B_SZ);
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kb & 1][i][t], bv[kb & 1][j][t], acc[i][j], 0, 0, 0);
+      if (has_next) {
+        if (kb < LoaderA::PER_T) ls_a.store_part(kb, an);
+        if (kb < LoaderB::PER_T) ls_b.store_part(kb, bn);
+      }
     }
     __syncthreads();
+  };
+  typedef std::integral_constant<bool, true> T_;
+  typedef std::integral_constant<bool, false> F_;
+  typedef std::integral_constant<int, 0> B0;
+  typedef std::integral_constant<int, 1> B1;
+
+  if (nk > 0) {
+    fetch(la0, lb0, 0);
+    la0.store(As0);
+    lb0.store(Bs0);
+    if (nk > 1) fetch(la0, lb0, 1);
+  }
+  __syncthreads();
+  int kt = 0;
+  if (fastA && fastB) {
+    for (; kt + 3 < nk_full; kt += 2) {      // both phases prefetch full tiles (kt+2, kt+3 < nk_full)
+      phase(T_(), kt, B0(), la0, lb0, la1, lb1);
+      phase(T_(), kt + 1, B1(), la1, lb1, la0, lb0);
+    }
+  }
+  for (; kt < nk; kt += 2) {                  // generic tail (or whole loop when a fast path is not available)
+    phase(F_(), kt, B0(), la0, lb0, la1, lb1);
+    if (kt + 1 < nk) phase(F_(), kt + 1, B1(), la1, lb1, la0, lb0);
   }
 
   // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -307,6 +348,9 @@ extern "C" int cgc_gemm_f32(int transA, int transB, int M, int N, int K, float a
   if (N <= 64) return launch_cfg<4, 1, 1, 2>(a, transA, transB, batch, m_extent, stream);   // 128 x 64
   if (m_extent <= 32) return launch_cfg<1, 4, 1, 1>(a, transA, transB, batch, m_extent, stream);   // 32 x 128
   if (m_extent <= 64) return launch_cfg<1, 4, 2, 1>(a, transA, transB, batch, m_extent, stream);   // 64 x 128
+  // too few 128x128 tiles to fill 256 CUs x 2 resident workgroups: halve the tile width
+  if ((long long)ceil_div(m_extent, 128) * ceil_div(N, 128) * batch < 448)
+    return launch_cfg<4, 1, 1, 2>(a, transA, transB, batch, m_extent, stream);                       // 128 x 64
   return launch_cfg<2, 2, 2, 2>(a, transA, transB, batch, m_extent, stream);                        // 128 x 128
 }
 
