@@ -9,14 +9,20 @@
 //   * gathers are issued four at a time before the first FMA so that ~4 KiB per wave is in flight;
 //   * wide rows are cut into column tiles and the block index is remapped so that one XCD (private 4 MiB L2) works on a
 //     contiguous range of rows (= a few whole graphs): the ~9x re-read of neighbour rows is then served by that L2.
+#include <stdlib.h>
+
 #include "common.hpp"
+
+#ifndef GATHER_U
+#define GATHER_U 9   // neighbour rows requested before the first FMA: one batch covers a k-NN(8)+self row
+#endif
 
 template <int VEC>
 __global__ __launch_bounds__(256) void k_spmm(const int* __restrict__ rowptr, const int* __restrict__ col, const int* __restrict__ perm,
                                               const float* __restrict__ val, const float* __restrict__ pre,
                                               const float* __restrict__ post, const float* __restrict__ x, float* __restrict__ out,
                                               int n, int W, int lpr, int n_ctiles, int rows_per_block, int blocks_per_ct,
-                                              int n_chunks) {
+                                              int n_chunks, int nt_store, const int* __restrict__ gptr) {
   // XCD-contiguous virtual block id (blocks are dealt round-robin to the 8 XCDs; speed only, never correctness)
   const int nb = gridDim.x, b = blockIdx.x;
   const int vb = (nb % 8 == 0) ? (b % 8) * (nb / 8) + b / 8 : b;
@@ -25,8 +31,18 @@ __global__ __launch_bounds__(256) void k_spmm(const int* __restrict__ rowptr, co
   if (chunk >= n_chunks) return;
   const int rem = vb - chunk * per_chunk;
   const int ct = rem / blocks_per_ct, rb = rem - ct * blocks_per_ct;
-  const int row0 = (chunk * blocks_per_ct + rb) * rows_per_block;
-  const int row_end = min(row0 + rows_per_block, n);
+  // chunk = rows whose neighbour rows one XCD should keep in its L2 while it sweeps the column tiles: a whole graph
+  // when the caller told us the graph boundaries, a fixed row range otherwise
+  int row0, row_end;
+  if (gptr != nullptr) {
+    const int g0 = gptr[chunk], g1 = gptr[chunk + 1];
+    row0 = g0 + rb * rows_per_block;
+    if (row0 >= g1) return;
+    row_end = min(row0 + rows_per_block, g1);
+  } else {
+    row0 = (chunk * blocks_per_ct + rb) * rows_per_block;
+    row_end = min(row0 + rows_per_block, n);
+  }
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sl = lane & (lpr - 1), sub = lane / lpr, rpw = 64 / lpr;
@@ -53,11 +69,11 @@ __global__ __launch_bounds__(256) void k_spmm(const int* __restrict__ rowptr, co
         myw = w;
       }
       const int cnt = min(lpr, e - k0);
-      for (int t = 0; t < cnt; t += 4) {
-        Vec<VEC> xv[4];
-        float ww[4];
+      for (int t = 0; t < cnt; t += GATHER_U) {
+        Vec<VEC> xv[GATHER_U];
+        float ww[GATHER_U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < GATHER_U; ++u) {
           const int tt = t + u;
           const int cc = __shfl(myc, tt & (lpr - 1), lpr);
           ww[u] = __shfl(myw, tt & (lpr - 1), lpr);
@@ -70,44 +86,190 @@ __global__ __launch_bounds__(256) void k_spmm(const int* __restrict__ rowptr, co
           }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < GATHER_U; ++u)
 #pragma unroll
           for (int v = 0; v < VEC; ++v) acc[v] = fmaf(ww[u], xv[u].v[v], acc[v]);
       }
     }
     if (valid && colok) {
       const float ps = post != nullptr ? post[r] : 1.f;
-      Vec<VEC> o;
+      float* op = out + (size_t)r * W + c0;
+      if (nt_store && VEC == 4) {   // streaming result: keep it from evicting the re-read neighbour rows out of L2
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        f4v o4 = {acc[0] * ps, acc[VEC > 1 ? 1 : 0] * ps, acc[VEC > 2 ? 2 : 0] * ps, acc[VEC > 3 ? 3 : 0] * ps};
+        __builtin_nontemporal_store(o4, reinterpret_cast<f4v*>(op));
+      } else {
+        Vec<VEC> o;
 #pragma unroll
-      for (int v = 0; v < VEC; ++v) o.v[v] = acc[v] * ps;
-      o.store(out + (size_t)r * W + c0);
+        for (int v = 0; v < VEC; ++v) o.v[v] = acc[v] * ps;
+        o.store(op);
+      }
     }
   }
+}
+
+// tuning knobs (read once from the environment; defaults are the measured best for ~1800-node cell graphs)
+static int knob(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v != nullptr ? atoi(v) : dflt;
+}
+
+static int launch_gather(const int* rowptr, const int* col, const int* perm, const float* val, const float* pre, const float* post,
+                         const float* x, float* out, int n, int width, const int* gptr, int B, int nmax, hipStream_t stream) {
+  static const int k_passes = knob("CGC_SPMM_PASSES", 2), k_chunk = knob("CGC_SPMM_CHUNK", 2048);
+  static const int k_nt = knob("CGC_SPMM_NT", 1), k_lds = knob("CGC_SPMM_LDS", 0), k_lpr = knob("CGC_SPMM_LPR", 64);
+  const bool vec = (width % 4 == 0) && aligned16(x) && aligned16(out);
+  const int chunks = vec ? width / 4 : width;        // per-lane column chunks in a row
+  int lpr = pick_lpr(chunks);
+  if (lpr > k_lpr) lpr = k_lpr;     // narrower column tiles for wide rows (experiment)
+  const int n_ctiles = ceil_div(chunks, lpr);         // > 1 only for rows wider than 64 chunks (lpr == 64)
+  const int rpw = 64 / lpr;
+  const int rows_per_block = 4 * rpw * k_passes;
+  int blocks_per_ct, n_chunks;
+  if (gptr != nullptr && n_ctiles > 1) {              // graph-aligned chunks (only matters when rows are tiled)
+    blocks_per_ct = ceil_div(nmax, rows_per_block);
+    n_chunks = B;
+  } else {
+    gptr = nullptr;
+    const int chunk_rows = ceil_div(k_chunk, rows_per_block) * rows_per_block;
+    blocks_per_ct = chunk_rows / rows_per_block;
+    n_chunks = ceil_div(n, chunk_rows);
+  }
+  int nb = n_chunks * blocks_per_ct * n_ctiles;
+  nb = ceil_div(nb, 8) * 8;
+  dim3 grid(nb), block(CGC_BLOCK);
+  const int nt = (n_ctiles > 1) ? k_nt : 0;
+  if (vec)
+    hipLaunchKernelGGL(k_spmm<4>, grid, block, k_lds, stream, rowptr, col, perm, val, pre, post, x, out, n, width, lpr,
+                       n_ctiles, rows_per_block, blocks_per_ct, n_chunks, nt, gptr);
+  else
+    hipLaunchKernelGGL(k_spmm<1>, grid, block, 0, stream, rowptr, col, perm, val, pre, post, x, out, n, width, lpr,
+                       n_ctiles, rows_per_block, blocks_per_ct, n_chunks, nt, gptr);
+  CGC_RETURN_IF_LAUNCH_FAILED();
+  return 0;
 }
 
 extern "C" int cgc_spmm(const int* rowptr, const int* col, const int* perm, const float* val, const float* pre, const float* post,
                         const float* x, float* out, int n, int width, cgc_stream_t stream) {
   if (n <= 0 || width <= 0) return 0;
-  const bool vec = (width % 4 == 0) && aligned16(x) && aligned16(out);
-  const int chunks = vec ? width / 4 : width;        // per-lane column chunks in a row
-  const int lpr = pick_lpr(chunks);
-  const int n_ctiles = ceil_div(chunks, lpr);         // > 1 only for rows wider than 64 chunks (lpr == 64)
-  const int rpw = 64 / lpr;
-  // narrow rows: 4 passes of (4 waves x rpw rows); wide rows: 4 rows per wave
-  const int rows_per_block = 4 * rpw * 4;
-  // rows handled by one XCD-contiguous "chunk": about one graph (2048 rows) so that its neighbour rows stay in that L2
-  const int chunk_rows = 2048;
-  const int blocks_per_ct = chunk_rows / rows_per_block;
-  const int n_chunks = ceil_div(n, chunk_rows);
-  int nb = n_chunks * blocks_per_ct * n_ctiles;
-  nb = ceil_div(nb, 8) * 8;
-  dim3 grid(nb), block(CGC_BLOCK);
-  if (vec)
-    hipLaunchKernelGGL(k_spmm<4>, grid, block, 0, as_stream(stream), rowptr, col, perm, val, pre, post, x, out, n, width, lpr,
-                       n_ctiles, rows_per_block, blocks_per_ct, n_chunks);
-  else
-    hipLaunchKernelGGL(k_spmm<1>, grid, block, 0, as_stream(stream), rowptr, col, perm, val, pre, post, x, out, n, width, lpr,
-                       n_ctiles, rows_per_block, blocks_per_ct, n_chunks);
+  return launch_gather(rowptr, col, perm, val, pre, post, x, out, n, width, nullptr, 0, 0, as_stream(stream));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Wide rows ("K4": A*S with width = cluster count): graph-slab kernel.
+// The gather kernel above re-reads every neighbour row ~9x through L2/Infinity Cache (measured 12 TB/s of cache traffic
+// for 2.5 TB/s of algorithmic bandwidth).  Cell graphs are block diagonal and small (~1800 nodes), so instead one
+// workgroup takes (graph g, T-column tile): it copies the graph's N_g x T slab of X into LDS ONCE with coalesced 16-byte
+// loads (pre-scaled by `pre`), then every output row of the graph gathers its ~9 neighbours from LDS (ds_read_b128) and
+// streams its T results out with non-temporal stores.  HBM traffic = algorithmic traffic; the 9x reuse happens in LDS.
+// Workgroups of one graph get consecutive (XCD-contiguous) ids so that the two column tiles sharing a 128-byte line run
+// on the same XCD back to back.
+template <int T, int NTHR>
+__global__ __launch_bounds__(NTHR) void k_spmm_slab(const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                    const int* __restrict__ perm, const float* __restrict__ val,
+                                                    const float* __restrict__ pre, const float* __restrict__ post,
+                                                    const float* __restrict__ x, float* __restrict__ out,
+                                                    const int* __restrict__ gptr, int B, int W, int n_ctiles) {
+  extern __shared__ __attribute__((aligned(16))) float slab[];   // [N_g][T]
+  constexpr int Q = T / 4;                                        // 16-byte units per slab row
+  const int nb = gridDim.x, b = blockIdx.x;
+  const int vb = (nb % 8 == 0) ? (b % 8) * (nb / 8) + b / 8 : b;
+  const int g = vb / n_ctiles;
+  if (g >= B) return;
+  const int ct = vb - g * n_ctiles;
+  const int g0 = gptr[g], ng = gptr[g + 1] - g0;
+  const int tid = threadIdx.x;
+
+  // phase 1: slab <- pre * X[g0 : g0+ng, ct*T : ct*T+T]
+  for (int u = tid; u < ng * Q; u += NTHR) {
+    const int r = u / Q, q = u - r * Q;
+    const int c = ct * T + q * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < W) {
+      v = *reinterpret_cast<const float4*>(x + (size_t)(g0 + r) * W + c);
+      if (pre != nullptr) {
+        const float p = pre[g0 + r];
+        v.x *= p; v.y *= p; v.z *= p; v.w *= p;
+      }
+    }
+    *reinterpret_cast<float4*>(&slab[r * T + q * 4]) = v;
+  }
+  __syncthreads();
+
+  // phase 2: Q lanes per output row
+  const int q = tid % Q;
+  const int c = ct * T + q * 4;
+  for (int r = tid / Q; r < ng; r += NTHR / Q) {
+    const int i = g0 + r;
+    const int s = rowptr[i], e = rowptr[i + 1];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k0 = s; k0 < e; k0 += 8) {
+      int cc[8];
+      float ww[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {      // indices and weights first (independent loads), LDS gathers after
+        const int k = k0 + u;
+        cc[u] = -1;
+        ww[u] = 0.f;
+        if (k < e) {
+          cc[u] = col[k] - g0;
+          ww[u] = val != nullptr ? val[perm != nullptr ? perm[k] : k] : 1.f;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (cc[u] >= 0) {
+          const float4 v = *reinterpret_cast<const float4*>(&slab[cc[u] * T + q * 4]);
+          acc.x = fmaf(ww[u], v.x, acc.x);
+          acc.y = fmaf(ww[u], v.y, acc.y);
+          acc.z = fmaf(ww[u], v.z, acc.z);
+          acc.w = fmaf(ww[u], v.w, acc.w);
+        }
+      }
+    }
+    if (c < W) {
+      const float ps = post != nullptr ? post[i] : 1.f;
+      float* op = out + (size_t)i * W + c;
+      typedef float f4v __attribute__((ext_vector_type(4)));
+      f4v o4 = {acc.x * ps, acc.y * ps, acc.z * ps, acc.w * ps};
+      __builtin_nontemporal_store(o4, reinterpret_cast<f4v*>(op));
+    }
+  }
+}
+
+template <int T, int NTHR>
+static int launch_slab(const int* rowptr, const int* col, const int* perm, const float* val, const float* pre, const float* post,
+                       const float* x, float* out, const int* gptr, int B, int nmax, int W, hipStream_t stream) {
+  const int n_ctiles = ceil_div(W, T);
+  const size_t lds = sizeof(float) * (size_t)nmax * T;
+  static bool attr_set = false;      // per instantiation; idempotent
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmm_slab<T, NTHR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  const int nb = ceil_div(B * n_ctiles, 8) * 8;
+  hipLaunchKernelGGL((k_spmm_slab<T, NTHR>), dim3(nb), dim3(NTHR), lds, stream, rowptr, col, perm, val, pre, post, x, out, gptr, B, W, n_ctiles);
   CGC_RETURN_IF_LAUNCH_FAILED();
   return 0;
+}
+
+// Graph-aware entry point: gptr[B+1] = first row of each graph (every row's neighbours lie inside its own graph),
+// nmax = largest graph.  Wide, 16-byte-aligned rows of graphs that fit LDS take the slab kernel; everything else the
+// gather kernel.
+extern "C" int cgc_spmm_graphs(const int* rowptr, const int* col, const int* perm, const float* val, const float* pre,
+                               const float* post, const float* x, float* out, int n, int width, const int* gptr, int B,
+                               int nmax, cgc_stream_t stream) {
+  if (n <= 0 || width <= 0) return 0;
+  static const int k_slab = knob("CGC_SPMM_SLAB", 0);
+  const size_t budget = 150 * 1024;
+  if (k_slab && gptr != nullptr && B > 0 && width > 64 && width % 4 == 0 && aligned16(x) && aligned16(out) && nmax > 0) {
+    hipStream_t st = as_stream(stream);
+    static const int k_t = knob("CGC_SPMM_T", 16), k_thr = knob("CGC_SPMM_THR", 1024);
+#define SLAB_ARGS rowptr, col, perm, val, pre, post, x, out, gptr, B, nmax, width, st
+    if (k_t >= 16 && (size_t)nmax * 16 * 4 <= budget) return k_thr >= 1024 ? launch_slab<16, 1024>(SLAB_ARGS) : launch_slab<16, 512>(SLAB_ARGS);
+    if (k_t >= 8 && (size_t)nmax * 8 * 4 <= budget) return k_thr >= 1024 ? launch_slab<8, 1024>(SLAB_ARGS) : launch_slab<8, 512>(SLAB_ARGS);
+    if ((size_t)nmax * 4 * 4 <= budget) return k_thr >= 1024 ? launch_slab<4, 1024>(SLAB_ARGS) : launch_slab<4, 512>(SLAB_ARGS);
+#undef SLAB_ARGS
+  }
+  return launch_gather(rowptr, col, perm, val, pre, post, x, out, n, width, gptr, B, nmax, as_stream(stream));
 }

@@ -92,7 +92,8 @@ class _Aggregate(Function):
     def forward(ctx, x, g, mean):
         x = _f32c(x)
         out = torch.empty_like(x)
-        K().spmm(g.rowptr, g.col, None, g.val, None, g.inv_d if mean else None, x, out, g.n, x.shape[1])
+        K().spmm(g.rowptr, g.col, None, g.val, None, g.inv_d if mean else None, x, out, g.n, x.shape[1],
+                 g.gptr, g.B, g.nmax)
         ctx.g, ctx.mean = g, mean
         return out
 
@@ -103,7 +104,7 @@ class _Aggregate(Function):
         dx = torch.empty_like(dy)
         # transpose aggregation: dx[j] = sum_i w_ij * inv_d[i] * dy[i]
         K().spmm(g.t_rowptr, g.t_col, g.t_perm if g.val is not None else None, g.val,
-                 g.inv_d if ctx.mean else None, None, dy, dx, g.n, dy.shape[1])
+                 g.inv_d if ctx.mean else None, None, dy, dx, g.n, dy.shape[1], g.gptr, g.B, g.nmax)
         return dx, None, None
 
 
@@ -280,7 +281,7 @@ class _DiffPoolSparse(Function):
         c = s.shape[1]
         dev = s.device
         p = torch.empty_like(s)                                   # P = A S   (K4, wide SpMM)
-        K().spmm(g.rowptr, g.col, None, g.val, None, None, s, p, n, c)
+        K().spmm(g.rowptr, g.col, None, g.val, None, None, s, p, n, c, g.gptr, g.B, g.nmax)
         xo = torch.empty(g.B, c, dx, dtype=torch.float32, device=dev)
         ao = torch.empty(g.B, c, c, dtype=torch.float32, device=dev)
         # ragged-K, transposed-A contractions: per graph  [c x N_b] . [N_b x (dx | c)]
@@ -302,7 +303,8 @@ class _DiffPoolSparse(Function):
         K().gemm(s, dao, dp, 0, c, c, False, False, c, c, c, 1.0, 0.0, None, g.B, 0, c * c, 0, g.gptr, 1, g.nmax, n)
         # dS = A^T dP  (transpose SpMM) + P dA'^T + X dX'^T
         ds = torch.empty_like(s)
-        K().spmm(g.t_rowptr, g.t_col, g.t_perm if g.val is not None else None, g.val, None, None, dp, ds, n, c)
+        K().spmm(g.t_rowptr, g.t_col, g.t_perm if g.val is not None else None, g.val, None, None, dp, ds, n, c,
+                 g.gptr, g.B, g.nmax)
         K().gemm(p, dao, ds, 0, c, c, False, True, c, c, c, 1.0, 1.0, None, g.B, 0, c * c, 0, g.gptr, 1, g.nmax, n)
         K().gemm(embed, dxo, ds, 0, c, dx, False, True, dx, dx, c, 1.0, 1.0, None, g.B, 0, c * dx, 0, g.gptr, 1, g.nmax, n)
         # dX = S dX'

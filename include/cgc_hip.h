@@ -56,6 +56,12 @@ int cgc_csr_invdeg(const int* rowptr, const float* val, int n, float* out, cgc_s
 int cgc_spmm(const int* rowptr, const int* col, const int* perm, const float* val, const float* pre,
              const float* post, const float* x, float* out, int n, int width, cgc_stream_t stream);
 
+/* Same contract when the rows are a batch of graphs (block-diagonal adjacency): gptr[B+1] = first row of each graph,
+ * nmax = largest graph.  Lets wide rows use the LDS graph-slab kernel (each X element is read from HBM once). */
+int cgc_spmm_graphs(const int* rowptr, const int* col, const int* perm, const float* val, const float* pre,
+                    const float* post, const float* x, float* out, int n, int width, const int* gptr, int B, int nmax,
+                    cgc_stream_t stream);
+
 /* ---- A4/A5/A8: dense contractions on fp32 MFMA (v_mfma_f32_32x32x2_f32).  Replaces torch.matmul / nn.Linear at
  * model/network.py:122 (assignment Linear), :206-207 (S^T X, S^T A S), and the level-2/3 adj@x.
  * C_b = alpha*op(A_b)*op(B_b) + beta*C_b (+ bias[N]);  op(A): M x K (transA: stored [K,M]); op(B): K x N (transB: stored [N,K]).

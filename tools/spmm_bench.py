@@ -1,0 +1,43 @@
+#!/usr/bin/env python
+"""Micro-benchmark of the wide aggregation SpMM (K4: A*S, width = cluster count) on C3-shaped graphs.  GPU only.
+Reports algorithmic GB/s = (8 n W + 4(n+1) + 4 nnz) / time.  usage: python tools/spmm_bench.py [width ...]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import cgc_net_amd  # noqa: E402,F401
+from cgc_net_amd import kernels  # noqa: E402
+from cgc_net_amd.data import Batch, SyntheticCellGraphs  # noqa: E402
+from cgc_net_amd.graph import BatchGraph  # noqa: E402
+
+dev = 'cuda:0'
+K = kernels.get()
+widths = [int(a) for a in sys.argv[1:]] or [1140]
+ds = SyntheticCellGraphs(32, 1800, 16, base_seed=0)
+b = Batch.from_data_list([ds[i] for i in range(32)]).to(dev)
+g = BatchGraph.from_batch(b)
+n, nnz = g.n, g.nnz
+for W in widths:
+    x = torch.randn(n, W, device=dev)
+    out = torch.empty_like(x)
+    def run():
+        K.spmm(g.rowptr, g.col, None, None, None, None, x, out, n, W, g.gptr, g.B, g.nmax)
+    def run_t():
+        K.spmm(g.t_rowptr, g.t_col, None, None, None, None, x, out, n, W, g.gptr, g.B, g.nmax)
+    for name, fn in (('A x', run), ('A^T x', run_t)):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(10):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        ms = s.elapsed_time(e) / 10
+        by = 8.0 * n * W + 4.0 * (n + 1) + 4.0 * nnz
+        print('%-6s n=%d nnz=%d W=%5d  %8.1f us  %7.1f GB/s algorithmic (%.1f%% of 8 TB/s)  [env %s]' % (
+            name, n, nnz, W, ms * 1e3, by / ms / 1e6, by / ms / 1e6 / 80.0,
+            {k: v for k, v in os.environ.items() if k.startswith('CGC_SPMM')}))
