@@ -163,7 +163,16 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const GemmArgs a) {   // 2 
   float* const As0 = lds;                 // As[buf] = As0 + buf*A_SZ
   float* const Bs0 = lds + 2 * A_SZ;      // Bs[buf] = Bs0 + buf*B_SZ
 
-  const int b = blockIdx.z;
+  // XCD-aware workgroup order (speed only): workgroups are dealt round-robin to the 8 XCDs, each with a private 4 MiB L2.
+  // Give every XCD a CONTIGUOUS run of (batch, tile_m, tile_n) ids, tile_n fastest: the ~64 workgroups resident on an XCD
+  // then form a (few tile_m) x (all tile_n) super-tile that streams each A panel and each B panel through that L2 once
+  // (measured before this remap: 31-50 % L2 hit rate and ~9x the algorithmic bytes fetched from the fabric).
+  const unsigned per_batch = gridDim.x, total = gridDim.x * gridDim.z;
+  const unsigned lin = blockIdx.z * per_batch + blockIdx.x;
+  const unsigned q8 = total >> 3, r8 = total & 7u, xcd = lin & 7u;
+  const unsigned vb = xcd * q8 + (xcd < r8 ? xcd : r8) + (lin >> 3);
+  const int b = vb / per_batch;
+  const int tile_id = vb - b * per_batch;
   int M = a.M, K = a.K;
   const float* A = a.A + (size_t)b * a.strideA;
   const float* B = a.B + (size_t)b * a.strideB;
@@ -179,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const GemmArgs a) {   // 2 
     A += (size_t)g0 * a.lda;
     B += (size_t)g0 * a.ldb;
   }
-  const int tile_m = blockIdx.x / a.tiles_n, tile_n = blockIdx.x - tile_m * a.tiles_n;
+  const int tile_m = tile_id / a.tiles_n, tile_n = tile_id - tile_m * a.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   if (m0 >= M) return;
   const int N = a.N;

@@ -1,0 +1,28 @@
+#!/usr/bin/env python
+"""Per-kernel medians of rocprofv3 --pmc counter_collection.csv files (one directory per pass).
+usage: summarize_pmc.py dir1 [dir2 ...] [--match substr]
+FETCH_SIZE / WRITE_SIZE are in KiB-ish units of 1 KB (rocprofv3); on gfx950 FETCH_SIZE reports HALF of the bytes of a wide
+coalesced read (MI355X_MICROARCH.md, HBM section) -- the 'x2' column applies that correction."""
+import collections
+import csv
+import sys
+
+
+def main():
+    dirs = [a for a in sys.argv[1:] if not a.startswith('--')]
+    match = sys.argv[sys.argv.index('--match') + 1] if '--match' in sys.argv else ''
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for d in dirs:
+        for r in csv.DictReader(open(d.rstrip('/') + '/p_counter_collection.csv')):
+            name = r['Kernel_Name'].split('(')[0].replace('void ', '')
+            if match in name:
+                agg[name][r['Counter_Name']].append(float(r['Counter_Value']))
+    print('%-70s %-14s %8s %14s %14s' % ('kernel', 'counter', 'calls', 'median', 'max'))
+    for name in sorted(agg, key=lambda k: -max(max(v) for v in agg[k].values())):
+        for c, vals in sorted(agg[name].items()):
+            vals = sorted(vals)
+            print('%-70s %-14s %8d %14.4g %14.4g' % (name[:70], c, len(vals), vals[len(vals) // 2], vals[-1]))
+
+
+if __name__ == '__main__':
+    main()
