@@ -317,22 +317,144 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const GemmArgs a) {   // 2 
     }
 }
 
+template <int WGM, int WGN, int TM, int TN, bool TA, bool TB>
+__global__ __launch_bounds__(256, 3) void k_gemm_f32_shortk(const GemmArgs a) {
+  constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
+  constexpr int LDA_S = TA ? BM + 4 : KC_LD;   // TA: A stored [K,M] -> k-major tile; else row-major [m][k]
+  constexpr int LDB_S = TB ? KC_LD : BN + 4;   // TB: B stored [N,K] -> row-major [n][k]; else k-major
+  constexpr int A_SZ = TA ? BK * LDA_S : BM * KC_LD, B_SZ = TB ? BN * KC_LD : BK * LDB_S;   // multiples of 4 words
+  __shared__ __attribute__((aligned(16))) float lds[A_SZ + B_SZ];   // ONE stage: 36.9 KB; 3 workgroups per CU (register-limited)
+  float* const As0 = lds;                 // As[buf] = As0 + buf*A_SZ
+  float* const Bs0 = lds + A_SZ;
+
+  // XCD-aware workgroup order (speed only): workgroups are dealt round-robin to the 8 XCDs, each with a private 4 MiB L2.
+  // Give every XCD a CONTIGUOUS run of (batch, tile_m, tile_n) ids, tile_n fastest: the ~64 workgroups resident on an XCD
+  // then form a (few tile_m) x (all tile_n) super-tile that streams each A panel and each B panel through that L2 once
+  // (measured before this remap: 31-50 % L2 hit rate and ~9x the algorithmic bytes fetched from the fabric).
+  const unsigned per_batch = gridDim.x, total = gridDim.x * gridDim.z;
+  const unsigned lin = blockIdx.z * per_batch + blockIdx.x;
+  const unsigned q8 = total >> 3, r8 = total & 7u, xcd = lin & 7u;
+  const unsigned vb = xcd * q8 + (xcd < r8 ? xcd : r8) + (lin >> 3);
+  const int b = vb / per_batch;
+  const int tile_id = vb - b * per_batch;
+  int M = a.M, K = a.K;
+  const float* A = a.A + (size_t)b * a.strideA;
+  const float* B = a.B + (size_t)b * a.strideB;
+  float* C = a.C + (size_t)b * a.strideC;
+  if (a.ragged == 1) {
+    const int g0 = a.gptr[b];
+    M = a.gptr[b + 1] - g0;
+    A += (size_t)g0 * a.lda;
+    C += (size_t)g0 * a.ldc;
+  } else if (a.ragged == 2) {
+    const int g0 = a.gptr[b];
+    K = a.gptr[b + 1] - g0;
+    A += (size_t)g0 * a.lda;
+    B += (size_t)g0 * a.ldb;
+  }
+  const int tile_m = tile_id / a.tiles_n, tile_n = tile_id - tile_m * a.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  if (m0 >= M) return;
+  const int N = a.N;
+
+  const bool vecA = (a.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) & 15u) == 0);
+  const bool vecB = (a.ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(B) & 15u) == 0);
+
+  typedef typename std::conditional<TA, MnContigLoader<BM>, KContigLoader<BM>>::type LoaderA;
+  typedef typename std::conditional<TB, KContigLoader<BN>, MnContigLoader<BN>>::type LoaderB;
+  LoaderA la0;
+  LoaderB lb0;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / WGN, wn = wave - wm * WGN;
+  const int l31 = lane & 31, lhi = lane >> 5;
+
+  floatx16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = (K + BK - 1) / BK, nk_full = K / BK;
+  // unguarded 16-byte loads for full k-tiles when the layout allows (block-uniform decision)
+  const bool fastA = vecA && (TA ? (M % 4 == 0 && M >= 4) : true);
+  const bool fastB = vecB && (TB ? true : (N % 4 == 0 && N >= 4));
+  const int a_last = TA ? M - 4 : M - 1, b_last = TB ? N - 1 : N - 4;
+  auto fetch = [&](LoaderA& la, LoaderB& lb, int kt) {
+    if (fastA && kt < nk_full) la.load_fast(A, a.lda, m0, a_last, kt * BK);
+    else la.load(A, a.lda, m0, M, kt * BK, K, vecA);
+    if (fastB && kt < nk_full) lb.load_fast(B, a.ldb, n0, b_last, kt * BK);
+    else lb.load(B, a.ldb, n0, N, kt * BK, K, vecB);
+  };
+  // Short reductions (K <= 96: rank-k updates such as dS += X dX'^T, dA~ = g x^T, h = agg W): the kernel is bound by the
+  // C tile it writes (and reads when beta != 0), not by the MFMAs.  One LDS stage keeps the footprint at 36.9 KB so that three
+  // workgroups share a CU and overlap each other's load / compute / store phases.
+  for (int kt = 0; kt < nk; ++kt) {
+    fetch(la0, lb0, kt);
+    if (kt > 0) __syncthreads();          // everybody finished reading the previous tile
+    la0.store(As0);
+    lb0.store(Bs0);
+    __syncthreads();
+    const float* as = As0 + (TA ? wm * TM * 32 : wm * TM * 32 * KC_LD);
+    const float* bs = Bs0 + (TB ? wn * TN * 32 * KC_LD : wn * TN * 32);
+#pragma unroll
+    for (int kb = 0; kb < BK / 8; ++kb) {
+      float av[TM][4], bv[TN][4];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fetch_frag<TA, LDA_S>(as + (TA ? i * 32 : i * 32 * KC_LD), kb, l31, lhi, av[i]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fetch_frag<!TB, LDB_S>(bs + (TB ? j * 32 * KC_LD : j * 32), kb, l31, lhi, bv[j]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][t], bv[j][t], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const float alpha = a.alpha, beta = a.beta;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + (wn * TN + j) * 32 + l31;
+      if (col >= N) continue;
+      const float bia = a.bias != nullptr ? a.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        if (row < M) {
+          float* p = C + (size_t)row * a.ldc + col;
+          float v = alpha * acc[i][j][r] + bia;
+          if (beta != 0.f) v += beta * (*p);
+          *p = v;
+        }
+      }
+    }
+}
+
 template <int WGM, int WGN, int TM, int TN>
-static int launch_cfg(const GemmArgs& a0, int transA, int transB, int batch, int m_extent, hipStream_t stream) {
+static int launch_cfg(const GemmArgs& a0, int transA, int transB, int batch, int m_extent, bool short_k, hipStream_t stream) {
   constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
   GemmArgs a = a0;
   a.tiles_n = ceil_div(a.N, BN);
   const long long tiles = (long long)ceil_div(m_extent, BM) * a.tiles_n;
   if (tiles <= 0 || tiles > 0x7fffffffLL || batch > 65535) return CGC_EINVAL;
   dim3 grid((unsigned)tiles, 1, (unsigned)batch), block(256);
-  if (!transA && !transB)
-    hipLaunchKernelGGL((k_gemm_f32<WGM, WGN, TM, TN, false, false>), grid, block, 0, stream, a);
-  else if (!transA && transB)
-    hipLaunchKernelGGL((k_gemm_f32<WGM, WGN, TM, TN, false, true>), grid, block, 0, stream, a);
-  else if (transA && !transB)
-    hipLaunchKernelGGL((k_gemm_f32<WGM, WGN, TM, TN, true, false>), grid, block, 0, stream, a);
-  else
-    return CGC_EINVAL;
+  if (transA && transB) return CGC_EINVAL;
+  if (short_k) {
+    if (!transA && !transB) hipLaunchKernelGGL((k_gemm_f32_shortk<WGM, WGN, TM, TN, false, false>), grid, block, 0, stream, a);
+    else if (!transA) hipLaunchKernelGGL((k_gemm_f32_shortk<WGM, WGN, TM, TN, false, true>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((k_gemm_f32_shortk<WGM, WGN, TM, TN, true, false>), grid, block, 0, stream, a);
+  } else {
+    if (!transA && !transB) hipLaunchKernelGGL((k_gemm_f32<WGM, WGN, TM, TN, false, false>), grid, block, 0, stream, a);
+    else if (!transA) hipLaunchKernelGGL((k_gemm_f32<WGM, WGN, TM, TN, false, true>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((k_gemm_f32<WGM, WGN, TM, TN, true, false>), grid, block, 0, stream, a);
+  }
   CGC_RETURN_IF_LAUNCH_FAILED();
   return 0;
 }
@@ -352,15 +474,23 @@ extern "C" int cgc_gemm_f32(int transA, int transB, int M, int N, int K, float a
   a.strideA = strideA; a.strideB = strideB; a.strideC = strideC;
   a.alpha = alpha; a.beta = beta; a.ragged = ragged; a.tiles_n = 0;
   hipStream_t stream = as_stream(stream_);
-  // tile shape by output aspect: the hot contractions are (>=1140) x (>=1140); the skinny ones are K- or output-bound
-  if (N <= 32) return launch_cfg<4, 1, 1, 1>(a, transA, transB, batch, m_extent, stream);   // 128 x 32
-  if (N <= 64) return launch_cfg<4, 1, 1, 2>(a, transA, transB, batch, m_extent, stream);   // 128 x 64
-  if (m_extent <= 32) return launch_cfg<1, 4, 1, 1>(a, transA, transB, batch, m_extent, stream);   // 32 x 128
-  if (m_extent <= 64) return launch_cfg<1, 4, 2, 1>(a, transA, transB, batch, m_extent, stream);   // 64 x 128
-  // too few 128x128 tiles to fill 256 CUs x 2 resident workgroups: halve the tile width
-  if ((long long)ceil_div(m_extent, 128) * ceil_div(N, 128) * batch < 448)
-    return launch_cfg<4, 1, 1, 2>(a, transA, transB, batch, m_extent, stream);                       // 128 x 64
-  return launch_cfg<2, 2, 2, 2>(a, transA, transB, batch, m_extent, stream);                        // 128 x 128
+  // tile shape by output aspect: the hot contractions are (>=1140) x (>=1140); the skinny ones are K- or output-bound.
+  // `fill` = workgroups a 128-row tiling would launch; below ~448 (256 CUs x 2 resident) the tile is halved in M.
+  const int k_extent = ragged == 2 ? max_ragged : K;
+  const bool sk = k_extent <= 96;
+  const long long fill = (long long)ceil_div(m_extent, 128) * batch;
+  if (N <= 32) return launch_cfg<4, 1, 1, 1>(a, transA, transB, batch, m_extent, sk, stream);          // 128 x 32
+  if (N <= 64) {
+    if (m_extent > 64 && fill < 448) return launch_cfg<2, 2, 1, 1>(a, transA, transB, batch, m_extent, sk, stream);   // 64 x 64
+    return launch_cfg<4, 1, 1, 2>(a, transA, transB, batch, m_extent, sk, stream);                                     // 128 x 64
+  }
+  if (m_extent <= 32) return launch_cfg<1, 4, 1, 1>(a, transA, transB, batch, m_extent, sk, stream);   // 32 x 128
+  if (m_extent <= 64) return launch_cfg<1, 4, 2, 1>(a, transA, transB, batch, m_extent, sk, stream);   // 64 x 128
+  if (fill * ceil_div(N, 128) < 448) {   // measured on [32 x 1140 x 1140] x [1140 x 114]: NN/NT prefer 64x128, TN prefers 128x64
+    if (transA) return launch_cfg<4, 1, 1, 2>(a, transA, transB, batch, m_extent, sk, stream);
+    return launch_cfg<1, 4, 2, 1>(a, transA, transB, batch, m_extent, sk, stream);
+  }
+  return launch_cfg<2, 2, 2, 2>(a, transA, transB, batch, m_extent, sk, stream);                        // 128 x 128
 }
 
 // ---- deterministic split-K combine

@@ -327,9 +327,10 @@ class SoftPoolingGcnEncoder(nn.Module):
             adj = ops.renorm_dense(adj, RENORM_P)
         emb_blk = getattr(self, 'GCN_embed_%d' % level)
         a = ops.rownorm_clamp(adj) if emb_blk.mean_aggregation else adj
+        shared = ops.SharedGrad() if (torch.is_grad_enabled() and a.requires_grad) else None   # one d(adjacency) buffer per level
 
         def aggregate(h):
-            return ops.bmatmul(a, h.view(B, C, -1)).view(B * C, -1)
+            return ops.bmatmul(a, h.view(B, C, -1), shared=shared).view(B * C, -1)
         xf = x.reshape(B * C, -1)
         agg0 = aggregate(xf)
         embed = emb_blk.run_rows(xf, aggregate, B * C, agg0)

@@ -329,10 +329,42 @@ def _bgemm(A, B, C, tA, tB, beta=0.0):
              A.shape[1] * A.shape[2], B.shape[1] * B.shape[2], M * N)
 
 
+class SharedGrad(object):
+    """Gradient accumulator for ONE tensor that feeds several _BMatmul nodes as operand A (the row-normalised adjacency
+    of a dense level feeds every convolution of both blocks).  Each node adds its contribution into one buffer with the
+    GEMM's beta = 1; the node that contributes last hands the buffer to autograd, the others report no gradient.  This
+    replaces (uses - 1) full-size `add` kernels and temporaries of [B, C, C] per level; the result does not depend on the
+    order in which autograd runs the nodes."""
+
+    def __init__(self):
+        self.uses = 0
+        self.pending = 0
+        self.buf = None
+
+    def register(self):
+        self.uses += 1
+        self.pending = self.uses
+
+    def contribute(self, like, write):
+        """write(buf, beta) must perform buf = beta*buf + contribution.  Returns the total once complete, else None."""
+        first = self.buf is None
+        if first:
+            self.buf = torch.empty_like(like)
+        write(self.buf, 0.0 if first else 1.0)
+        self.pending -= 1
+        if self.pending == 0:
+            out, self.buf, self.pending = self.buf, None, self.uses
+            return out
+        return None
+
+
 class _BMatmul(Function):
     @staticmethod
-    def forward(ctx, A, B, tA, tB):
+    def forward(ctx, A, B, tA, tB, shared=None):
         A, B = _f32c(A), _f32c(B)
+        ctx.shared = shared
+        if shared is not None:
+            shared.register()
         M = A.shape[2] if tA else A.shape[1]
         N = B.shape[1] if tB else B.shape[2]
         C = torch.empty(A.shape[0], M, N, dtype=torch.float32, device=A.device)
@@ -348,23 +380,29 @@ class _BMatmul(Function):
         dC = _f32c(dC)
         dA = dB = None
         if ctx.needs_input_grad[0]:
-            dA = torch.empty_like(A)
-            if not tA:
-                _bgemm(dC, B, dA, False, not tB)        # dA = dC op(B)^T
+            def write(buf, beta):
+                if not tA:
+                    _bgemm(dC, B, buf, False, not tB, beta)   # dA = dC op(B)^T
+                else:
+                    _bgemm(B, dC, buf, tB, True, beta)        # dA = op(B) dC^T
+            if ctx.shared is not None:
+                dA = ctx.shared.contribute(A, write)
             else:
-                _bgemm(B, dC, dA, tB, True)             # dA = op(B) dC^T
+                dA = torch.empty_like(A)
+                write(dA, 0.0)
         if ctx.needs_input_grad[1]:
             dB = torch.empty_like(B)
             if not tB:
                 _bgemm(A, dC, dB, not tA, False)        # dB = op(A)^T dC
             else:
                 _bgemm(dC, A, dB, True, tA)             # dB = dC^T op(A)
-        return dA, dB, None, None
+        return dA, dB, None, None, None
 
 
-def bmatmul(A, B, tA=False, tB=False):
+def bmatmul(A, B, tA=False, tB=False, shared=None):
+    """``shared``: a SharedGrad that every bmatmul using the same A passes (optional; see SharedGrad)."""
     assert not (tA and tB)
-    return _BMatmul.apply(A, B, tA, tB)
+    return _BMatmul.apply(A, B, tA, tB, shared)
 
 
 def diff_pool_dense(embed, adj, s):
