@@ -33,6 +33,14 @@ struct GemmArgs {
   float alpha, beta;
   int ragged;
   int tiles_n;
+  // optional extra K segments: C += alpha * A_x[s] * B_x[s] (same op() orientation, M, N as the main pair), i.e. the
+  // product of the column-concatenated [A | A_x0 | A_x1] with the row-concatenated [B ; B_x0 ; B_x1] without ever
+  // materialising the concatenation (Linear over cat[x1,x2,x3]; dS = P dA'^T + X dX'^T)
+  int nx;
+  const float* xA[2];
+  const float* xB[2];
+  int xlda[2], xldb[2], xK[2];
+  long long xsA[2], xsB[2];
 };
 
 #define BK 32
@@ -213,16 +221,44 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const GemmArgs a) {   // 2 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nk = (K + BK - 1) / BK, nk_full = K / BK;
+  const int nk_main = (K + BK - 1) / BK, nk_full = K / BK;
+  // extra K segments follow the main operand pair in the tile sequence (always through the guarded loader: they are short)
+  const float* xA0 = nullptr; const float* xB0 = nullptr; const float* xA1 = nullptr; const float* xB1 = nullptr;
+  int nkx0 = 0, nkx1 = 0;
+  if (a.nx > 0) {
+    const size_t roff = a.ragged == 1 ? (size_t)a.gptr[b] : 0;
+    xA0 = a.xA[0] + (size_t)b * a.xsA[0] + roff * a.xlda[0];
+    xB0 = a.xB[0] + (size_t)b * a.xsB[0];
+    nkx0 = (a.xK[0] + BK - 1) / BK;
+    if (a.nx > 1) {
+      xA1 = a.xA[1] + (size_t)b * a.xsA[1] + roff * a.xlda[1];
+      xB1 = a.xB[1] + (size_t)b * a.xsB[1];
+      nkx1 = (a.xK[1] + BK - 1) / BK;
+    }
+  }
+  const int nk = nk_main + nkx0 + nkx1;
   // unguarded 16-byte loads for full k-tiles when the layout allows (block-uniform decision)
   const bool fastA = vecA && (TA ? (M % 4 == 0 && M >= 4) : true);
   const bool fastB = vecB && (TB ? true : (N % 4 == 0 && N >= 4));
   const int a_last = TA ? M - 4 : M - 1, b_last = TB ? N - 1 : N - 4;
   auto fetch = [&](LoaderA& la, LoaderB& lb, int kt) {
-    if (fastA && kt < nk_full) la.load_fast(A, a.lda, m0, a_last, kt * BK);
-    else la.load(A, a.lda, m0, M, kt * BK, K, vecA);
-    if (fastB && kt < nk_full) lb.load_fast(B, a.ldb, n0, b_last, kt * BK);
-    else lb.load(B, a.ldb, n0, N, kt * BK, K, vecB);
+    if (kt < nk_main) {
+      if (fastA && kt < nk_full) la.load_fast(A, a.lda, m0, a_last, kt * BK);
+      else la.load(A, a.lda, m0, M, kt * BK, K, vecA);
+      if (fastB && kt < nk_full) lb.load_fast(B, a.ldb, n0, b_last, kt * BK);
+      else lb.load(B, a.ldb, n0, N, kt * BK, K, vecB);
+    } else {
+      int kx = kt - nk_main;
+      const bool second = kx >= nkx0;
+      if (second) kx -= nkx0;
+      const float* Ax = second ? xA1 : xA0;
+      const float* Bx = second ? xB1 : xB0;
+      const int ldax = a.xlda[second], ldbx = a.xldb[second], Kx = a.xK[second];
+      const bool va = (ldax % 4 == 0) && ((reinterpret_cast<uintptr_t>(Ax) & 15u) == 0);
+      const bool vb = (ldbx % 4 == 0) && ((reinterpret_cast<uintptr_t>(Bx) & 15u) == 0);
+      la.load(Ax, ldax, m0, M, kx * BK, Kx, va);
+      lb.load(Bx, ldbx, n0, N, kx * BK, Kx, vb);
+    }
   };
   // One k-tile: consume LDS buffer `cur` with 4 groups of TM*TN*4 MFMAs.  The fragments of group kb+1 are read from LDS
   // before the MFMAs of group kb are issued; between the groups a quarter of the NEXT tile (already in registers `ls_*`)
@@ -459,25 +495,18 @@ static int launch_cfg(const GemmArgs& a0, int transA, int transB, int batch, int
   return 0;
 }
 
-extern "C" int cgc_gemm_f32(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda, const float* B, int ldb,
-                            float beta, float* C, int ldc, const float* bias, int batch, int64_t strideA, int64_t strideB,
-                            int64_t strideC, const int* gptr, int ragged, int max_ragged, cgc_stream_t stream_) {
+static int gemm_dispatch(GemmArgs& a, int transA, int transB, int batch, int max_ragged, hipStream_t stream) {
+  const int M = a.M, N = a.N, K = a.K, ragged = a.ragged;
   if (batch <= 0 || N <= 0) return 0;
-  if (ragged == 1 && (transA || gptr == nullptr)) return CGC_EINVAL;
-  if (ragged == 2 && (!transA || transB || gptr == nullptr)) return CGC_EINVAL;
+  if (ragged == 1 && (transA || a.gptr == nullptr)) return CGC_EINVAL;
+  if (ragged == 2 && (!transA || transB || a.gptr == nullptr || a.nx > 0)) return CGC_EINVAL;
   if (ragged < 0 || ragged > 2) return CGC_EINVAL;
   const int m_extent = ragged == 1 ? max_ragged : M;
   if (m_extent <= 0) return 0;
-  GemmArgs a;
-  a.A = A; a.B = B; a.C = C; a.bias = bias; a.gptr = gptr;
-  a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
-  a.strideA = strideA; a.strideB = strideB; a.strideC = strideC;
-  a.alpha = alpha; a.beta = beta; a.ragged = ragged; a.tiles_n = 0;
-  hipStream_t stream = as_stream(stream_);
   // tile shape by output aspect: the hot contractions are (>=1140) x (>=1140); the skinny ones are K- or output-bound.
   // `fill` = workgroups a 128-row tiling would launch; below ~448 (256 CUs x 2 resident) the tile is halved in M.
   const int k_extent = ragged == 2 ? max_ragged : K;
-  const bool sk = k_extent <= 96;
+  const bool sk = k_extent <= 96 && a.nx == 0;
   const long long fill = (long long)ceil_div(m_extent, 128) * batch;
   if (N <= 32) return launch_cfg<4, 1, 1, 1>(a, transA, transB, batch, m_extent, sk, stream);          // 128 x 32
   if (N <= 64) {
@@ -491,6 +520,44 @@ extern "C" int cgc_gemm_f32(int transA, int transB, int M, int N, int K, float a
     return launch_cfg<1, 4, 2, 1>(a, transA, transB, batch, m_extent, sk, stream);
   }
   return launch_cfg<2, 2, 2, 2>(a, transA, transB, batch, m_extent, sk, stream);                        // 128 x 128
+}
+
+static void gemm_fill(GemmArgs& a, int M, int N, int K, float alpha, const float* A, int lda, const float* B, int ldb, float beta,
+                      float* C, int ldc, const float* bias, int64_t strideA, int64_t strideB, int64_t strideC, const int* gptr,
+                      int ragged) {
+  a.A = A; a.B = B; a.C = C; a.bias = bias; a.gptr = gptr;
+  a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
+  a.strideA = strideA; a.strideB = strideB; a.strideC = strideC;
+  a.alpha = alpha; a.beta = beta; a.ragged = ragged; a.tiles_n = 0;
+  a.nx = 0;
+  for (int i = 0; i < 2; ++i) { a.xA[i] = a.xB[i] = nullptr; a.xlda[i] = a.xldb[i] = a.xK[i] = 0; a.xsA[i] = a.xsB[i] = 0; }
+}
+
+extern "C" int cgc_gemm_f32(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda, const float* B, int ldb,
+                            float beta, float* C, int ldc, const float* bias, int batch, int64_t strideA, int64_t strideB,
+                            int64_t strideC, const int* gptr, int ragged, int max_ragged, cgc_stream_t stream_) {
+  GemmArgs a;
+  gemm_fill(a, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, strideA, strideB, strideC, gptr, ragged);
+  return gemm_dispatch(a, transA, transB, batch, max_ragged, as_stream(stream_));
+}
+
+extern "C" int cgc_gemm_f32_cat(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda, const float* B,
+                                int ldb, float beta, float* C, int ldc, const float* bias, int batch, int64_t strideA,
+                                int64_t strideB, int64_t strideC, const int* gptr, int ragged, int max_ragged, int nx,
+                                const float* const* xA, const int* xlda, const int64_t* xstrideA, const float* const* xB,
+                                const int* xldb, const int64_t* xstrideB, const int* xK, cgc_stream_t stream_) {
+  if (nx < 0 || nx > 2) return CGC_EINVAL;
+  GemmArgs a;
+  gemm_fill(a, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, strideA, strideB, strideC, gptr, ragged);
+  int kept = 0;
+  for (int i = 0; i < nx; ++i) {
+    if (xK[i] <= 0) continue;
+    a.xA[kept] = xA[i]; a.xB[kept] = xB[i]; a.xlda[kept] = xlda[i]; a.xldb[kept] = xldb[i]; a.xK[kept] = xK[i];
+    a.xsA[kept] = xstrideA[i]; a.xsB[kept] = xstrideB[i];
+    ++kept;
+  }
+  a.nx = kept;
+  return gemm_dispatch(a, transA, transB, batch, max_ragged, as_stream(stream_));
 }
 
 // ---- deterministic split-K combine

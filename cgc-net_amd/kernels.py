@@ -52,7 +52,7 @@ class KernelSpec(object):
 
     # ------------------------------------------------------------------ dense contractions (MFMA fp32)
     def gemm(self, A, B, C, M, N, K, transA, transB, lda, ldb, ldc, alpha=1.0, beta=0.0, bias=None,
-             batch=1, strideA=0, strideB=0, strideC=0, gptr=None, ragged=0, max_ragged=0, ragged_total=0):
+             batch=1, strideA=0, strideB=0, strideC=0, gptr=None, ragged=0, max_ragged=0, ragged_total=0, extra=()):
         """C_b = alpha * op(A_b) op(B_b) + beta * C_b (+ bias[N]),  b = 0..batch-1, row-major.
 
         op(A) is M x K (stored [M,K] or, transA, [K,M]); op(B) is K x N (stored [K,N] or, transB, [N,K]).
@@ -60,6 +60,8 @@ class KernelSpec(object):
         (not transposed) and C advance by gptr[b] rows.  ragged=2: K_b = gptr[b+1]-gptr[b], A (transposed)
         and B (not transposed) advance by gptr[b] rows.  max_ragged bounds the ragged extent (grid size);
         ragged_total = sum of the ragged extents (host-side flop accounting only).
+        extra: up to two (A_x, B_x, lda, ldb, K_x, strideA, strideB) pairs whose products are added to op(A)op(B)
+        (same orientation, M, N, batch and ragged row offsets): the concatenated-K product without the concatenation.
         """
         raise NotImplementedError
 
@@ -263,21 +265,35 @@ class HipKernels(KernelSpec):
 
     # -- dense contractions
     def gemm(self, A, B, C, M, N, K, transA, transB, lda, ldb, ldc, alpha=1.0, beta=0.0, bias=None,
-             batch=1, strideA=0, strideB=0, strideC=0, gptr=None, ragged=0, max_ragged=0, ragged_total=0):
+             batch=1, strideA=0, strideB=0, strideC=0, gptr=None, ragged=0, max_ragged=0, ragged_total=0, extra=()):
         self._dev(A, B, C, bias, gptr)
         t0 = None
         if self.timer is not None and N > 64 and (max_ragged if ragged == 1 else M) > 64:
             # algorithmic flops of this launch: 2*M*N*K summed over the batch (ragged extents sum to the row count)
+            kk = K + sum(e[4] for e in extra)
             if ragged:
-                flops = 2.0 * (M if ragged == 2 else K) * N * ragged_total
+                flops = 2.0 * (M if ragged == 2 else kk) * N * ragged_total
             else:
-                flops = 2.0 * M * N * K * batch
+                flops = 2.0 * M * N * kk * batch
             if flops >= 1e9:
                 t0 = self.timer.begin()
-        rc = self.lib.cgc_gemm_f32(int(transA), int(transB), M, N, K, ctypes.c_float(alpha), _ptr(A), lda,
-                                   _ptr(B), ldb, ctypes.c_float(beta), _ptr(C), ldc, _ptr(bias), batch,
-                                   ctypes.c_int64(strideA), ctypes.c_int64(strideB), ctypes.c_int64(strideC),
-                                   _ptr(gptr), ragged, max_ragged, self._stream())
+        if extra:
+            nx = len(extra)
+            self._dev(*[e[0] for e in extra], *[e[1] for e in extra])
+            PA, IA, LA = ctypes.c_void_p * nx, ctypes.c_int * nx, ctypes.c_int64 * nx
+            rc = self.lib.cgc_gemm_f32_cat(int(transA), int(transB), M, N, K, ctypes.c_float(alpha), _ptr(A), lda,
+                                           _ptr(B), ldb, ctypes.c_float(beta), _ptr(C), ldc, _ptr(bias), batch,
+                                           ctypes.c_int64(strideA), ctypes.c_int64(strideB), ctypes.c_int64(strideC),
+                                           _ptr(gptr), ragged, max_ragged, nx,
+                                           PA(*[e[0].data_ptr() for e in extra]), IA(*[e[2] for e in extra]),
+                                           LA(*[e[5] for e in extra]), PA(*[e[1].data_ptr() for e in extra]),
+                                           IA(*[e[3] for e in extra]), LA(*[e[6] for e in extra]),
+                                           IA(*[e[4] for e in extra]), self._stream())
+        else:
+            rc = self.lib.cgc_gemm_f32(int(transA), int(transB), M, N, K, ctypes.c_float(alpha), _ptr(A), lda,
+                                       _ptr(B), ldb, ctypes.c_float(beta), _ptr(C), ldc, _ptr(bias), batch,
+                                       ctypes.c_int64(strideA), ctypes.c_int64(strideB), ctypes.c_int64(strideC),
+                                       _ptr(gptr), ragged, max_ragged, self._stream())
         self._chk(rc, 'cgc_gemm_f32')
         if t0 is not None:
             self.timer.end('gemm_128x128', t0, flops)

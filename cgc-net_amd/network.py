@@ -202,13 +202,15 @@ class GNN_Module(nn.Module):
                     z = ops.l2_act_bn(z, None, count, 'identity', True, self.training)
                 h = ops.l2_act_bn(z * row_mask, bn, count, self.activation, False, self.training)
             outs.append(h)
+        if self.lin is not None and row_mask is None:
+            # Linear over cat[x1,x2,x3] without the concatenation: the two narrow pieces are joined (cheap), the wide one
+            # ([rows, cluster count]) is the main operand of the same GEMM
+            return ops.linear_cat([torch.cat(outs[:2], dim=-1), outs[2]], self.lin.weight, self.lin.bias)
         h = torch.cat(outs, dim=-1)
         if row_mask is not None:
             h = h * row_mask
         if self.lin is not None:
-            h = ops.linear_bias(h, self.lin.weight, self.lin.bias, out_in_layout=True)
-            if row_mask is not None:
-                h = h * row_mask
+            h = ops.linear_bias(h, self.lin.weight, self.lin.bias, out_in_layout=True) * row_mask
         return h
 
     def forward_graph(self, x, g, agg0=None):

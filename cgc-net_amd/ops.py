@@ -155,6 +155,60 @@ def linear_bias(x, weight, bias=None, out_in_layout=False):
     return _LinearBias.apply(x, weight, bias, out_in_layout)
 
 
+class _LinearCat(Function):
+    """y = cat(xs, dim=1) @ W^T + b with W in nn.Linear layout [out, sum F_k]; the concatenation is never formed:
+    the widest x_k is the main operand of one GEMM, the others ride along as extra K segments (model/network.py:118-122)."""
+
+    @staticmethod
+    def forward(ctx, weight, bias, *xs):
+        xs = [_f32c(x) for x in xs]
+        weight = _f32c(weight)
+        n, fout, ftot = xs[0].shape[0], weight.shape[0], weight.shape[1]
+        offs, o = [], 0
+        for x in xs:
+            offs.append(o)
+            o += x.shape[1]
+        assert o == ftot and len(xs) <= 3
+        order = sorted(range(len(xs)), key=lambda i: -xs[i].shape[1])
+        m = order[0]
+        y = torch.empty(n, fout, dtype=torch.float32, device=weight.device)
+        extra = [(xs[i], weight[:, offs[i]:], xs[i].shape[1], ftot, xs[i].shape[1], 0, 0) for i in order[1:]]
+        K().gemm(xs[m], weight[:, offs[m]:], y, n, fout, xs[m].shape[1], False, True, xs[m].shape[1], ftot, fout,
+                 1.0, 0.0, bias, extra=extra)
+        ctx.save_for_backward(weight, *xs)
+        ctx.offs, ctx.has_bias = offs, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        weight, xs = ctx.saved_tensors[0], ctx.saved_tensors[1:]
+        dy, ld = _rows_ld(dy)
+        n, fout, ftot = dy.shape[0], weight.shape[0], weight.shape[1]
+        dw = db = None
+        dxs = [None] * len(xs)
+        if any(ctx.needs_input_grad[2:]):
+            dcat = torch.empty(n, ftot, dtype=torch.float32, device=dy.device)     # d cat = dy W ; the d x_k are column slices
+            K().gemm(dy, weight, dcat, n, ftot, fout, False, False, ld, ftot, ftot)
+            dxs = [dcat[:, o:o + x.shape[1]] if need else None
+                   for o, x, need in zip(ctx.offs, xs, ctx.needs_input_grad[2:])]
+        if ctx.needs_input_grad[0]:
+            dw = torch.empty_like(weight)
+            for o, x in zip(ctx.offs, xs):                                          # dW[:, slice_k] = dy^T x_k
+                f = x.shape[1]
+                tmp = torch.empty(fout, f, dtype=torch.float32, device=dy.device)
+                gemm_tn_rows(dy, ld, fout, x, f, f, n, tmp)
+                dw[:, o:o + f].copy_(tmp)
+        if ctx.has_bias and ctx.needs_input_grad[1]:
+            db = torch.empty(fout, dtype=torch.float32, device=dy.device)
+            K().colsum(dy, ld, n, fout, db)
+        return (dw, db) + tuple(dxs)
+
+
+def linear_cat(xs, weight, bias=None):
+    """nn.Linear applied to torch.cat(xs, dim=1) (at most 3 pieces) without forming the concatenation."""
+    return _LinearCat.apply(weight, bias, *xs)
+
+
 # ----------------------------------------------------------------------------------------------
 # row L2-normalise -> activation -> BatchNorm (statistics over `count` rows, zero padding included)
 # ----------------------------------------------------------------------------------------------
@@ -305,8 +359,9 @@ class _DiffPoolSparse(Function):
         ds = torch.empty_like(s)
         K().spmm(g.t_rowptr, g.t_col, g.t_perm if g.val is not None else None, g.val, None, None, dp, ds, n, c,
                  g.gptr, g.B, g.nmax)
-        K().gemm(p, dao, ds, 0, c, c, False, True, c, c, c, 1.0, 1.0, None, g.B, 0, c * c, 0, g.gptr, 1, g.nmax, n)
-        K().gemm(embed, dxo, ds, 0, c, dx, False, True, dx, dx, c, 1.0, 1.0, None, g.B, 0, c * dx, 0, g.gptr, 1, g.nmax, n)
+        # ... both products in one launch: [P | X] [dA' | dX']^T, the K = dx segment rides on the K = c product
+        K().gemm(p, dao, ds, 0, c, c, False, True, c, c, c, 1.0, 1.0, None, g.B, 0, c * c, 0, g.gptr, 1, g.nmax, n,
+                 extra=[(embed, dxo, dx, dx, dx, 0, c * dx)])
         # dX = S dX'
         de = torch.empty_like(embed)
         K().gemm(s, dxo, de, 0, dx, c, False, False, c, dx, dx, 1.0, 0.0, None, g.B, 0, c * dx, 0, g.gptr, 1, g.nmax, n)
@@ -330,32 +385,34 @@ def _bgemm(A, B, C, tA, tB, beta=0.0):
 
 
 class SharedGrad(object):
-    """Gradient accumulator for ONE tensor that feeds several _BMatmul nodes as operand A (the row-normalised adjacency
-    of a dense level feeds every convolution of both blocks).  Each node adds its contribution into one buffer with the
-    GEMM's beta = 1; the node that contributes last hands the buffer to autograd, the others report no gradient.  This
-    replaces (uses - 1) full-size `add` kernels and temporaries of [B, C, C] per level; the result does not depend on the
-    order in which autograd runs the nodes."""
+    """Deferred, batched gradient of ONE tensor A that feeds several ``C_i = A @ B_i`` nodes (the row-normalised adjacency
+    of a dense level feeds every convolution of both blocks).  dA = sum_i dC_i B_i^T is a sum of short (K = 20..60)
+    rank-k updates, each of which would write -- and, accumulating, re-read -- the full [B, C, C] tensor.  Instead every
+    node only deposits (dC_i, B_i); the node that arrives last concatenates them along the feature axis and issues ONE
+    product [dC_1 | dC_2 | ...] [B_1 | B_2 | ...]^T, so the [B, C, C] gradient is written once.  The other nodes report no
+    gradient; the result does not depend on the order in which autograd runs the nodes.  Every registered node must take
+    part in the backward pass (true for the encoder: all aggregations reach the loss)."""
 
     def __init__(self):
         self.uses = 0
         self.pending = 0
-        self.buf = None
+        self.parts = []
 
     def register(self):
         self.uses += 1
         self.pending = self.uses
 
-    def contribute(self, like, write):
-        """write(buf, beta) must perform buf = beta*buf + contribution.  Returns the total once complete, else None."""
-        first = self.buf is None
-        if first:
-            self.buf = torch.empty_like(like)
-        write(self.buf, 0.0 if first else 1.0)
+    def contribute(self, like, dC, B):
+        self.parts.append((dC, B))
         self.pending -= 1
-        if self.pending == 0:
-            out, self.buf, self.pending = self.buf, None, self.uses
-            return out
-        return None
+        if self.pending > 0:
+            return None
+        parts, self.parts, self.pending = self.parts, [], self.uses
+        g = parts[0][0] if len(parts) == 1 else torch.cat([p[0] for p in parts], dim=2)
+        x = parts[0][1] if len(parts) == 1 else torch.cat([p[1] for p in parts], dim=2)
+        dA = torch.empty_like(like)
+        _bgemm(g, x, dA, False, True)          # dA = [dC_1|dC_2|..] [B_1|B_2|..]^T
+        return dA
 
 
 class _BMatmul(Function):
@@ -380,16 +437,14 @@ class _BMatmul(Function):
         dC = _f32c(dC)
         dA = dB = None
         if ctx.needs_input_grad[0]:
-            def write(buf, beta):
-                if not tA:
-                    _bgemm(dC, B, buf, False, not tB, beta)   # dA = dC op(B)^T
-                else:
-                    _bgemm(B, dC, buf, tB, True, beta)        # dA = op(B) dC^T
             if ctx.shared is not None:
-                dA = ctx.shared.contribute(A, write)
+                dA = ctx.shared.contribute(A, dC, B)          # plain A @ B nodes only (asserted in bmatmul)
             else:
                 dA = torch.empty_like(A)
-                write(dA, 0.0)
+                if not tA:
+                    _bgemm(dC, B, dA, False, not tB)          # dA = dC op(B)^T
+                else:
+                    _bgemm(B, dC, dA, tB, True)               # dA = op(B) dC^T
         if ctx.needs_input_grad[1]:
             dB = torch.empty_like(B)
             if not tB:
@@ -402,6 +457,7 @@ class _BMatmul(Function):
 def bmatmul(A, B, tA=False, tB=False, shared=None):
     """``shared``: a SharedGrad that every bmatmul using the same A passes (optional; see SharedGrad)."""
     assert not (tA and tB)
+    assert shared is None or not (tA or tB)
     return _BMatmul.apply(A, B, tA, tB, shared)
 
 

@@ -73,6 +73,17 @@ int cgc_gemm_f32(int transA, int transB, int M, int N, int K, float alpha, const
                  int64_t strideA, int64_t strideB, int64_t strideC, const int* gptr, int ragged, int max_ragged,
                  cgc_stream_t stream);
 
+/* Same, with up to two EXTRA operand pairs that continue the reduction: C_b = alpha*( op(A_b)op(B_b) + sum_s op(xA[s]_b)op(xB[s]_b) )
+ * + beta*C_b (+bias), i.e. the product of column-concatenated A's with row-concatenated B's without materialising either
+ * (assignment Linear over cat[x1,x2,x3], model/network.py:118-122; dS = P dA'^T + X dX'^T in _diff_pool's backward).
+ * Extra pairs share op(), M, N, the batch and (ragged = 1) the row offsets of the main pair; xK[s] = their reduction length.
+ * Host arrays of length nx (<= 2).  ragged = 2 is not supported here. */
+int cgc_gemm_f32_cat(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
+                     const float* B, int ldb, float beta, float* C, int ldc, const float* bias, int batch,
+                     int64_t strideA, int64_t strideB, int64_t strideC, const int* gptr, int ragged, int max_ragged,
+                     int nx, const float* const* xA, const int* xlda, const int64_t* xstrideA,
+                     const float* const* xB, const int* xldb, const int64_t* xstrideB, const int* xK, cgc_stream_t stream);
+
 /* out[j] = beta*out[j] + sum_{s<parts} ws[s*numel + j]  (deterministic split-K combine) */
 int cgc_reduce_batch_sum(const float* ws, float* out, int parts, int64_t numel, float beta, cgc_stream_t stream);
 

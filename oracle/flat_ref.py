@@ -105,7 +105,7 @@ class TorchKernels(KernelSpec):
 
     # ------------------------------------------------------------------ dense contractions
     def gemm(self, A, B, C, M, N, K, transA, transB, lda, ldb, ldc, alpha=1.0, beta=0.0, bias=None,
-             batch=1, strideA=0, strideB=0, strideC=0, gptr=None, ragged=0, max_ragged=0, ragged_total=0):
+             batch=1, strideA=0, strideB=0, strideC=0, gptr=None, ragged=0, max_ragged=0, ragged_total=0, extra=()):
         if ragged == 1:
             assert not transA
         if ragged == 2:
@@ -127,7 +127,14 @@ class TorchKernels(KernelSpec):
             a = _mat(A, k, m, lda, oa).t() if transA else _mat(A, m, k, lda, oa)
             bm = _mat(B, N, k, ldb, ob).t() if transB else _mat(B, k, N, ldb, ob)
             c = _mat(C, m, N, ldc, oc)
-            r = alpha * (a @ bm)
+            prod = a @ bm
+            for (Ax, Bx, ldax, ldbx, Kx, sAx, sBx) in extra:       # concatenated-K product, segment by segment
+                assert ragged != 2
+                oax = b * sAx + (g[b] * ldax if ragged == 1 else 0)
+                ax = _mat(Ax, Kx, m, ldax, oax).t() if transA else _mat(Ax, m, Kx, ldax, oax)
+                bx = _mat(Bx, N, Kx, ldbx, b * sBx).t() if transB else _mat(Bx, Kx, N, ldbx, b * sBx)
+                prod = prod + ax @ bx
+            r = alpha * prod
             if beta != 0.0:
                 r = r + beta * c
             if bias is not None:

@@ -206,6 +206,36 @@ def test_gemm_ragged(C, D):
     close(got, want, 2e-5, 'ragged-M NT')
 
 
+def test_gemm_extra_k_segments():
+    """concatenated-K products without the concatenation: flat NT (Linear over cat) and ragged-M NT (dS += X dX'^T)."""
+    n, fo = 333, 150
+    x3, x12, W = rnd(n, 1140 // 10 * 4, seed=1), rnd(n, 40, seed=2), rnd(fo, 40 + 456, seed=3)
+    bias = rnd(fo, seed=4)
+    want = torch.cat([x12, x3], 1) @ W.t() + bias
+    got = torch.empty(n, fo, device=DEV)
+    gW = g(W)
+    hip().gemm(g(x3), gW[:, 40:], got, n, fo, 456, False, True, 456, 496, fo, 1.0, 0.0, g(bias),
+               extra=[(g(x12), gW, 40, 496, 40, 0, 0)])
+    close(got, want, 2e-5, 'linear over cat')
+    ref = torch.empty(n, fo)
+    REF.gemm(x3, W[:, 40:], ref, n, fo, 456, False, True, 456, 496, fo, 1.0, 0.0, bias, extra=[(x12, W, 40, 496, 40, 0, 0)])
+    close(ref, want, 2e-5, 'torch twin of the same call')
+    counts = [37, 0, 130, 64, 201]
+    nn_, C, D = sum(counts), 180, 60
+    gptr = torch.tensor(np.cumsum([0] + counts), dtype=torch.int32)
+    P, X, dA, dX, Z0 = rnd(nn_, C, seed=5), rnd(nn_, D, seed=6), rnd(5, C, C, seed=7), rnd(5, C, D, seed=8), rnd(nn_, C, seed=9)
+    want, got = Z0.clone(), g(Z0.clone())
+    args = (0, C, C, False, True, C, C, C, 1.0, 1.0, None, 5, 0, C * C, 0)
+    REF.gemm(P, dA, want, *args, gptr, 1, max(counts), nn_, extra=[(X, dX, D, D, D, 0, C * D)])
+    hip().gemm(g(P), g(dA), got, *args, g(gptr), 1, max(counts), nn_, extra=[(g(X), g(dX), D, D, D, 0, C * D)])
+    close(got, want, 2e-5, 'ragged-M with an extra segment')
+    manual = Z0.clone()
+    for b in range(5):
+        lo, hi = int(gptr[b]), int(gptr[b + 1])
+        manual[lo:hi] += P[lo:hi] @ dA[b].t() + X[lo:hi] @ dX[b].t()
+    close(want, manual, 2e-5, 'twin vs explicit formula')
+
+
 def test_gemm_strided_batch_and_splitk_reduce():
     A, B = rnd(5, 70, 90, seed=1), rnd(5, 90, 40, seed=2)
     want, got = torch.zeros(5, 70, 40), torch.zeros(5, 70, 40, device=DEV)
