@@ -11,8 +11,9 @@ each, cluster counts fixed by the reference's ``setting.max_num_nodes`` = 11404 
 (setting.py:15, train.py:254).  ``--maxn 1800`` gives the "clusters proportional to the graph" variant (C1 = 180).
 
 Extra objects on the line:
-  roofline            dominant kernel = the 128x128 fp32-MFMA GEMM (bound "mfma", peak 157.3 TFLOP/s): algorithmic
-                      flops of each launch / HIP-event duration of that launch, measured inside the timed region
+  roofline            dominant kernel = the 128x128 pipelined fp32-MFMA GEMM k_gemm_f32<2,2,2,2,*> (bound "mfma", peak
+                      157.3 TFLOP/s): algorithmic flops 2MNK of every launch of it / HIP-event duration of that launch,
+                      measured inside the timed region (rocprofv3 --stats: average over its three instantiations)
   roofline_aggregation  the wide neighbour-aggregation SpMM A*S ("K4", bound "hbm", peak 8000 GB/s): algorithmic
                       bytes 4(n+1) + 4 nnz (+4 nnz weighted) + 8 n W per launch / HIP-event duration
   cpu_baseline        the dense CPU oracle (the reference's algorithm incl. densification; oracle/dense_ref.py)
@@ -200,7 +201,7 @@ def main():
             if 'gemm_128x128' in s:
                 g = s['gemm_128x128']
                 tf = g['rate'] / 1e12
-                out['roofline'] = {'kernel': 'k_gemm_f32<2,2,2,2> (fp32 MFMA 32x32x2, 128x128x32 tile)', 'bound': 'mfma',
+                out['roofline'] = {'kernel': 'k_gemm_f32<2,2,2,2,*> (fp32 MFMA 32x32x2, 128x128x32 tile; all launches of its NN/NT/TN instantiations)', 'bound': 'mfma',
                                    'achieved': round(tf, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                                    'frac': round(tf / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': None,
                                    'launches_per_step': g['launches'] / args.steps, 'avg_launch_ms': round(g['avg_ms'], 4),

@@ -268,14 +268,18 @@ class HipKernels(KernelSpec):
              batch=1, strideA=0, strideB=0, strideC=0, gptr=None, ragged=0, max_ragged=0, ragged_total=0, extra=()):
         self._dev(A, B, C, bias, gptr)
         t0 = None
-        if self.timer is not None and N > 64 and (max_ragged if ragged == 1 else M) > 64:
-            # algorithmic flops of this launch: 2*M*N*K summed over the batch (ragged extents sum to the row count)
-            kk = K + sum(e[4] for e in extra)
-            if ragged:
-                flops = 2.0 * (M if ragged == 2 else kk) * N * ragged_total
-            else:
-                flops = 2.0 * M * N * kk * batch
-            if flops >= 1e9:
+        if self.timer is not None:
+            # time exactly the launches that gemm_dispatch() (csrc/gemm.hip) sends to the 128x128 pipelined kernel
+            # k_gemm_f32<2,2,2,2,*>: N > 64, more than 64 rows, enough tiles to fill the chip, reduction longer than 96
+            m_ext = max_ragged if ragged == 1 else M
+            k_ext = max_ragged if ragged == 2 else K
+            fill = -(-m_ext // 128) * batch
+            if N > 64 and m_ext > 64 and fill * (-(-N // 128)) >= 448 and (k_ext > 96 or extra):
+                kk = K + sum(e[4] for e in extra)
+                if ragged:   # ragged extents sum to ragged_total rows
+                    flops = 2.0 * (M if ragged == 2 else kk) * N * ragged_total
+                else:
+                    flops = 2.0 * M * N * kk * batch
                 t0 = self.timer.begin()
         if extra:
             nx = len(extra)
