@@ -16,6 +16,8 @@
 //   per 8 k.  Both fetches hand lane l the k values 8*kb + 4*(l>>5) + {0,1,2,3}; MFMA t of the group consumes element t,
 //   i.e. the k-pair {8kb+t, 8kb+4+t} -- a permutation of the k order that A and B share, so the product is unchanged;
 //   global->register prefetch of tile t+1 overlaps the 64 MFMA/wave (128x128) on tile t; 2 LDS buffers, 1 barrier/k-tile.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.hpp"
@@ -506,16 +508,18 @@ static int gemm_dispatch(GemmArgs& a, int transA, int transB, int batch, int max
   // tile shape by output aspect: the hot contractions are (>=1140) x (>=1140); the skinny ones are K- or output-bound.
   // `fill` = workgroups a 128-row tiling would launch; below ~448 (256 CUs x 2 resident) the tile is halved in M.
   const int k_extent = ragged == 2 ? max_ragged : K;
-  const bool sk = k_extent <= 96 && a.nx == 0;
+  static const int shortk_max = getenv("CGC_GEMM_SHORTK") ? atoi(getenv("CGC_GEMM_SHORTK")) : 160;
+  static const int fill_min = getenv("CGC_GEMM_FILL") ? atoi(getenv("CGC_GEMM_FILL")) : 448;
+  const bool sk = k_extent <= shortk_max && a.nx == 0;
   const long long fill = (long long)ceil_div(m_extent, 128) * batch;
   if (N <= 32) return launch_cfg<4, 1, 1, 1>(a, transA, transB, batch, m_extent, sk, stream);          // 128 x 32
   if (N <= 64) {
-    if (m_extent > 64 && fill < 448) return launch_cfg<2, 2, 1, 1>(a, transA, transB, batch, m_extent, sk, stream);   // 64 x 64
+    if (m_extent > 64 && fill < fill_min) return launch_cfg<2, 2, 1, 1>(a, transA, transB, batch, m_extent, sk, stream);   // 64 x 64
     return launch_cfg<4, 1, 1, 2>(a, transA, transB, batch, m_extent, sk, stream);                                     // 128 x 64
   }
   if (m_extent <= 32) return launch_cfg<1, 4, 1, 1>(a, transA, transB, batch, m_extent, sk, stream);   // 32 x 128
   if (m_extent <= 64) return launch_cfg<1, 4, 2, 1>(a, transA, transB, batch, m_extent, sk, stream);   // 64 x 128
-  if (fill * ceil_div(N, 128) < 448) {   // measured on [32 x 1140 x 1140] x [1140 x 114]: NN/NT prefer 64x128, TN prefers 128x64
+  if (fill * ceil_div(N, 128) < fill_min) {   // measured on [32 x 1140 x 1140] x [1140 x 114]: NN/NT prefer 64x128, TN prefers 128x64
     if (transA) return launch_cfg<4, 1, 1, 2>(a, transA, transB, batch, m_extent, sk, stream);
     return launch_cfg<1, 4, 2, 1>(a, transA, transB, batch, m_extent, sk, stream);
   }
@@ -569,8 +573,50 @@ __global__ void k_reduce_batch_sum(const float* __restrict__ ws, float* __restri
   }
 }
 
+// many slices of a small tensor (the weight gradients of the narrow layers: 50-110 slices of <= 64 x 64): 8 slice groups x
+// 32 elements per workgroup, 8 loads in flight per thread, fixed summation order
+__global__ __launch_bounds__(256) void k_reduce_many_parts(const float* __restrict__ ws, float* __restrict__ out, int parts, int numel,
+                                                           float beta) {
+  __shared__ float part[8][32];
+  const int cl = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  ws += (size_t)blockIdx.y * parts * numel;     // blockIdx.y = outer batch: ws is [outer][parts][numel], out is [outer][numel]
+  out += (size_t)blockIdx.y * numel;
+  float s = 0.f;
+  if (c < numel) {
+    float a[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] = 0.f;
+    int k = grp;
+    for (; k + 56 < parts; k += 64) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] += ws[(size_t)(k + 8 * u) * numel + c];
+    }
+    for (; k < parts; k += 8) a[0] += ws[(size_t)k * numel + c];
+    s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  }
+  part[grp][cl] = s;
+  __syncthreads();
+  if (grp == 0 && c < numel) {
+    float t = part[0][cl];
+#pragma unroll
+    for (int g = 1; g < 8; ++g) t += part[g][cl];
+    out[c] = beta != 0.f ? t + beta * out[c] : t;
+  }
+}
+
+extern "C" int cgc_reduce_batched(const float* ws, float* out, int outer, int parts, int numel, float beta, cgc_stream_t stream) {
+  if (numel <= 0 || outer <= 0) return 0;
+  if (outer > 65535) return CGC_EINVAL;
+  hipLaunchKernelGGL(k_reduce_many_parts, dim3((unsigned)ceil_div(numel, 32), (unsigned)outer), dim3(256), 0, as_stream(stream), ws, out,
+                     parts, numel, beta);
+  CGC_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}
+
 extern "C" int cgc_reduce_batch_sum(const float* ws, float* out, int parts, int64_t numel, float beta, cgc_stream_t stream) {
   if (numel <= 0) return 0;
+  if (parts >= 16 && numel <= (1 << 20)) return cgc_reduce_batched(ws, out, 1, parts, (int)numel, beta, stream);
   const int64_t blocks = ceil_div64(numel, 256);
   hipLaunchKernelGGL(k_reduce_batch_sum, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, as_stream(stream), ws, out,
                      parts, (long long)numel, beta);

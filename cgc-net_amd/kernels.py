@@ -69,6 +69,10 @@ class KernelSpec(object):
         """out[j] = beta*out[j] + sum_s ws[s*numel + j]  (deterministic split-K combine)."""
         raise NotImplementedError
 
+    def reduce_batched(self, ws, out, outer, parts, numel, beta=0.0):
+        """out[o, j] = beta*out[o, j] + sum_s ws[o, s, j]  for ws [outer, parts, numel]."""
+        raise NotImplementedError
+
     # ------------------------------------------------------------------ conv epilogue: L2 norm, activation, BatchNorm (A4, A5)
     def l2norm_act_stats(self, h, n, F, normalize, act, hn_out, rinv_out, stats_out):
         """hn = h / max(||h||_2, 1e-12) row-wise (or hn = h), rinv = that reciprocal;
@@ -306,6 +310,11 @@ class HipKernels(KernelSpec):
         self._dev(ws, out)
         self._chk(self.lib.cgc_reduce_batch_sum(_ptr(ws), _ptr(out), parts, ctypes.c_int64(numel),
                                                 ctypes.c_float(beta), self._stream()), 'cgc_reduce_batch_sum')
+
+    def reduce_batched(self, ws, out, outer, parts, numel, beta=0.0):
+        self._dev(ws, out)
+        self._chk(self.lib.cgc_reduce_batched(_ptr(ws), _ptr(out), outer, parts, numel, ctypes.c_float(beta),
+                                              self._stream()), 'cgc_reduce_batched')
 
     # -- conv epilogue
     def l2norm_act_stats(self, h, n, F, normalize, act, hn_out, rinv_out, stats_out):

@@ -375,11 +375,34 @@ def diff_pool_sparse(embed, s, g):
 # ----------------------------------------------------------------------------------------------
 # strided-batched dense matmul C_b = op(A_b) op(B_b)  (levels 2-3: A~ x, S^T X, A S, S^T (A S))
 # ----------------------------------------------------------------------------------------------
+_BSPLIT_CACHE = {}
+
+
+def _bsplit_ptr(batch, Kd, parts, device):
+    """Row split points of a [batch*Kd, .] flattening: every batch's Kd rows are cut into `parts` slices."""
+    key = (batch, Kd, parts, str(device))
+    if key not in _BSPLIT_CACHE:
+        step = -(-(-(-Kd // parts)) // 32) * 32
+        ptr = [b * Kd + min(p * step, Kd) for b in range(batch) for p in range(parts)] + [batch * Kd]
+        _BSPLIT_CACHE[key] = (torch.tensor(ptr, dtype=torch.int32, device=device), step)
+    return _BSPLIT_CACHE[key]
+
+
 def _bgemm(A, B, C, tA, tB, beta=0.0):
     """A, B, C: contiguous [batch, r, c] tensors; computes C = op(A) op(B) (+ beta C)."""
     batch = C.shape[0]
     M, N = C.shape[1], C.shape[2]
     Kd = A.shape[1] if tA else A.shape[2]
+    if tA and not tB and M <= 128 and N <= 128 and Kd >= 512 and batch * 2 < 256:
+        # small outputs reduced over a long axis (S2^T P2, S2^T X at level 2): too few tiles to fill the chip -> cut every
+        # batch's reduction into slices (ragged-K over the flattened rows), combine deterministically
+        parts = max(2, min(Kd // 128, -(-384 // (batch * (2 if N > 64 else 1)))))
+        ptr, step = _bsplit_ptr(batch, Kd, parts, A.device)
+        ws = torch.empty(batch * parts, M * N, dtype=torch.float32, device=A.device)
+        K().gemm(A, B, ws, M, N, 0, True, False, A.shape[2], B.shape[2], N, 1.0, 0.0, None, batch * parts, 0, 0, M * N,
+                 ptr, 2, step, batch * Kd)
+        K().reduce_batched(ws, C, batch, parts, M * N, beta)
+        return
     K().gemm(A, B, C, M, N, Kd, tA, tB, A.shape[2], B.shape[2], N, 1.0, beta, None, batch,
              A.shape[1] * A.shape[2], B.shape[1] * B.shape[2], M * N)
 

@@ -86,6 +86,8 @@ int cgc_gemm_f32_cat(int transA, int transB, int M, int N, int K, float alpha, c
 
 /* out[j] = beta*out[j] + sum_{s<parts} ws[s*numel + j]  (deterministic split-K combine) */
 int cgc_reduce_batch_sum(const float* ws, float* out, int parts, int64_t numel, float beta, cgc_stream_t stream);
+/* batched form: ws [outer][parts][numel] -> out [outer][numel] (split-K of a strided batch of small products) */
+int cgc_reduce_batched(const float* ws, float* out, int outer, int parts, int numel, float beta, cgc_stream_t stream);
 
 /* ---- A4/A5: conv epilogue.  Replaces F.normalize + activation + nn.BatchNorm1d over the padded [B*Nmax, C]
  * view (model/network.py:101-107,114-116).

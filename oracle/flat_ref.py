@@ -146,6 +146,11 @@ class TorchKernels(KernelSpec):
         o = out.view(-1)
         o.copy_(s + beta * o if beta != 0.0 else s)
 
+    def reduce_batched(self, ws, out, outer, parts, numel, beta=0.0):
+        s = ws.reshape(-1)[:outer * parts * numel].view(outer, parts, numel).sum(1)
+        o = out.view(outer, numel)
+        o.copy_(s + beta * o if beta != 0.0 else s)
+
     # ------------------------------------------------------------------ conv epilogue
     def l2norm_act_stats(self, h, n, F_, normalize, act, hn_out, rinv_out, stats_out):
         if normalize:

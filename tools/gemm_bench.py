@@ -80,6 +80,16 @@ if __name__ == '__main__':
     ragged(1140, 1140, counts, 'M_NT', 'dS = P dA2^T')
     ragged(1140, 60, counts, 'M_NN', 'dX = S dX2')
     # level 2, strided batch of 32
+    import itertools
+    for (Mm, Nn, Kk, tA, tB) in [(1140, 1140, 114, False, True), (1140, 1140, 140, False, True), (1140, 114, 1140, False, False), (1140, 114, 1140, True, False), (114, 114, 1140, True, False), (1140, 20, 1140, True, False), (1140, 60, 1140, True, False)]:
+        Am = torch.randn(32, *((Kk, Mm) if tA else (Mm, Kk)), device=dev)
+        Bm = torch.randn(32, *((Nn, Kk) if tB else (Kk, Nn)), device=dev)
+        Cm = torch.empty(32, Mm, Nn, device=dev)
+        ms = timeit(lambda: K.gemm(Am, Bm, Cm, Mm, Nn, Kk, tA, tB, Am.shape[2], Bm.shape[2], Nn, 1.0, 0.0, None, 32, Am.shape[1] * Am.shape[2], Bm.shape[1] * Bm.shape[2], Mm * Nn))
+        a_, b_ = (Am.transpose(1, 2) if tA else Am), (Bm.transpose(1, 2) if tB else Bm)
+        ms_t = timeit(lambda: torch.bmm(a_, b_, out=Cm))
+        fl = 2.0 * 32 * Mm * Nn * Kk
+        print('level-2 %s%s M=%4d N=%4d K=%4d b=32          ours %8.1f us %6.1f TF | torch.bmm %8.1f us %6.1f TF' % ('T' if tA else 'N', 'T' if tB else 'N', Mm, Nn, Kk, ms * 1e3, fl / ms / 1e9, ms_t * 1e3, fl / ms_t / 1e9))
     A = torch.randn(32, 1140, 1140, device=dev)
     for F in (60, 20, 114):
         X = torch.randn(32, 1140, F, device=dev)
