@@ -19,10 +19,10 @@ PROTOTYPES = {
     'cgc_bn_finalize': [P, I, D, F, F, P, P, P, P, P],
     'cgc_bn_act_apply': [P, I, I, I, P, P, P, P, P, I, P],
     'cgc_bn_bwd_reduce': [P, I, P, I, I, I, P, P, P, P, P],
-    'cgc_bn_act_l2_bwd': [P, I, P, P, I, I, I, I, I, P, P, P, P, D, P, P],
+    'cgc_bn_act_l2_bwd': [P, I, P, P, I, I, I, I, I, P, P, P, P, D, P, P, P, P],
     'cgc_colsum': [P, I, I, I, P, P, P],
     'cgc_softmax_fwd': [P, I, I, P, P],
-    'cgc_softmax_bwd': [P, P, I, I, P, P],
+    'cgc_softmax_bwd': [P, P, I, I, P, P, P, P],
     'cgc_segment_max_fwd': [P, P, I, I, I, P, P, P],
     'cgc_segment_max_bwd': [P, P, I, I, P, P],
     'cgc_dense_rownorm_fwd': [P, I, I, P, P, P, P],

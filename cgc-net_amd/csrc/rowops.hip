@@ -365,8 +365,15 @@ __global__ __launch_bounds__(256) void k_bn_act_l2_bwd(const float* __restrict__
                                                        const float* __restrict__ rinv, int n, int F, int lpr, int act,
                                                        int normalize, int mode, const float* __restrict__ mean,
                                                        const float* __restrict__ istd, const float* __restrict__ gamma,
-                                                       const float* __restrict__ sums, float inv_count, float* __restrict__ dh) {
+                                                       const float* __restrict__ sums, float inv_count, float* __restrict__ dh,
+                                                       float* __restrict__ ws /* per-block column sums of dh, or null */) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
   const RowGroup rg(lpr);
+  float csum[1][MAXJ][VEC];
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j)
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) csum[0][j][v] = 0.f;
   // per-lane column constants: do = ca*dy - cb - xhat*cc  with  ca = gamma*istd, cb = ca*s0/count, cc = ca*s1/count
   float ca[MAXJ][VEC], cb[MAXJ][VEC], cc[MAXJ][VEC], mu[MAXJ][VEC], is[MAXJ][VEC];
 #pragma unroll
@@ -423,25 +430,37 @@ __global__ __launch_bounds__(256) void k_bn_act_l2_bwd(const float* __restrict__
         for (int v = 0; v < VEC; ++v) {
           const float gv = g[j].v[v];
           o.v[v] = !normalize ? gv : (clamped ? gv * (1.f / L2_EPS) : r * (gv - x[j].v[v] * dot));
+          csum[0][j][v] += o.v[v];
         }
         o.store(dh + (size_t)row * F + c);
       }
     }
   }
+  if (ws != nullptr) col_reduce_store<VEC, MAXJ, 1>(csum, F, lpr, smem, ws + (size_t)blockIdx.x * F);
 }
 
 extern "C" int cgc_bn_act_l2_bwd(const float* dy, int ldy, const float* hn, const float* rinv, int n, int F, int act,
                                  int normalize, int mode, const float* mean, const float* istd, const float* gamma,
-                                 const float* sums, double count, float* dh, cgc_stream_t stream) {
-  if (n <= 0 || F <= 0) return 0;
+                                 const float* sums, double count, float* dh, float* dh_colsum, float* ws, cgc_stream_t stream) {
+  if (F <= 0) return 0;
+  if (n <= 0) {
+    if (dh_colsum) (void)hipMemsetAsync(dh_colsum, 0, sizeof(float) * F, as_stream(stream));
+    return 0;
+  }
+  if (dh_colsum != nullptr && ws == nullptr) return CGC_EINVAL;
   const bool vec = (F % 4 == 0) && (ldy % 4 == 0) && aligned16(dy) && aligned16(hn) && aligned16(dh);
   ColCfg cfg = col_cfg(n, F, vec);
   if (!cfg.ok) return CGC_EINVAL;
-  cfg.blocks = row_blocks(n, cfg.lpr);
+  if (dh_colsum == nullptr) cfg.blocks = row_blocks(n, cfg.lpr);   // no reduction slots needed: use the full grid
   const float inv_count = (float)(1.0 / count);
-  DISPATCH_COL(k_bn_act_l2_bwd, cfg, 0, as_stream(stream), dy, ldy, hn, rinv, n, F, cfg.lpr, act, normalize, mode, mean, istd,
-               gamma, sums, inv_count, dh);
+  const size_t smem = dh_colsum ? sizeof(float) * 3 * F : 0;
+  DISPATCH_COL(k_bn_act_l2_bwd, cfg, smem, as_stream(stream), dy, ldy, hn, rinv, n, F, cfg.lpr, act, normalize, mode, mean, istd,
+               gamma, sums, inv_count, dh, dh_colsum ? ws : (float*)nullptr);
   CGC_RETURN_IF_LAUNCH_FAILED();
+  if (dh_colsum) {
+    hipLaunchKernelGGL(k_reduce_slots<float>, REDUCE_SLOTS_GRID(F), dim3(256), 0, as_stream(stream), ws, cfg.blocks, F, dh_colsum);
+    CGC_RETURN_IF_LAUNCH_FAILED();
+  }
   return 0;
 }
 
@@ -532,33 +551,50 @@ __global__ __launch_bounds__(256) void k_softmax_fwd(const float* __restrict__ x
   }
 }
 
-template <int VEC>
+template <int VEC, int MAXJ>
 __global__ __launch_bounds__(256) void k_softmax_bwd(const float* __restrict__ S, const float* __restrict__ dS, int n, int C,
-                                                     int lpr, float* __restrict__ dx) {
+                                                     int lpr, float* __restrict__ dx, float* __restrict__ ws) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
   const RowGroup rg(lpr);
+  float csum[1][MAXJ][VEC];
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j)
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) csum[0][j][v] = 0.f;
   for (int base = rg.gwave * rg.rpw; base < n; base += rg.nwaves * rg.rpw) {
     const int row = base + rg.sub;
     const bool valid = row < n;
+    Vec<VEC> s[MAXJ], d[MAXJ];
     float dot = 0.f;
-    if (valid)
-      for (int c = rg.sl * VEC; c < C; c += lpr * VEC) {
-        Vec<VEC> s, d;
-        s.load(S + (size_t)row * C + c);
-        d.load(dS + (size_t)row * C + c);
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) dot += s.v[v] * d.v[v];
+    for (int j = 0; j < MAXJ; ++j) {
+      const int c = (rg.sl + lpr * j) * VEC;
+      if (valid && c < C) {
+        s[j].load(S + (size_t)row * C + c);
+        d[j].load(dS + (size_t)row * C + c);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) dot += s[j].v[v] * d[j].v[v];
+      } else {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) s[j].v[v] = d[j].v[v] = 0.f;
       }
+    }
     dot = group_sum(dot, lpr);
     if (!valid) continue;
-    for (int c = rg.sl * VEC; c < C; c += lpr * VEC) {
-      Vec<VEC> s, d;
-      s.load(S + (size_t)row * C + c);
-      d.load(dS + (size_t)row * C + c);
 #pragma unroll
-      for (int v = 0; v < VEC; ++v) d.v[v] = s.v[v] * (d.v[v] - dot);
-      d.store(dx + (size_t)row * C + c);
+    for (int j = 0; j < MAXJ; ++j) {
+      const int c = (rg.sl + lpr * j) * VEC;
+      if (c < C) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          d[j].v[v] = s[j].v[v] * (d[j].v[v] - dot);
+          csum[0][j][v] += d[j].v[v];
+        }
+        d[j].store(dx + (size_t)row * C + c);
+      }
     }
   }
+  if (ws != nullptr) col_reduce_store<VEC, MAXJ, 1>(csum, C, lpr, smem, ws + (size_t)blockIdx.x * C);
 }
 
 extern "C" int cgc_softmax_fwd(const float* x, int n, int C, float* out, cgc_stream_t stream) {
@@ -574,16 +610,25 @@ extern "C" int cgc_softmax_fwd(const float* x, int n, int C, float* out, cgc_str
   return 0;
 }
 
-extern "C" int cgc_softmax_bwd(const float* S, const float* dS, int n, int C, float* dx, cgc_stream_t stream) {
-  if (n <= 0 || C <= 0) return 0;
+extern "C" int cgc_softmax_bwd(const float* S, const float* dS, int n, int C, float* dx, float* dx_colsum, float* ws,
+                               cgc_stream_t stream) {
+  if (C <= 0) return 0;
+  if (n <= 0) {
+    if (dx_colsum) (void)hipMemsetAsync(dx_colsum, 0, sizeof(float) * C, as_stream(stream));
+    return 0;
+  }
+  if (dx_colsum != nullptr && ws == nullptr) return CGC_EINVAL;
   const bool vec = (C % 4 == 0) && aligned16(S) && aligned16(dS) && aligned16(dx);
-  const int lpr = pick_lpr(vec ? C / 4 : C);
-  dim3 grid(row_blocks(n, lpr)), block(CGC_BLOCK);
-  if (vec)
-    hipLaunchKernelGGL(k_softmax_bwd<4>, grid, block, 0, as_stream(stream), S, dS, n, C, lpr, dx);
-  else
-    hipLaunchKernelGGL(k_softmax_bwd<1>, grid, block, 0, as_stream(stream), S, dS, n, C, lpr, dx);
+  ColCfg cfg = col_cfg(n, C, vec);
+  if (!cfg.ok) return CGC_EINVAL;
+  if (dx_colsum == nullptr) cfg.blocks = row_blocks(n, cfg.lpr);
+  const size_t smem = dx_colsum ? sizeof(float) * 3 * C : 0;
+  DISPATCH_COL(k_softmax_bwd, cfg, smem, as_stream(stream), S, dS, n, C, cfg.lpr, dx, dx_colsum ? ws : (float*)nullptr);
   CGC_RETURN_IF_LAUNCH_FAILED();
+  if (dx_colsum) {
+    hipLaunchKernelGGL(k_reduce_slots<float>, REDUCE_SLOTS_GRID(C), dim3(256), 0, as_stream(stream), ws, cfg.blocks, C, dx_colsum);
+    CGC_RETURN_IF_LAUNCH_FAILED();
+  }
   return 0;
 }
 

@@ -94,8 +94,9 @@ class KernelSpec(object):
         """sums[0,f] = sum_i dy, sums[1,f] = sum_i dy * xhat, xhat = (act(hn)-mean)*istd."""
         raise NotImplementedError
 
-    def bn_act_l2_bwd(self, dy, ldy, hn, rinv, n, F, act, normalize, mode, mean, istd, gamma, sums, count, dh_out):
-        """Backward of BN o act o l2norm for one row block.
+    def bn_act_l2_bwd(self, dy, ldy, hn, rinv, n, F, act, normalize, mode, mean, istd, gamma, sums, count, dh_out,
+                      dh_colsum_out=None):
+        """Backward of BN o act o l2norm for one row block (dh_colsum_out[f] = sum_i dh[i,f], optional).
         mode 2 (batch stats): do = gamma*istd*(dy - s0/count - xhat*s1/count); mode 1 (running stats):
         do = gamma*istd*dy; mode 0 (no BN): do = dy.   dhn = do*act'(hn);
         normalize: dh = rinv*(dhn - hn*<hn,dhn>) (dh = dhn*1e12 where the norm clamp was active)."""
@@ -109,8 +110,8 @@ class KernelSpec(object):
     def softmax_fwd(self, x, n, C, out):
         raise NotImplementedError
 
-    def softmax_bwd(self, S, dS, n, C, dx_out):
-        """dx = S * (dS - <dS, S>_row)."""
+    def softmax_bwd(self, S, dS, n, C, dx_out, dx_colsum_out=None):
+        """dx = S * (dS - <dS, S>_row);  dx_colsum_out[c] = sum_i dx[i,c] (optional)."""
         raise NotImplementedError
 
     def segment_max_fwd(self, x, gptr, B, D, nmax, out, arg_out):
@@ -343,11 +344,17 @@ class HipKernels(KernelSpec):
         self._chk(self.lib.cgc_bn_bwd_reduce(_ptr(dy), ldy, _ptr(hn), n, F, act, _ptr(mean), _ptr(istd),
                                              _ptr(sums_out), _ptr(ws), self._stream()), 'cgc_bn_bwd_reduce')
 
-    def bn_act_l2_bwd(self, dy, ldy, hn, rinv, n, F, act, normalize, mode, mean, istd, gamma, sums, count, dh_out):
-        self._dev(dy, hn, rinv, mean, istd, gamma, sums, dh_out)
+    def _slots(self, n, F, dev):
+        return torch.empty(max(self.lib.cgc_stats_blocks(n, F), 1) * 2 * F, dtype=torch.float32, device=dev)
+
+    def bn_act_l2_bwd(self, dy, ldy, hn, rinv, n, F, act, normalize, mode, mean, istd, gamma, sums, count, dh_out,
+                      dh_colsum_out=None):
+        self._dev(dy, hn, rinv, mean, istd, gamma, sums, dh_out, dh_colsum_out)
+        ws = self._slots(n, F, hn.device) if dh_colsum_out is not None else None
         self._chk(self.lib.cgc_bn_act_l2_bwd(_ptr(dy), ldy, _ptr(hn), _ptr(rinv), n, F, act, int(normalize), mode,
                                              _ptr(mean), _ptr(istd), _ptr(gamma), _ptr(sums),
-                                             ctypes.c_double(count), _ptr(dh_out), self._stream()), 'cgc_bn_act_l2_bwd')
+                                             ctypes.c_double(count), _ptr(dh_out), _ptr(dh_colsum_out), _ptr(ws),
+                                             self._stream()), 'cgc_bn_act_l2_bwd')
 
     def colsum(self, x, ld, n, F, out):
         self._dev(x, out)
@@ -360,9 +367,11 @@ class HipKernels(KernelSpec):
         self._dev(x, out)
         self._chk(self.lib.cgc_softmax_fwd(_ptr(x), n, C, _ptr(out), self._stream()), 'cgc_softmax_fwd')
 
-    def softmax_bwd(self, S, dS, n, C, dx_out):
-        self._dev(S, dS, dx_out)
-        self._chk(self.lib.cgc_softmax_bwd(_ptr(S), _ptr(dS), n, C, _ptr(dx_out), self._stream()), 'cgc_softmax_bwd')
+    def softmax_bwd(self, S, dS, n, C, dx_out, dx_colsum_out=None):
+        self._dev(S, dS, dx_out, dx_colsum_out)
+        ws = self._slots(n, C, S.device) if dx_colsum_out is not None else None
+        self._chk(self.lib.cgc_softmax_bwd(_ptr(S), _ptr(dS), n, C, _ptr(dx_out), _ptr(dx_colsum_out), _ptr(ws),
+                                           self._stream()), 'cgc_softmax_bwd')
 
     def segment_max_fwd(self, x, gptr, B, D, nmax, out, arg_out):
         self._dev(x, gptr, out, arg_out)

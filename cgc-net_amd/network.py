@@ -183,12 +183,17 @@ class GNN_Module(nn.Module):
 
     # -- core: rows are nodes; `aggregate` maps [rows, F] -> [rows, F]; `count` = rows the BatchNorm of the
     #    dense layout would see (B*Nmax); `row_mask` only for the dense API with padded rows.
-    def run_rows(self, x, aggregate, count, agg0=None, row_mask=None):
+    def run_rows(self, x, aggregate, count, agg0=None, row_mask=None, softmax=False):
+        """``softmax=True`` (pool blocks): return softmax(lin(cat)) -- the assignment matrix -- instead of the logits."""
         outs, h = [], x
         for k in (1, 2, 3):
             conv = getattr(self, 'gcn%d' % k)
             bn = getattr(self, 'bn%d' % k) if self.use_bn else None
             agg = agg0 if (k == 1 and agg0 is not None) else aggregate(h)
+            if self.mean_aggregation and row_mask is None:
+                h = ops.sage_project(agg, conv.weight, conv.bias, bn, count, self.activation, conv.normalize, self.training)
+                outs.append(h)
+                continue
             if self.mean_aggregation:
                 z, normalize = conv.project(agg), conv.normalize
             else:
@@ -205,18 +210,18 @@ class GNN_Module(nn.Module):
         if self.lin is not None and row_mask is None:
             # Linear over cat[x1,x2,x3] without the concatenation: the two narrow pieces are joined (cheap), the wide one
             # ([rows, cluster count]) is the main operand of the same GEMM
-            return ops.linear_cat([torch.cat(outs[:2], dim=-1), outs[2]], self.lin.weight, self.lin.bias)
+            return ops.linear_cat([torch.cat(outs[:2], dim=-1), outs[2]], self.lin.weight, self.lin.bias, softmax)
         h = torch.cat(outs, dim=-1)
         if row_mask is not None:
             h = h * row_mask
         if self.lin is not None:
             h = ops.linear_bias(h, self.lin.weight, self.lin.bias, out_in_layout=True) * row_mask
-        return h
+        return ops.softmax_rows(h) if softmax else h
 
-    def forward_graph(self, x, g, agg0=None):
+    def forward_graph(self, x, g, agg0=None, softmax=False):
         """Level-1 path on flat rows + CSR (``g``: graph.BatchGraph).  Returns [Ntot, width]."""
         mean = self.mean_aggregation
-        return self.run_rows(x, lambda h: ops.aggregate(h, g, mean), g.padded_rows, agg0)
+        return self.run_rows(x, lambda h: ops.aggregate(h, g, mean), g.padded_rows, agg0, None, softmax)
 
     def forward(self, x, adj, mask=None):
         """Dense-tensor contract of the reference: x [B,N,F], adj [B,N,N], mask [B,N,1] or None."""
@@ -309,7 +314,7 @@ class SoftPoolingGcnEncoder(nn.Module):
         if self.jk:
             embed = self.jk1(embed)
         readout = ops.segment_max(embed, g.gptr, g.B, g.nmax)
-        s = ops.softmax_rows(pool_blk.forward_graph(x, g, agg0))
+        s = pool_blk.forward_graph(x, g, agg0, softmax=True)
         if self.collect_assign:
             self.assign_matrix.append(self._pad_assign(s.detach(), g))
         xn, an = ops.diff_pool_sparse(embed, s, g)
@@ -341,7 +346,7 @@ class SoftPoolingGcnEncoder(nn.Module):
         readout = ops.segment_max(embed, uniform_ptr(B, C, x.device), B, C)
         if level == 3:
             return readout, None, None
-        s = ops.softmax_rows(getattr(self, 'GCN_pool_%d' % level).run_rows(xf, aggregate, B * C, agg0))
+        s = getattr(self, 'GCN_pool_%d' % level).run_rows(xf, aggregate, B * C, agg0, None, True)
         if self.collect_assign:
             self.assign_matrix.append(s.detach().view(B, C, -1))
         xn, an = ops.diff_pool_dense(embed.view(B, C, -1), adj, s.view(B, C, -1))

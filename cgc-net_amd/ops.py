@@ -160,7 +160,7 @@ class _LinearCat(Function):
     the widest x_k is the main operand of one GEMM, the others ride along as extra K segments (model/network.py:118-122)."""
 
     @staticmethod
-    def forward(ctx, weight, bias, *xs):
+    def forward(ctx, weight, bias, softmax, *xs):
         xs = [_f32c(x) for x in xs]
         weight = _f32c(weight)
         n, fout, ftot = xs[0].shape[0], weight.shape[0], weight.shape[1]
@@ -175,22 +175,36 @@ class _LinearCat(Function):
         extra = [(xs[i], weight[:, offs[i]:], xs[i].shape[1], ftot, xs[i].shape[1], 0, 0) for i in order[1:]]
         K().gemm(xs[m], weight[:, offs[m]:], y, n, fout, xs[m].shape[1], False, True, xs[m].shape[1], ftot, fout,
                  1.0, 0.0, bias, extra=extra)
-        ctx.save_for_backward(weight, *xs)
-        ctx.offs, ctx.has_bias = offs, bias is not None
+        if softmax:                      # row softmax of the assignment logits, in place (model/network.py:200)
+            K().softmax_fwd(y, n, fout, y)
+            ctx.save_for_backward(weight, y, *xs)
+        else:
+            ctx.save_for_backward(weight, *xs)
+        ctx.offs, ctx.has_bias, ctx.softmax = offs, bias is not None, softmax
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        weight, xs = ctx.saved_tensors[0], ctx.saved_tensors[1:]
-        dy, ld = _rows_ld(dy)
-        n, fout, ftot = dy.shape[0], weight.shape[0], weight.shape[1]
+        weight = ctx.saved_tensors[0]
         dw = db = None
+        if ctx.softmax:
+            s_out, xs = ctx.saved_tensors[1], ctx.saved_tensors[2:]
+            ds = _f32c(dy)
+            dy = torch.empty_like(s_out)
+            if ctx.has_bias and ctx.needs_input_grad[1]:
+                db = torch.empty(s_out.shape[1], dtype=torch.float32, device=ds.device)
+            K().softmax_bwd(s_out, ds, s_out.shape[0], s_out.shape[1], dy, db)    # + column sums = bias gradient
+            ld = dy.shape[1]
+        else:
+            xs = ctx.saved_tensors[1:]
+            dy, ld = _rows_ld(dy)
+        n, fout, ftot = dy.shape[0], weight.shape[0], weight.shape[1]
         dxs = [None] * len(xs)
-        if any(ctx.needs_input_grad[2:]):
+        if any(ctx.needs_input_grad[3:]):
             dcat = torch.empty(n, ftot, dtype=torch.float32, device=dy.device)     # d cat = dy W ; the d x_k are column slices
             K().gemm(dy, weight, dcat, n, ftot, fout, False, False, ld, ftot, ftot)
             dxs = [dcat[:, o:o + x.shape[1]] if need else None
-                   for o, x, need in zip(ctx.offs, xs, ctx.needs_input_grad[2:])]
+                   for o, x, need in zip(ctx.offs, xs, ctx.needs_input_grad[3:])]
         if ctx.needs_input_grad[0]:
             dw = torch.empty_like(weight)
             for o, x in zip(ctx.offs, xs):                                          # dW[:, slice_k] = dy^T x_k
@@ -198,15 +212,16 @@ class _LinearCat(Function):
                 tmp = torch.empty(fout, f, dtype=torch.float32, device=dy.device)
                 gemm_tn_rows(dy, ld, fout, x, f, f, n, tmp)
                 dw[:, o:o + f].copy_(tmp)
-        if ctx.has_bias and ctx.needs_input_grad[1]:
+        if ctx.has_bias and ctx.needs_input_grad[1] and db is None:
             db = torch.empty(fout, dtype=torch.float32, device=dy.device)
             K().colsum(dy, ld, n, fout, db)
-        return (dw, db) + tuple(dxs)
+        return (dw, db, None) + tuple(dxs)
 
 
-def linear_cat(xs, weight, bias=None):
-    """nn.Linear applied to torch.cat(xs, dim=1) (at most 3 pieces) without forming the concatenation."""
-    return _LinearCat.apply(weight, bias, *xs)
+def linear_cat(xs, weight, bias=None, softmax=False):
+    """nn.Linear applied to torch.cat(xs, dim=1) (at most 3 pieces) without forming the concatenation;
+    ``softmax=True`` appends the row softmax (the assignment matrix of _diff_pool) in the same autograd node."""
+    return _LinearCat.apply(weight, bias, softmax, *xs)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -271,6 +286,79 @@ def l2_act_bn(h, bn, count, act='relu', normalize=True, training=True):
         return _L2ActBN.apply(h, bn.weight, bn.bias, rm, rv, count, code, normalize, 2, bn.eps, momentum)
     return _L2ActBN.apply(h, bn.weight, bn.bias, bn.running_mean, bn.running_var, count, code, normalize, 1,
                           bn.eps, 0.0)
+
+
+class _SageProject(Function):
+    """BN(act(l2norm(agg @ W + b))): the tail of one SAGE convolution as ONE autograd node.  Forward = the launches of
+    linear_bias + l2_act_bn; backward computes d(agg W + b) with the fused BN/act/l2 kernel, which also emits its column
+    sums (= db), then dW (row-split GEMM) and d agg."""
+
+    @staticmethod
+    def forward(ctx, agg, weight, bias, gamma, beta, running_mean, running_var, count, act, normalize, bn_mode, eps, momentum):
+        agg, weight = _f32c(agg), _f32c(weight)
+        n, fin = agg.shape
+        F = weight.shape[1]
+        dev = agg.device
+        h = torch.empty(n, F, dtype=torch.float32, device=dev)
+        K().gemm(agg, weight, h, n, F, fin, False, False, fin, F, F, 1.0, 0.0, bias)
+        rinv = torch.empty(n, dtype=torch.float32, device=dev)
+        mean = istd = None
+        if bn_mode == 2:
+            stats = torch.empty(2, F, dtype=torch.float64, device=dev)
+            K().l2norm_act_stats(h, n, F, normalize, act, h, rinv, stats)          # in place: h becomes hn
+            mean = torch.empty(F, dtype=torch.float32, device=dev)
+            istd = torch.empty(F, dtype=torch.float32, device=dev)
+            K().bn_finalize(stats, float(count), eps, momentum, running_mean, running_var, mean, istd)
+        else:
+            K().l2norm_act_stats(h, n, F, normalize, act, h, rinv, None)
+            if bn_mode == 1:
+                mean, istd = running_mean, torch.rsqrt(running_var + eps)
+        y = torch.empty(n, F, dtype=torch.float32, device=dev)
+        K().bn_act_apply(h, n, F, act, mean, istd, gamma, beta, y, F)
+        ctx.save_for_backward(agg, weight, h, rinv, mean, istd, gamma)
+        ctx.cfg = (act, normalize, bn_mode, float(count), bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        agg, weight, hn, rinv, mean, istd, gamma = ctx.saved_tensors
+        act, normalize, bn_mode, count, has_bias = ctx.cfg
+        n, F = hn.shape
+        fin = agg.shape[1]
+        dy, ld = _rows_ld(dy)
+        dev = hn.device
+        sums = dgamma = dbeta = None
+        if bn_mode != 0:
+            sums = torch.empty(2, F, dtype=torch.float32, device=dev)
+            K().bn_bwd_reduce(dy, ld, hn, n, F, act, mean, istd, sums)
+            dbeta, dgamma = sums[0], sums[1]
+        dh = torch.empty_like(hn)
+        db = torch.empty(F, dtype=torch.float32, device=dev) if has_bias else None
+        K().bn_act_l2_bwd(dy, ld, hn, rinv, n, F, act, normalize, bn_mode, mean, istd, gamma, sums, count, dh, db)
+        dagg = dw = None
+        if ctx.needs_input_grad[0]:
+            dagg = torch.empty_like(agg)
+            K().gemm(dh, weight, dagg, n, fin, F, False, True, F, F, fin)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(weight)
+            gemm_tn_rows(agg, fin, fin, dh, F, F, n, dw)
+        return dagg, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None
+
+
+def sage_project(agg, weight, bias, bn, count, act='relu', normalize=True, training=True):
+    """One node for ``l2_act_bn(linear_bias(agg, weight, bias), bn, ...)`` (weight in PyG layout [in, out])."""
+    code = ACT_CODES[act]
+    if bn is None:
+        return _SageProject.apply(agg, weight, bias, None, None, None, None, count, code, normalize, 0, 0.0, 0.0)
+    use_batch = training or bn.running_mean is None
+    if use_batch and training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    momentum = bn.momentum if bn.momentum is not None else 1.0 / float(max(int(bn.num_batches_tracked), 1))
+    rm, rv = (bn.running_mean, bn.running_var) if (training and bn.track_running_stats) else (None, None)
+    if use_batch:
+        return _SageProject.apply(agg, weight, bias, bn.weight, bn.bias, rm, rv, count, code, normalize, 2, bn.eps, momentum)
+    return _SageProject.apply(agg, weight, bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, count, code,
+                              normalize, 1, bn.eps, 0.0)
 
 
 # ----------------------------------------------------------------------------------------------

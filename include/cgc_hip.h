@@ -104,12 +104,15 @@ int cgc_bn_bwd_reduce(const float* dy, int ldy, const float* hn, int n, int F, i
 /* mode: 2 batch statistics, 1 running statistics, 0 no BN */
 int cgc_bn_act_l2_bwd(const float* dy, int ldy, const float* hn, const float* rinv, int n, int F, int act,
                       int normalize, int mode, const float* mean, const float* istd, const float* gamma,
-                      const float* sums, double count, float* dh, cgc_stream_t stream);
+                      const float* sums, double count, float* dh,
+                      float* dh_colsum /*[F] or NULL: fused column sums of dh = bias gradient of the preceding linear*/,
+                      float* ws /*cgc_stats_blocks(n,F)*F floats when dh_colsum != NULL*/, cgc_stream_t stream);
 int cgc_colsum(const float* x, int ld, int n, int F, float* out, float* ws, cgc_stream_t stream);
 
 /* ---- A8: row softmax of the assignment matrix (model/network.py:200); A9: max readout (model/network.py:264) */
 int cgc_softmax_fwd(const float* x, int n, int C, float* out, cgc_stream_t stream);
-int cgc_softmax_bwd(const float* S, const float* dS, int n, int C, float* dx, cgc_stream_t stream);
+int cgc_softmax_bwd(const float* S, const float* dS, int n, int C, float* dx,
+                    float* dx_colsum /*[C] or NULL: fused column sums of dx*/, float* ws, cgc_stream_t stream);
 int cgc_segment_max_fwd(const float* x, const int* gptr, int B, int D, int nmax, float* out, int* arg, cgc_stream_t stream);
 int cgc_segment_max_bwd(const float* dout, const int* arg, int B, int D, float* dx_zeroed, cgc_stream_t stream);
 

@@ -186,7 +186,8 @@ class TorchKernels(KernelSpec):
         sums_out[0] = d.sum(0)
         sums_out[1] = (d * xhat).sum(0)
 
-    def bn_act_l2_bwd(self, dy, ldy, hn, rinv, n, F_, act, normalize, mode, mean, istd, gamma, sums, count, dh_out):
+    def bn_act_l2_bwd(self, dy, ldy, hn, rinv, n, F_, act, normalize, mode, mean, istd, gamma, sums, count, dh_out,
+                      dh_colsum_out=None):
         d = _mat(dy, n, F_, ldy)
         if mode == 2:
             xhat = (_act(hn, act) - mean) * istd
@@ -203,6 +204,8 @@ class TorchKernels(KernelSpec):
         else:
             dh = dhn
         dh_out.copy_(dh)
+        if dh_colsum_out is not None:
+            dh_colsum_out.copy_(dh.sum(0))
 
     def colsum(self, x, ld, n, F_, out):
         out.copy_(_mat(x, n, F_, ld).sum(0))
@@ -211,8 +214,10 @@ class TorchKernels(KernelSpec):
     def softmax_fwd(self, x, n, C, out):
         out.copy_(torch.softmax(x, dim=1))
 
-    def softmax_bwd(self, S, dS, n, C, dx_out):
+    def softmax_bwd(self, S, dS, n, C, dx_out, dx_colsum_out=None):
         dx_out.copy_(S * (dS - (dS * S).sum(1, keepdim=True)))
+        if dx_colsum_out is not None:
+            dx_colsum_out.copy_(dx_out.sum(0))
 
     def segment_max_fwd(self, x, gptr, B, D, nmax, out, arg_out):
         g = gptr.tolist()

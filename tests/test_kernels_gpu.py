@@ -278,13 +278,16 @@ def test_conv_epilogue_chain(n, F, act):
         sums = torch.empty(2, F, device=dev)
         K_.bn_bwd_reduce(dy, F + 8, hn, n, F, act, mean, istd, sums)
         dh = torch.empty(n, F, device=dev)
-        K_.bn_act_l2_bwd(dy, F + 8, hn, rinv, n, F, act, True, 2, mean, istd, t(gamma), sums, count, dh)
+        dhc = torch.empty(F, device=dev)                        # fused column sums of dh (bias gradient)
+        K_.bn_act_l2_bwd(dy, F + 8, hn, rinv, n, F, act, True, 2, mean, istd, t(gamma), sums, count, dh, dhc)
         dh1 = torch.empty(n, F, device=dev)
         K_.bn_act_l2_bwd(dy, F + 8, hn, rinv, n, F, act, False, 1, mean, istd, t(gamma), sums, count, dh1)
         cs = torch.empty(F, device=dev)
         K_.colsum(dy, F + 8, n, F, cs)
+        mask_ = torch.ones(n, dtype=torch.bool, device=dev)
+        mask_[min(3, n - 1)] = False                             # the clamped zero row carries a 1e12 factor: compare without it
         outs[name] = dict(hn=hn, rinv=rinv, stats=stats, rm=rm, rv=rv, mean=mean, istd=istd, y=y, sums=sums, dh=dh,
-                          dh1=dh1, cs=cs)
+                          dh1=dh1, cs=cs, dhc_consistent=(dhc - dh[~mask_].sum(0)), dh_colsum=dh[mask_].sum(0))
     torch.cuda.synchronize()
     for key in outs['ref']:
         tol = 1e-3 if key in ('dh',) and h[min(3, n - 1)].abs().sum() == 0 else TOL
@@ -325,9 +328,17 @@ def test_softmax(n, C):
     close(got, want, 1e-5, 'softmax')
     dS = rnd(n, C, seed=1)
     w2, g2 = torch.empty(n, C), torch.empty(n, C, device=DEV)
-    REF.softmax_bwd(want, dS, n, C, w2)
-    hip().softmax_bwd(g(want), g(dS), n, C, g2)
+    wc, gc = torch.empty(C), torch.empty(C, device=DEV)
+    REF.softmax_bwd(want, dS, n, C, w2, wc)
+    hip().softmax_bwd(g(want), g(dS), n, C, g2, gc)
     close(g2, w2, 1e-5, 'softmax bwd')
+    close(gc, wc, 1e-4, 'softmax bwd fused column sums')
+    g3 = torch.empty(n, C, device=DEV)
+    hip().softmax_bwd(g(want), g(dS), n, C, g3)            # without the fused sums
+    close(g3, w2, 1e-5, 'softmax bwd (no colsum)')
+    inpl = g(x.clone())
+    hip().softmax_fwd(inpl, n, C, inpl)                    # in-place forward (used by the fused Linear+softmax node)
+    close(inpl, want, 1e-5, 'softmax in place')
 
 
 @pytest.mark.parametrize('D', [8, 20, 60, 100])
