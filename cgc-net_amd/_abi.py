@@ -25,6 +25,9 @@ PROTOTYPES = {
     'cgc_softmax_bwd': [P, P, I, I, P, P, P, P],
     'cgc_segment_max_fwd': [P, P, I, I, I, P, P, P],
     'cgc_segment_max_bwd': [P, P, I, I, P, P],
+    'cgc_jk_supported': [I],
+    'cgc_jk_lstm_fwd': [P, I, I, I, P, P, P, P, P, P, P],
+    'cgc_jk_lstm_bwd': [P, P, I, I, I, P, P, P, P, P, P, P, P, P, P],
     'cgc_dense_rownorm_fwd': [P, I, I, P, P, P, P],
     'cgc_dense_rownorm_bwd': [P, P, P, P, I, I, P, P],
     'cgc_dense_renorm_fwd': [P, I, I, F, P, P],

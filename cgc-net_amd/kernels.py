@@ -124,6 +124,23 @@ class KernelSpec(object):
         """dx[arg[b,d], d] = dout[b,d] where arg >= 0 (dx arrives zero-filled)."""
         raise NotImplementedError
 
+    # ------------------------------------------------------------------ jumping-knowledge attention (A7)
+    def jk_supported(self, C):
+        """Whether the fused DenseJK kernels exist for this channel count."""
+        raise NotImplementedError
+
+    def jk_fwd(self, xs, n, npad, C, lstm, w_att, b_att, out, HS, CS):
+        """DenseJK forward (model/network.py:36-52): xs [n,3C] -> out [n,C].  ``lstm`` = 8 tensors
+        (w_ih, w_hh, b_ih, b_hh) x (forward, reverse) in torch.nn.LSTM layout, hidden H = 3C/2.
+        HS, CS [6H, npad]: hidden / cell state of (direction d, step t, unit j) at row (d*3+t)*H + j."""
+        raise NotImplementedError
+
+    def jk_bwd(self, xs, dout, n, npad, C, lstm, w_att, b_att, HS, CS, dxs, DGT, INT, DHC):
+        """DenseJK backward: dxs [n,3C]; DGT [2, 4H+1, 3*npad] and INT [2, C+2H+1, 3*npad] such that
+        G_d = DGT[d] @ INT[d]^T gives dW_ih = G_d[:4H,:C], dW_hh = G_d[:4H,C:C+H], db_ih = db_hh = G_d[:4H,C+H],
+        d w_att[dH:(d+1)H] = G_d[4H, C+H+1:], d b_att = G_0[4H, C+H].  DHC [2,H,npad] is scratch."""
+        raise NotImplementedError
+
     # ------------------------------------------------------------------ dense adjacency ops at levels 2-3 (A4, A6)
     def dense_rownorm_fwd(self, A, R, C, out, invd_out, ge1_out):
         """s = rowsum(A); d = max(s,1); out = A/d; invd = 1/d; ge1 = (s >= 1)  (clamp(min=1) of DenseSAGEConv)."""
@@ -382,6 +399,25 @@ class HipKernels(KernelSpec):
         self._dev(dout, arg, dx_zeroed)
         self._chk(self.lib.cgc_segment_max_bwd(_ptr(dout), _ptr(arg), B, D, _ptr(dx_zeroed), self._stream()),
                   'cgc_segment_max_bwd')
+
+    # -- jumping knowledge
+    def jk_supported(self, C):
+        return bool(self.lib.cgc_jk_supported(int(C)))
+
+    @staticmethod
+    def _ptr_array(tensors):
+        return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+    def jk_fwd(self, xs, n, npad, C, lstm, w_att, b_att, out, HS, CS):
+        self._dev(xs, w_att, b_att, out, HS, CS, *lstm)
+        self._chk(self.lib.cgc_jk_lstm_fwd(_ptr(xs), n, npad, C, self._ptr_array(lstm), _ptr(w_att), _ptr(b_att), _ptr(out),
+                                           _ptr(HS), _ptr(CS), self._stream()), 'cgc_jk_lstm_fwd')
+
+    def jk_bwd(self, xs, dout, n, npad, C, lstm, w_att, b_att, HS, CS, dxs, DGT, INT, DHC):
+        self._dev(xs, dout, w_att, b_att, HS, CS, dxs, DGT, INT, DHC, *lstm)
+        self._chk(self.lib.cgc_jk_lstm_bwd(_ptr(xs), _ptr(dout), n, npad, C, self._ptr_array(lstm), _ptr(w_att), _ptr(b_att),
+                                           _ptr(HS), _ptr(CS), _ptr(dxs), _ptr(DGT), _ptr(INT), _ptr(DHC), self._stream()),
+                  'cgc_jk_lstm_bwd')
 
     # -- dense adjacency ops
     def dense_rownorm_fwd(self, A, R, C, out, invd_out, ge1_out):

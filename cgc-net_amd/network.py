@@ -22,6 +22,12 @@ EPS = 1e-15
 RENORM_P = 0.4      # model/network.py:260,271,280
 
 
+def _cpu_seam():
+    """True only when tests have swapped the kernel table for the torch restatement (never in product runs)."""
+    from . import kernels
+    return kernels._instance is not None and not kernels.is_native()
+
+
 def _activation_module(name):
     assert name in ('relu', 'elu', 'leakyrelu')          # model/network.py:84-91
     return {'relu': nn.ReLU, 'elu': nn.ELU, 'leakyrelu': nn.LeakyReLU}[name](inplace=True)
@@ -113,7 +119,7 @@ class DenseGINConv(nn.Module):
 # ------------------------------------------------------------------------------------------------
 class DenseJK(nn.Module):
     """LSTM-attention jumping knowledge over a block's three layer outputs (model/network.py:11-55).
-    The recurrence stays on torch.nn.LSTM (MIOpen): SURVEY A7."""
+    Three layers with 8/16/20 channels run on the fused HIP kernels (csrc/jk.hip); anything else on torch.nn.LSTM."""
 
     def __init__(self, mode, channels=None, num_layers=None):
         super().__init__()
@@ -135,7 +141,13 @@ class DenseJK(nn.Module):
     def forward(self, xs):
         """[..., layers*channels] -> [..., channels]; works on [B, N, 3C] and on flat [Ntot, 3C] rows alike."""
         lead = xs.shape[:-1]
-        seq = xs.reshape(-1, xs.shape[-1] // self.channel, self.channel)   # [rows, layers, channels]
+        layers = xs.shape[-1] // self.channel
+        if not xs.is_cuda and not _cpu_seam():
+            raise RuntimeError('cgc_net_amd.DenseJK takes GPU tensors only (there is no CPU fallback)')
+        if layers == 3 and ops.K().jk_supported(self.channel):
+            # fused bi-LSTM + attention kernels (one thread per node); nn.LSTM / nn.Linear only hold the parameters
+            return ops.dense_jk(xs.reshape(-1, 3 * self.channel), self.lstm, self.att).reshape(*lead, self.channel)
+        seq = xs.reshape(-1, layers, self.channel)   # [rows, layers, channels]: other shapes stay on torch.nn.LSTM (MIOpen)
         alpha, _ = self.lstm(seq)
         alpha = torch.softmax(self.att(alpha).squeeze(-1), dim=-1)
         return (seq * alpha.unsqueeze(-1)).sum(dim=1).reshape(*lead, self.channel)

@@ -413,6 +413,66 @@ def segment_max(x, gptr, B, nmax):
 
 
 # ----------------------------------------------------------------------------------------------
+# jumping-knowledge attention (DenseJK): fused bi-LSTM + attention, one thread per node
+# ----------------------------------------------------------------------------------------------
+class _DenseJK(Function):
+    @staticmethod
+    def forward(ctx, xs, w_att, b_att, *lstm):
+        xs = _f32c(xs)
+        n = xs.shape[0]
+        C = xs.shape[1] // 3
+        H = 3 * C // 2
+        npad = -(-max(n, 1) // 1024) * 1024            # row padding of the transposed buffers: K slices of 1536 divide 3*npad
+        dev = xs.device
+        lstm = [_f32c(p) for p in lstm]
+        w_att, b_att = _f32c(w_att), _f32c(b_att)
+        out = torch.empty(n, C, dtype=torch.float32, device=dev)
+        HS = torch.empty(6 * H, npad, dtype=torch.float32, device=dev)
+        CS = torch.empty(6 * H, npad, dtype=torch.float32, device=dev)
+        K().jk_fwd(xs, n, npad, C, lstm, w_att, b_att, out, HS, CS)
+        ctx.save_for_backward(xs, w_att, b_att, HS, CS, *lstm)
+        ctx.dims = (n, npad, C, H)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        xs, w_att, b_att, HS, CS = ctx.saved_tensors[:5]
+        lstm = list(ctx.saved_tensors[5:])
+        n, npad, C, H = ctx.dims
+        dev = xs.device
+        ng, ni, ktot = 4 * H + 1, C + 2 * H + 1, 3 * npad
+        dxs = torch.empty_like(xs)
+        DGT = torch.empty(2, ng, ktot, dtype=torch.float32, device=dev)
+        INT = torch.empty(2, ni, ktot, dtype=torch.float32, device=dev)
+        DHC = torch.empty(2, H, npad, dtype=torch.float32, device=dev)
+        K().jk_bwd(xs, _f32c(dout), n, npad, C, lstm, w_att, b_att, HS, CS, dxs, DGT, INT, DHC)
+        # parameter gradients: G_d = DGT[d] @ INT[d]^T, reduced over K slices of 1536 columns (deterministic combine)
+        kp = 1536
+        parts = ktot // kp
+        G = torch.empty(2, ng * ni, dtype=torch.float32, device=dev)
+        ws = torch.empty(parts, ng * ni, dtype=torch.float32, device=dev)
+        for d in range(2):
+            K().gemm(DGT[d], INT[d], ws, ng, ni, kp, False, True, ktot, ktot, ni, 1.0, 0.0, None, parts, kp, kp, ng * ni)
+            K().reduce_batch_sum(ws, G[d], parts, ng * ni, 0.0)
+        G = G.view(2, ng, ni)
+        grads = []
+        for d in range(2):
+            grads += [G[d, :4 * H, :C], G[d, :4 * H, C:C + H], G[d, :4 * H, C + H], G[d, :4 * H, C + H]]
+        dw_att = torch.cat([G[0, 4 * H, C + H + 1:], G[1, 4 * H, C + H + 1:]]).reshape(w_att.shape)
+        db_att = G[0, 4 * H, C + H].reshape(b_att.shape)
+        return (dxs, dw_att, db_att) + tuple(grads)
+
+
+def dense_jk(xs, lstm_module, att_module):
+    """DenseJK on flat rows: xs [rows, 3C] -> [rows, C] through the fused kernels (torch.nn.LSTM / nn.Linear hold the
+    parameters; their layouts are consumed as they are)."""
+    p = lstm_module
+    lstm = (p.weight_ih_l0, p.weight_hh_l0, p.bias_ih_l0, p.bias_hh_l0,
+            p.weight_ih_l0_reverse, p.weight_hh_l0_reverse, p.bias_ih_l0_reverse, p.bias_hh_l0_reverse)
+    return _DenseJK.apply(xs, att_module.weight, att_module.bias, *lstm)
+
+
+# ----------------------------------------------------------------------------------------------
 # DiffPool on the sparse level:  X' = S^T X,  A' = S^T (A S)   per graph
 # ----------------------------------------------------------------------------------------------
 class _DiffPoolSparse(Function):

@@ -116,6 +116,21 @@ int cgc_softmax_bwd(const float* S, const float* dS, int n, int C, float* dx,
 int cgc_segment_max_fwd(const float* x, const int* gptr, int B, int D, int nmax, float* out, int* arg, cgc_stream_t stream);
 int cgc_segment_max_bwd(const float* dout, const int* arg, int B, int D, float* dx_zeroed, cgc_stream_t stream);
 
+/* ---- A7: DenseJK (model/network.py:11-55): bi-LSTM(C -> H = 3C/2) over a node's 3 layer embeddings + Linear(2H -> 1)
+ * attention + softmax-weighted sum, one thread per node.  xs [n, 3C], out [n, C].  lstm = HOST array of 8 device pointers
+ * {w_ih[4H,C], w_hh[4H,H], b_ih[4H], b_hh[4H]} for the forward direction, then the same four for the reverse direction
+ * (torch.nn.LSTM layout, gate order i,f,g,o).  HS, CS: [6H, npad] saved hidden / cell states (npad >= n).
+ * cgc_jk_supported(C): 1 if this C is compiled in (8, 16, 20).
+ * Backward writes dxs [n, 3C] and, for the parameter gradients, the transposed buffers DGT [2][4H+1][3*npad] and
+ * INT [2][C+2H+1][3*npad] (zero in padded columns) whose per-direction product DGT_d * INT_d^T (cgc_gemm_f32, NT) holds
+ * [dW_ih | dW_hh | db | .] in rows 0..4H-1 and [. | . | d b_att | d w_att[dH:(d+1)H]] in row 4H.  DHC: [2][H][npad] scratch. */
+int cgc_jk_supported(int C);
+int cgc_jk_lstm_fwd(const float* xs, int n, int npad, int C, const float* const* lstm, const float* w_att,
+                    const float* b_att, float* out, float* HS, float* CS, cgc_stream_t stream);
+int cgc_jk_lstm_bwd(const float* xs, const float* dout, int n, int npad, int C, const float* const* lstm,
+                    const float* w_att, const float* b_att, const float* HS, const float* CS, float* dxs, float* DGT,
+                    float* INT, float* DHC, cgc_stream_t stream);
+
 /* ---- A4/A6 at levels 2-3 (dense, real-valued adjacency that carries gradient) */
 int cgc_dense_rownorm_fwd(const float* A, int R, int C, float* out, float* invd, float* ge1, cgc_stream_t stream);
 int cgc_dense_rownorm_bwd(const float* dOut, const float* Anorm, const float* invd, const float* ge1, int R, int C,

@@ -242,6 +242,66 @@ class TorchKernels(KernelSpec):
         ok = a >= 0
         dx_zeroed[a[ok], cols[ok]] = dout[ok]
 
+    # ------------------------------------------------------------------ jumping-knowledge attention
+    def jk_supported(self, C):
+        return C % 2 == 0
+
+    @staticmethod
+    def _jk_math(xs, C, lstm, w_att, b_att):
+        """bi-LSTM (torch gate order i,f,g,o) over the 3 layer embeddings + attention; returns out, hs, cs, gates."""
+        H = 3 * C // 2
+        x = xs.reshape(-1, 3, C)
+        hs, cs = {}, {}
+        for d in range(2):
+            w_ih, w_hh, b_ih, b_hh = lstm[4 * d:4 * d + 4]
+            h = x.new_zeros(x.shape[0], H)
+            c = x.new_zeros(x.shape[0], H)
+            for s in range(3):
+                t = s if d == 0 else 2 - s
+                g = x[:, t] @ w_ih.t() + b_ih + h @ w_hh.t() + b_hh
+                i, f, gg, o = torch.sigmoid(g[:, :H]), torch.sigmoid(g[:, H:2 * H]), torch.tanh(g[:, 2 * H:3 * H]), torch.sigmoid(g[:, 3 * H:])
+                c = f * c + i * gg
+                h = o * torch.tanh(c)
+                hs[(d, t)], cs[(d, t)] = h, c
+        score = torch.stack([torch.cat([hs[(0, t)], hs[(1, t)]], 1) @ w_att + b_att for t in range(3)], 1)
+        a = torch.softmax(score, dim=1)
+        return (x * a.unsqueeze(-1)).sum(1), hs, cs
+
+    def jk_fwd(self, xs, n, npad, C, lstm, w_att, b_att, out, HS, CS):
+        H = 3 * C // 2
+        o, hs, cs = self._jk_math(xs.detach(), C, [p.detach() for p in lstm], w_att.detach().reshape(-1), b_att.detach())
+        out.copy_(o)
+        for d in range(2):
+            for t in range(3):
+                HS[(d * 3 + t) * H:(d * 3 + t + 1) * H, :n] = hs[(d, t)].t()
+                CS[(d * 3 + t) * H:(d * 3 + t + 1) * H, :n] = cs[(d, t)].t()
+
+    def jk_bwd(self, xs, dout, n, npad, C, lstm, w_att, b_att, HS, CS, dxs, DGT, INT, DHC):
+        """Same CONTRACT as the HIP kernel (the products DGT[d] @ INT[d]^T hold the parameter gradients), obtained
+        here from autograd: the gate-gradient rows are reconstructed so that the product matches."""
+        H = 3 * C // 2
+        with torch.enable_grad():
+            x = xs.detach().clone().requires_grad_()
+            ps = [p.detach().clone().requires_grad_() for p in lstm]
+            wa, ba = w_att.detach().clone().reshape(-1).requires_grad_(), b_att.detach().clone().requires_grad_()
+            o, hs, cs = self._jk_math(x, C, ps, wa, ba)
+            grads = torch.autograd.grad(o, [x] + ps + [wa, ba], dout)
+        dxs.copy_(grads[0])
+        # encode the parameter gradients in the (DGT, INT) factorisation: put G_d in the first columns against an identity
+        DGT.zero_()
+        INT.zero_()
+        ni = C + 2 * H + 1
+        for d in range(2):
+            g = torch.zeros(4 * H + 1, ni)
+            g[:4 * H, :C] = grads[1 + 4 * d]
+            g[:4 * H, C:C + H] = grads[2 + 4 * d]
+            g[:4 * H, C + H] = grads[3 + 4 * d]
+            g[4 * H, C + H + 1:] = grads[9][d * H:(d + 1) * H]
+            g[4 * H, C + H] = grads[10].reshape(()) if d == 0 else 0.0
+            assert 3 * npad >= ni, 'twin needs 3*npad >= C+2H+1 columns'
+            DGT[d][:, :ni] = g.to(DGT.device)
+            INT[d][:, :ni] = torch.eye(ni, device=INT.device)
+
     # ------------------------------------------------------------------ dense adjacency ops
     def dense_rownorm_fwd(self, A, R, C, out, invd_out, ge1_out):
         a = A.reshape(R, C)

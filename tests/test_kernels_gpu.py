@@ -381,3 +381,43 @@ def test_dense_adjacency_transforms(B_, C):
         res[name] = (out, invd, ge1, dA, rn, drn)
     for i, (x, y) in enumerate(zip(res['hip'], res['ref'])):
         close(x, y, 2e-5, 'dense transform %d' % i)
+
+
+@pytest.mark.parametrize('C,n', [(8, 37), (20, 300), (16, 1500), (20, 2500)])
+def test_dense_jk_kernels(C, n):
+    """Fused bi-LSTM + attention (csrc/jk.hip) against the torch restatement, and that restatement against torch.nn.LSTM."""
+    H = 3 * C // 2
+    torch.manual_seed(C + n)
+    lstm_mod = torch.nn.LSTM(C, H, bidirectional=True, batch_first=True)
+    att = torch.nn.Linear(2 * H, 1)
+    xs = torch.randn(n, 3 * C)
+    p = lstm_mod
+    lstm = [t.detach() for t in (p.weight_ih_l0, p.weight_hh_l0, p.bias_ih_l0, p.bias_hh_l0, p.weight_ih_l0_reverse,
+                                 p.weight_hh_l0_reverse, p.bias_ih_l0_reverse, p.bias_hh_l0_reverse)]
+    w_att, b_att = att.weight.detach().reshape(-1), att.bias.detach()
+    npad = -(-n // 1024) * 1024
+    # torch.nn.LSTM semantics of the twin (pins the gate order / direction handling)
+    seq = xs.reshape(n, 3, C)
+    alpha, _ = lstm_mod(seq)
+    a = torch.softmax(att(alpha).squeeze(-1), dim=-1)
+    want_out = (seq * a.unsqueeze(-1)).sum(1).detach()
+    res = {}
+    for name, K_, dev in (('ref', REF, 'cpu'), ('hip', hip(), DEV)):
+        t = lambda v: v.to(dev)
+        out = torch.empty(n, C, device=dev)
+        HS, CS = torch.zeros(6 * H, npad, device=dev), torch.zeros(6 * H, npad, device=dev)
+        K_.jk_fwd(t(xs), n, npad, C, [t(v) for v in lstm], t(w_att), t(b_att), out, HS, CS)
+        dout = t(rnd(n, C, seed=3))
+        dxs = torch.empty(n, 3 * C, device=dev)
+        DGT = torch.full((2, 4 * H + 1, 3 * npad), 7.0, device=dev)
+        INT = torch.full((2, C + 2 * H + 1, 3 * npad), 7.0, device=dev)
+        DHC = torch.empty(2, H, npad, device=dev)
+        K_.jk_bwd(t(xs), dout, n, npad, C, [t(v) for v in lstm], t(w_att), t(b_att), HS, CS, dxs, DGT, INT, DHC)
+        G = torch.stack([DGT[d].double().cpu() @ INT[d].double().cpu().t() for d in range(2)])
+        G[:, :4 * H, C + H + 1:] = 0            # unused corner blocks of the factorisation
+        G[:, 4 * H, :C + H] = 0
+        G[1, 4 * H, C + H] = 0
+        res[name] = dict(out=out, HS=HS[:, :n], CS=CS[:, :n], dxs=dxs, G=G)
+    close(res['ref']['out'], want_out, 1e-5, 'twin vs torch.nn.LSTM')
+    for k in res['ref']:
+        close(res['hip'][k], res['ref'][k], 2e-4 if k == 'G' else 2e-5, 'jk ' + k)
