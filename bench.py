@@ -8,7 +8,8 @@ SoftPoolingGcnEncoder forward, cross-entropy, backward through every kernel, gra
 
 Workload (BASELINE.json configs[2], SURVEY.md 8(d) "C3"): 32 graphs per GPU, ~1800 nodes / ~16k edges / 16 features
 each, cluster counts fixed by the reference's ``setting.max_num_nodes`` = 11404 -> C1 = 1140, C2 = 114
-(setting.py:15, train.py:254).  ``--maxn 1800`` gives the "clusters proportional to the graph" variant (C1 = 180).
+(setting.py:15, train.py:254), model flags as shipped in parallel_train.sh (--jk --norm_adj --drop 0.2; ``--flags plain``
+turns the three off).  ``--maxn 1800`` gives the "clusters proportional to the graph" variant (C1 = 180).
 
 Extra objects on the line:
   roofline            dominant kernel = the 128x128 pipelined fp32-MFMA GEMM k_gemm_f32<2,2,2,2,*> (bound "mfma", peak
@@ -45,8 +46,9 @@ def parse():
     p.add_argument('--nodes', type=int, default=1800, help='mean nodes per graph')
     p.add_argument('--feat', type=int, default=16)
     p.add_argument('--maxn', type=int, default=11404, help="the reference's setting.max_num_nodes (fixes cluster counts)")
-    p.add_argument('--flags', choices=['plain', 'shipped'], default='plain',
-                   help="'shipped' = parallel_train.sh: --jk --norm_adj --drop 0.2")
+    p.add_argument('--flags', choices=['plain', 'shipped'], default='shipped',
+                   help="'shipped' (default) = the reference's only shipped hyper-parameter set, parallel_train.sh:2-3: "
+                        "--jk --norm_adj --drop 0.2; 'plain' = none of the three (SURVEY 8(d) parity configuration)")
     p.add_argument('--pool', type=int, default=4, help='distinct resident batches cycled through')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--cpu-seconds', type=float, default=12.0, help='CPU baseline: stop after this much timed work')

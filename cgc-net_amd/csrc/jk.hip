@@ -1,7 +1,7 @@
 // Jumping-knowledge attention of CGC-Net (DenseJK, model/network.py:11-55): per node, a bidirectional LSTM (input C, hidden
 // H = 3C/2) runs over the node's THREE layer embeddings, a Linear(2H -> 1) scores each step, a softmax over the three
 // scores weights the embeddings.  Rows are independent and the recurrence is 3 steps long, so the whole operator is one
-// kernel per direction of autograd: ONE thread per node, the 2 x 4H x (C+H) LSTM weights live in LDS as float4 {i,f,g,o}
+// kernel per direction of autograd: TWO lanes per node (one per LSTM direction), the 2 x 4H x (C+H) LSTM weights live in LDS as float4 {i,f,g,o}
 // per (hidden unit, input) and are read as wave-wide broadcasts (conflict-free), 200 FMAs per ds_read_b128 x 50.
 // MIOpen's generic RNN path spends ~10 ms per training step on this (rocBLAS calls per time step); this takes < 0.2 ms.
 //
@@ -65,68 +65,81 @@ __global__ __launch_bounds__(JK_THREADS) void k_jk_fwd(const float* __restrict__
   float* watt = reinterpret_cast<float*>(B4 + 2 * H);
   jk_fill_lds<C>(w, Wt, B4, watt, JK_THREADS);
   __syncthreads();
-  const int row = blockIdx.x * JK_THREADS + threadIdx.x;
-  if (row >= n) return;
+  // two adjacent lanes per node: the even lane runs the forward-direction LSTM, the odd lane the reverse one (the two
+  // recurrences are independent); they meet once, through a shuffle, for the attention scores
+  const int gid = blockIdx.x * JK_THREADS + threadIdx.x;
+  const int row = gid >> 1, d = gid & 1;
+  const bool valid = row < n;          // keep invalid lanes alive for the shuffle below
+  const int r = valid ? row : 0;
 
   float x[3][C];
 #pragma unroll
   for (int t = 0; t < 3; ++t)
 #pragma unroll
-    for (int k = 0; k < C; ++k) x[t][k] = xs[(size_t)row * 3 * C + t * C + k];
+    for (int k = 0; k < C; ++k) x[t][k] = xs[(size_t)r * 3 * C + t * C + k];
   float score[3];
 #pragma unroll
-  for (int t = 0; t < 3; ++t) score[t] = watt[2 * H];
+  for (int t = 0; t < 3; ++t) score[t] = 0.f;
 
+  const float4* Wd = Wt + d * H * KIN;
 #pragma unroll
-  for (int d = 0; d < 2; ++d) {
+  for (int s = 0; s < 3; ++s) {
+    float hprev[H];
+    // time index of step s for this lane's direction (runtime d): forward s, reverse 2-s
+    const int t = d == 0 ? s : 2 - s;
+    const int tprev = d == 0 ? t - 1 : t + 1;
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {
-      const int t = d == 0 ? s : 2 - s;
-      const int tprev = d == 0 ? t - 1 : t + 1;
-      float hprev[H];
+    for (int k = 0; k < H; ++k) hprev[k] = (s > 0 && valid) ? HS[(size_t)((d * 3 + tprev) * H + k) * npad + r] : 0.f;
+    float xt[C];
 #pragma unroll
-      for (int k = 0; k < H; ++k) hprev[k] = s > 0 ? HS[(size_t)((d * 3 + tprev) * H + k) * npad + row] : 0.f;
-      const float4* Wd = Wt + d * H * KIN;
-      float sc = 0.f;
-      for (int j = 0; j < H; ++j) {     // rolled: keeps the code in the instruction cache
-        const float4* wj = Wd + j * KIN;
-        float4 acc = B4[d * H + j];
+    for (int k = 0; k < C; ++k) xt[k] = d == 0 ? x[s][k] : x[2 - s][k];
+    float sc = 0.f;
+    for (int j = 0; j < H; ++j) {     // rolled: keeps the code in the instruction cache
+      const float4* wj = Wd + j * KIN;
+      float4 acc = B4[d * H + j];
 #pragma unroll
-        for (int k = 0; k < C; ++k) {
-          const float4 q = wj[k];
-          acc.x = fmaf(q.x, x[t][k], acc.x); acc.y = fmaf(q.y, x[t][k], acc.y);
-          acc.z = fmaf(q.z, x[t][k], acc.z); acc.w = fmaf(q.w, x[t][k], acc.w);
-        }
-#pragma unroll
-        for (int k = 0; k < H; ++k) {
-          const float4 q = wj[C + k];
-          acc.x = fmaf(q.x, hprev[k], acc.x); acc.y = fmaf(q.y, hprev[k], acc.y);
-          acc.z = fmaf(q.z, hprev[k], acc.z); acc.w = fmaf(q.w, hprev[k], acc.w);
-        }
-        const float gi = sigmoidf_(acc.x), gf = sigmoidf_(acc.y), gg = tanhf(acc.z), go = sigmoidf_(acc.w);
-        const float cprev = s > 0 ? CS[(size_t)((d * 3 + tprev) * H + j) * npad + row] : 0.f;
-        const float c = gf * cprev + gi * gg;
-        const float h = go * tanhf(c);
-        CS[(size_t)((d * 3 + t) * H + j) * npad + row] = c;
-        HS[(size_t)((d * 3 + t) * H + j) * npad + row] = h;
-        sc = fmaf(watt[d * H + j], h, sc);
+      for (int k = 0; k < C; ++k) {
+        const float4 q = wj[k];
+        acc.x = fmaf(q.x, xt[k], acc.x); acc.y = fmaf(q.y, xt[k], acc.y);
+        acc.z = fmaf(q.z, xt[k], acc.z); acc.w = fmaf(q.w, xt[k], acc.w);
       }
-      score[t] += sc;
+#pragma unroll
+      for (int k = 0; k < H; ++k) {
+        const float4 q = wj[C + k];
+        acc.x = fmaf(q.x, hprev[k], acc.x); acc.y = fmaf(q.y, hprev[k], acc.y);
+        acc.z = fmaf(q.z, hprev[k], acc.z); acc.w = fmaf(q.w, hprev[k], acc.w);
+      }
+      const float gi = sigmoidf_(acc.x), gf = sigmoidf_(acc.y), gg = tanhf(acc.z), go = sigmoidf_(acc.w);
+      const float cprev = (s > 0 && valid) ? CS[(size_t)((d * 3 + tprev) * H + j) * npad + r] : 0.f;
+      const float c = gf * cprev + gi * gg;
+      const float h = go * tanhf(c);
+      if (valid) {
+        CS[(size_t)((d * 3 + t) * H + j) * npad + r] = c;
+        HS[(size_t)((d * 3 + t) * H + j) * npad + r] = h;
+      }
+      sc = fmaf(watt[d * H + j], h, sc);
     }
+    // score of TIME t: forward lane s -> t = s; reverse lane s -> t = 2-s
+    if (d == 0) score[s] = sc;
+    else score[2 - s] = sc;
   }
+#pragma unroll
+  for (int t = 0; t < 3; ++t) score[t] += __shfl_xor(score[t], 1) + watt[2 * H];
   const float m = fmaxf(score[0], fmaxf(score[1], score[2]));
   float a[3];
   float den = 0.f;
 #pragma unroll
   for (int t = 0; t < 3; ++t) { a[t] = expf(score[t] - m); den += a[t]; }
   const float inv = 1.f / den;
+  if (valid && d == 0) {
 #pragma unroll
-  for (int k = 0; k < C; ++k) out[(size_t)row * C + k] = (a[0] * x[0][k] + a[1] * x[1][k] + a[2] * x[2][k]) * inv;
+    for (int k = 0; k < C; ++k) out[(size_t)row * C + k] = (a[0] * x[0][k] + a[1] * x[1][k] + a[2] * x[2][k]) * inv;
+  }
 }
 
 // Backward.  DGT: [2][4H+1][3*npad]  (rows g*H+j = d loss / d pre-activation gate, row 4H = d loss / d attention score)
 //            INT: [2][C+2H+1][3*npad] (rows: x_t (C), h_{t-1} (H), ones (1), h_t (H)); column = t*npad + row.
-//            DHC: [2][H][npad] scratch (recurrent dh and dc carries).
+//            DHC: [2][2][H][npad] scratch (recurrent dh and dc carries of each direction).
 template <int C>
 __global__ __launch_bounds__(JK_THREADS) void k_jk_bwd(const float* __restrict__ xs, const float* __restrict__ dout, int n, int npad,
                                                        const JkWeights w, const float* HS, const float* CS,
@@ -140,21 +153,25 @@ __global__ __launch_bounds__(JK_THREADS) void k_jk_bwd(const float* __restrict__
   float* watt = reinterpret_cast<float*>(B4 + 2 * H);
   jk_fill_lds<C>(w, Wt, B4, watt, JK_THREADS);
   __syncthreads();
-  const int row = blockIdx.x * JK_THREADS + threadIdx.x;
-  if (row >= npad) return;
+  // two adjacent lanes per node, one per LSTM direction (as in the forward kernel); partial input gradients and partial
+  // attention scores are exchanged with one shuffle each
+  const int gid = blockIdx.x * JK_THREADS + threadIdx.x;
+  const int row = gid >> 1, d = gid & 1;
   const size_t ktot = (size_t)3 * npad;
+  float* dgt = DGT + (size_t)d * NG * ktot;
+  float* inT = INT + (size_t)d * NI * ktot;
   if (row >= n) {            // padding columns of the transposed buffers must be zero: they take part in the GEMM
-    for (int d = 0; d < 2; ++d)
+    if (row < npad)          // (no shuffle partner needed: both lanes of a padding node take this branch)
       for (int t = 0; t < 3; ++t) {
         const size_t col = (size_t)t * npad + row;
-        for (int r = 0; r < NG; ++r) DGT[((size_t)d * NG + r) * ktot + col] = 0.f;
-        for (int r = 0; r < NI; ++r) INT[((size_t)d * NI + r) * ktot + col] = 0.f;
+        for (int r = 0; r < NG; ++r) dgt[(size_t)r * ktot + col] = 0.f;
+        for (int r = 0; r < NI; ++r) inT[(size_t)r * ktot + col] = 0.f;
       }
     return;
   }
 
   float x[3][C], dx[3][C];
-  float score[3], ds[3];
+  float ds[3];
   {
     float dy[C];
 #pragma unroll
@@ -163,14 +180,13 @@ __global__ __launch_bounds__(JK_THREADS) void k_jk_bwd(const float* __restrict__
     for (int t = 0; t < 3; ++t)
 #pragma unroll
       for (int k = 0; k < C; ++k) x[t][k] = xs[(size_t)row * 3 * C + t * C + k];
-    // attention weights again (scores from the saved hidden states)
+    // attention weights again: this lane's half of every score from its direction's saved hidden states, partner's half by shuffle
+    float score[3];
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
-      float sc = watt[2 * H];
-#pragma unroll
-      for (int d = 0; d < 2; ++d)
-        for (int j = 0; j < H; ++j) sc = fmaf(watt[d * H + j], HS[(size_t)((d * 3 + t) * H + j) * npad + row], sc);
-      score[t] = sc;
+      float sc = 0.f;
+      for (int j = 0; j < H; ++j) sc = fmaf(watt[d * H + j], HS[(size_t)((d * 3 + t) * H + j) * npad + row], sc);
+      score[t] = sc + __shfl_xor(sc, 1) + watt[2 * H];
     }
     const float m = fmaxf(score[0], fmaxf(score[1], score[2]));
     float a[3], den = 0.f;
@@ -190,88 +206,96 @@ __global__ __launch_bounds__(JK_THREADS) void k_jk_bwd(const float* __restrict__
     for (int t = 0; t < 3; ++t) {
       ds[t] = a[t] * (da[t] - mean);
 #pragma unroll
-      for (int k = 0; k < C; ++k) dx[t][k] = a[t] * dy[k];
+      for (int k = 0; k < C; ++k) dx[t][k] = d == 0 ? a[t] * dy[k] : 0.f;     // the attention term is counted once
     }
   }
 
+  float* DH = DHC + (size_t)((d * 2 + 0) * H) * npad;       // [H][npad] recurrent carries of this direction
+  float* DC = DHC + (size_t)((d * 2 + 1) * H) * npad;
+  const float4* Wd = Wt + d * H * KIN;
 #pragma unroll
-  for (int d = 0; d < 2; ++d) {
-    float* DH = DHC + (size_t)(0 * H) * npad;       // [H][npad] carries; reused by the second direction (same thread, in order)
-    float* DC = DHC + (size_t)(1 * H) * npad;
-    float* dgt = DGT + (size_t)d * NG * ktot;
-    float* inT = INT + (size_t)d * NI * ktot;
+  for (int s = 2; s >= 0; --s) {
+    const int t = d == 0 ? s : 2 - s;
+    const int tprev = d == 0 ? t - 1 : t + 1;
+    const size_t col = (size_t)t * npad + row;
+    float xt[C], dxt[C];
 #pragma unroll
-    for (int s = 2; s >= 0; --s) {
-      const int t = d == 0 ? s : 2 - s;
-      const int tprev = d == 0 ? t - 1 : t + 1;
-      const size_t col = (size_t)t * npad + row;
-      float hprev[H], dhp[H];
+    for (int k = 0; k < C; ++k) { xt[k] = d == 0 ? x[s][k] : x[2 - s][k]; dxt[k] = 0.f; }
+    const float dst = d == 0 ? ds[s] : ds[2 - s];
+    float hprev[H], dhp[H];
+#pragma unroll
+    for (int k = 0; k < H; ++k) {
+      hprev[k] = s > 0 ? HS[(size_t)((d * 3 + tprev) * H + k) * npad + row] : 0.f;
+      dhp[k] = 0.f;
+      inT[(size_t)(C + k) * ktot + col] = hprev[k];
+    }
+#pragma unroll
+    for (int k = 0; k < C; ++k) inT[(size_t)k * ktot + col] = xt[k];
+    inT[(size_t)(C + H) * ktot + col] = 1.f;
+    dgt[(size_t)(4 * H) * ktot + col] = dst;
+    for (int j = 0; j < H; ++j) {
+      const float4* wj = Wd + j * KIN;
+      float4 acc = B4[d * H + j];
+#pragma unroll
+      for (int k = 0; k < C; ++k) {
+        const float4 q = wj[k];
+        acc.x = fmaf(q.x, xt[k], acc.x); acc.y = fmaf(q.y, xt[k], acc.y);
+        acc.z = fmaf(q.z, xt[k], acc.z); acc.w = fmaf(q.w, xt[k], acc.w);
+      }
 #pragma unroll
       for (int k = 0; k < H; ++k) {
-        hprev[k] = s > 0 ? HS[(size_t)((d * 3 + tprev) * H + k) * npad + row] : 0.f;
-        dhp[k] = 0.f;
-        inT[(size_t)(C + k) * ktot + col] = hprev[k];
+        const float4 q = wj[C + k];
+        acc.x = fmaf(q.x, hprev[k], acc.x); acc.y = fmaf(q.y, hprev[k], acc.y);
+        acc.z = fmaf(q.z, hprev[k], acc.z); acc.w = fmaf(q.w, hprev[k], acc.w);
+      }
+      const float gi = sigmoidf_(acc.x), gf = sigmoidf_(acc.y), gg = tanhf(acc.z), go = sigmoidf_(acc.w);
+      const size_t slot = (size_t)((d * 3 + t) * H + j) * npad + row;
+      const float cprev = s > 0 ? CS[(size_t)((d * 3 + tprev) * H + j) * npad + row] : 0.f;
+      const float th = tanhf(CS[slot]);
+      inT[(size_t)(C + H + 1 + j) * ktot + col] = HS[slot];                   // h_t: pairs with the score-gradient row
+      float dh = dst * watt[d * H + j];
+      float dc = 0.f;
+      if (s < 2) { dh += DH[(size_t)j * npad + row]; dc = DC[(size_t)j * npad + row]; }
+      dc = fmaf(dh * go, 1.f - th * th, dc);
+      float4 q;                                                               // d loss / d pre-activation (i, f, g, o)
+      q.x = dc * gg * gi * (1.f - gi);
+      q.y = dc * cprev * gf * (1.f - gf);
+      q.z = dc * gi * (1.f - gg * gg);
+      q.w = dh * th * go * (1.f - go);
+      if (s > 0) DC[(size_t)j * npad + row] = dc * gf;
+      dgt[(size_t)(0 * H + j) * ktot + col] = q.x;
+      dgt[(size_t)(1 * H + j) * ktot + col] = q.y;
+      dgt[(size_t)(2 * H + j) * ktot + col] = q.z;
+      dgt[(size_t)(3 * H + j) * ktot + col] = q.w;
+#pragma unroll
+      for (int k = 0; k < C; ++k) {
+        const float4 v = wj[k];
+        dxt[k] += v.x * q.x + v.y * q.y + v.z * q.z + v.w * q.w;
       }
 #pragma unroll
-      for (int k = 0; k < C; ++k) inT[(size_t)k * ktot + col] = x[t][k];
-      inT[(size_t)(C + H) * ktot + col] = 1.f;
-      dgt[(size_t)(4 * H) * ktot + col] = ds[t];
-      const float4* Wd = Wt + d * H * KIN;
-      for (int j = 0; j < H; ++j) {
-        const float4* wj = Wd + j * KIN;
-        float4 acc = B4[d * H + j];
-#pragma unroll
-        for (int k = 0; k < C; ++k) {
-          const float4 q = wj[k];
-          acc.x = fmaf(q.x, x[t][k], acc.x); acc.y = fmaf(q.y, x[t][k], acc.y);
-          acc.z = fmaf(q.z, x[t][k], acc.z); acc.w = fmaf(q.w, x[t][k], acc.w);
-        }
-#pragma unroll
-        for (int k = 0; k < H; ++k) {
-          const float4 q = wj[C + k];
-          acc.x = fmaf(q.x, hprev[k], acc.x); acc.y = fmaf(q.y, hprev[k], acc.y);
-          acc.z = fmaf(q.z, hprev[k], acc.z); acc.w = fmaf(q.w, hprev[k], acc.w);
-        }
-        const float gi = sigmoidf_(acc.x), gf = sigmoidf_(acc.y), gg = tanhf(acc.z), go = sigmoidf_(acc.w);
-        const size_t slot = (size_t)((d * 3 + t) * H + j) * npad + row;
-        const float cprev = s > 0 ? CS[(size_t)((d * 3 + tprev) * H + j) * npad + row] : 0.f;
-        const float th = tanhf(CS[slot]);
-        inT[(size_t)(C + H + 1 + j) * ktot + col] = HS[slot];                   // h_t: pairs with the score-gradient row
-        float dh = ds[t] * watt[d * H + j];
-        float dc = 0.f;
-        if (s < 2) { dh += DH[(size_t)j * npad + row]; dc = DC[(size_t)j * npad + row]; }
-        dc = fmaf(dh * go, 1.f - th * th, dc);
-        float4 q;                                                               // d loss / d pre-activation (i, f, g, o)
-        q.x = dc * gg * gi * (1.f - gi);
-        q.y = dc * cprev * gf * (1.f - gf);
-        q.z = dc * gi * (1.f - gg * gg);
-        q.w = dh * th * go * (1.f - go);
-        if (s > 0) DC[(size_t)j * npad + row] = dc * gf;
-        dgt[(size_t)(0 * H + j) * ktot + col] = q.x;
-        dgt[(size_t)(1 * H + j) * ktot + col] = q.y;
-        dgt[(size_t)(2 * H + j) * ktot + col] = q.z;
-        dgt[(size_t)(3 * H + j) * ktot + col] = q.w;
-#pragma unroll
-        for (int k = 0; k < C; ++k) {
-          const float4 v = wj[k];
-          dx[t][k] += v.x * q.x + v.y * q.y + v.z * q.z + v.w * q.w;
-        }
-#pragma unroll
-        for (int k = 0; k < H; ++k) {
-          const float4 v = wj[C + k];
-          dhp[k] += v.x * q.x + v.y * q.y + v.z * q.z + v.w * q.w;
-        }
+      for (int k = 0; k < H; ++k) {
+        const float4 v = wj[C + k];
+        dhp[k] += v.x * q.x + v.y * q.y + v.z * q.z + v.w * q.w;
       }
-      if (s > 0) {
+    }
+    if (s > 0) {
 #pragma unroll
-        for (int k = 0; k < H; ++k) DH[(size_t)k * npad + row] = dhp[k];
-      }
+      for (int k = 0; k < H; ++k) DH[(size_t)k * npad + row] = dhp[k];
+    }
+    // fold this step's input gradient into time slot t (static index per direction)
+#pragma unroll
+    for (int k = 0; k < C; ++k) {
+      if (d == 0) dx[s][k] += dxt[k];
+      else dx[2 - s][k] += dxt[k];
     }
   }
 #pragma unroll
   for (int t = 0; t < 3; ++t)
 #pragma unroll
-    for (int k = 0; k < C; ++k) dxs[(size_t)row * 3 * C + t * C + k] = dx[t][k];
+    for (int k = 0; k < C; ++k) {
+      const float tot = dx[t][k] + __shfl_xor(dx[t][k], 1);
+      if (d == 0) dxs[(size_t)row * 3 * C + t * C + k] = tot;
+    }
 }
 
 static void fill_weights(JkWeights& w, const float* const* lstm, const float* w_att, const float* b_att) {
@@ -289,14 +313,14 @@ extern "C" int cgc_jk_supported(int C) { return C == 8 || C == 16 || C == 20; }
 
 template <int C>
 static int launch_jk_fwd(const float* xs, int n, int npad, const JkWeights& w, float* out, float* HS, float* CS, hipStream_t st) {
-  hipLaunchKernelGGL(k_jk_fwd<C>, dim3(ceil_div(n, JK_THREADS)), dim3(JK_THREADS), JkDims<C>::lds_bytes, st, xs, n, npad, w, out, HS, CS);
+  hipLaunchKernelGGL(k_jk_fwd<C>, dim3(ceil_div(2 * n, JK_THREADS)), dim3(JK_THREADS), JkDims<C>::lds_bytes, st, xs, n, npad, w, out, HS, CS);
   CGC_RETURN_IF_LAUNCH_FAILED();
   return 0;
 }
 template <int C>
 static int launch_jk_bwd(const float* xs, const float* dout, int n, int npad, const JkWeights& w, const float* HS, const float* CS,
                          float* dxs, float* DGT, float* INT, float* DHC, hipStream_t st) {
-  hipLaunchKernelGGL(k_jk_bwd<C>, dim3(ceil_div(npad, JK_THREADS)), dim3(JK_THREADS), JkDims<C>::lds_bytes, st, xs, dout, n, npad, w,
+  hipLaunchKernelGGL(k_jk_bwd<C>, dim3(ceil_div(2 * npad, JK_THREADS)), dim3(JK_THREADS), JkDims<C>::lds_bytes, st, xs, dout, n, npad, w,
                      HS, CS, dxs, DGT, INT, DHC);
   CGC_RETURN_IF_LAUNCH_FAILED();
   return 0;

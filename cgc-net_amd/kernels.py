@@ -138,7 +138,7 @@ class KernelSpec(object):
     def jk_bwd(self, xs, dout, n, npad, C, lstm, w_att, b_att, HS, CS, dxs, DGT, INT, DHC):
         """DenseJK backward: dxs [n,3C]; DGT [2, 4H+1, 3*npad] and INT [2, C+2H+1, 3*npad] such that
         G_d = DGT[d] @ INT[d]^T gives dW_ih = G_d[:4H,:C], dW_hh = G_d[:4H,C:C+H], db_ih = db_hh = G_d[:4H,C+H],
-        d w_att[dH:(d+1)H] = G_d[4H, C+H+1:], d b_att = G_0[4H, C+H].  DHC [2,H,npad] is scratch."""
+        d w_att[dH:(d+1)H] = G_d[4H, C+H+1:], d b_att = G_0[4H, C+H].  DHC [2,2,H,npad] is scratch."""
         raise NotImplementedError
 
     # ------------------------------------------------------------------ dense adjacency ops at levels 2-3 (A4, A6)

@@ -444,7 +444,7 @@ class _DenseJK(Function):
         dxs = torch.empty_like(xs)
         DGT = torch.empty(2, ng, ktot, dtype=torch.float32, device=dev)
         INT = torch.empty(2, ni, ktot, dtype=torch.float32, device=dev)
-        DHC = torch.empty(2, H, npad, dtype=torch.float32, device=dev)
+        DHC = torch.empty(2, 2, H, npad, dtype=torch.float32, device=dev)
         K().jk_bwd(xs, _f32c(dout), n, npad, C, lstm, w_att, b_att, HS, CS, dxs, DGT, INT, DHC)
         # parameter gradients: G_d = DGT[d] @ INT[d]^T, reduced over K slices of 1536 columns (deterministic combine)
         kp = 1536

@@ -123,7 +123,7 @@ int cgc_segment_max_bwd(const float* dout, const int* arg, int B, int D, float* 
  * cgc_jk_supported(C): 1 if this C is compiled in (8, 16, 20).
  * Backward writes dxs [n, 3C] and, for the parameter gradients, the transposed buffers DGT [2][4H+1][3*npad] and
  * INT [2][C+2H+1][3*npad] (zero in padded columns) whose per-direction product DGT_d * INT_d^T (cgc_gemm_f32, NT) holds
- * [dW_ih | dW_hh | db | .] in rows 0..4H-1 and [. | . | d b_att | d w_att[dH:(d+1)H]] in row 4H.  DHC: [2][H][npad] scratch. */
+ * [dW_ih | dW_hh | db | .] in rows 0..4H-1 and [. | . | d b_att | d w_att[dH:(d+1)H]] in row 4H.  DHC: [2][2][H][npad] scratch. */
 int cgc_jk_supported(int C);
 int cgc_jk_lstm_fwd(const float* xs, int n, int npad, int C, const float* const* lstm, const float* w_att,
                     const float* b_att, float* out, float* HS, float* CS, cgc_stream_t stream);

@@ -411,7 +411,7 @@ def test_dense_jk_kernels(C, n):
         dxs = torch.empty(n, 3 * C, device=dev)
         DGT = torch.full((2, 4 * H + 1, 3 * npad), 7.0, device=dev)
         INT = torch.full((2, C + 2 * H + 1, 3 * npad), 7.0, device=dev)
-        DHC = torch.empty(2, H, npad, device=dev)
+        DHC = torch.empty(2, 2, H, npad, device=dev)
         K_.jk_bwd(t(xs), dout, n, npad, C, [t(v) for v in lstm], t(w_att), t(b_att), HS, CS, dxs, DGT, INT, DHC)
         G = torch.stack([DGT[d].double().cpu() @ INT[d].double().cpu().t() for d in range(2)])
         G[:, :4 * H, C + H + 1:] = 0            # unused corner blocks of the factorisation
