@@ -8,7 +8,7 @@
 
 #define L2_EPS 1e-12f
 #define RENORM_EPS 1e-15f
-#define MAX_SLOTS 512
+#define MAX_SLOTS 1024
 
 // ------------------------------------------------------------------------------------------------
 // column accumulators: block-level combine + second stage
@@ -374,24 +374,30 @@ __global__ __launch_bounds__(256) void k_bn_act_l2_bwd(const float* __restrict__
   for (int j = 0; j < MAXJ; ++j)
 #pragma unroll
     for (int v = 0; v < VEC; ++v) csum[0][j][v] = 0.f;
-  // per-lane column constants: do = ca*dy - cb - xhat*cc  with  ca = gamma*istd, cb = ca*s0/count, cc = ca*s1/count
-  float ca[MAXJ][VEC], cb[MAXJ][VEC], cc[MAXJ][VEC], mu[MAXJ][VEC], is[MAXJ][VEC];
+  // per-column constants: do = ca*dy - cb - xhat*cc  with  ca = gamma*istd, cb = ca*s0/count, cc = ca*s1/count.
+  // Narrow rows keep them in registers (the lane's columns never change); wide rows (MAXJ*VEC > 8: 5 x 32 registers would
+  // drop the kernel to one wave per SIMD) re-derive them from the L1-resident parameter vectors at every use.
+  constexpr bool REGC = MAXJ * VEC <= 8;
+  constexpr int RJ = REGC ? MAXJ : 1, RV = REGC ? VEC : 1;
+  float ca[RJ][RV], cb[RJ][RV], cc[RJ][RV], mu[RJ][RV], is[RJ][RV];
+  if (REGC) {
 #pragma unroll
-  for (int j = 0; j < MAXJ; ++j)
+    for (int j = 0; j < RJ; ++j)
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-      const int c = (rg.sl + lpr * j) * VEC + v;
-      ca[j][v] = 1.f; cb[j][v] = cc[j][v] = mu[j][v] = is[j][v] = 0.f;
-      if (mode != 0 && c < F) {
-        ca[j][v] = gamma[c] * istd[c];
-        if (mode == 2) {
-          cb[j][v] = ca[j][v] * sums[c] * inv_count;
-          cc[j][v] = ca[j][v] * sums[F + c] * inv_count;
-          mu[j][v] = mean[c];
-          is[j][v] = istd[c];
+      for (int v = 0; v < RV; ++v) {
+        const int c = (rg.sl + lpr * j) * VEC + v;
+        ca[j][v] = 1.f; cb[j][v] = cc[j][v] = mu[j][v] = is[j][v] = 0.f;
+        if (mode != 0 && c < F) {
+          ca[j][v] = gamma[c] * istd[c];
+          if (mode == 2) {
+            cb[j][v] = ca[j][v] * sums[c] * inv_count;
+            cc[j][v] = ca[j][v] * sums[F + c] * inv_count;
+            mu[j][v] = mean[c];
+            is[j][v] = istd[c];
+          }
         }
       }
-    }
+  }
   for (int base = rg.gwave * rg.rpw; base < n; base += rg.nwaves * rg.rpw) {
     const int row = base + rg.sub;
     const bool valid = row < n;
@@ -403,11 +409,27 @@ __global__ __launch_bounds__(256) void k_bn_act_l2_bwd(const float* __restrict__
       if (valid && c < F) {
         g[j].load(dy + (size_t)row * ldy + c);
         x[j].load(hn + (size_t)row * F + c);
+        Vec<VEC> pg, pi, pm, p0, p1;      // wide rows: parameter vectors for these columns
+        if (!REGC && mode != 0) {
+          pg.load(gamma + c);
+          pi.load(istd + c);
+          if (mode == 2) { pm.load(mean + c); p0.load(sums + c); p1.load(sums + F + c); }
+        }
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
           const float xv = x[j].v[v];
-          float go = ca[j][v] * g[j].v[v];
-          if (mode == 2) go = go - cb[j][v] - (act_fwd(xv, act) - mu[j][v]) * is[j][v] * cc[j][v];
+          float a_, b_ = 0.f, c_ = 0.f, m_ = 0.f, i_ = 0.f;
+          if (REGC) {
+            a_ = ca[REGC ? j : 0][REGC ? v : 0]; b_ = cb[REGC ? j : 0][REGC ? v : 0]; c_ = cc[REGC ? j : 0][REGC ? v : 0];
+            m_ = mu[REGC ? j : 0][REGC ? v : 0]; i_ = is[REGC ? j : 0][REGC ? v : 0];
+          } else if (mode != 0) {
+            a_ = pg.v[v] * pi.v[v];
+            if (mode == 2) { b_ = a_ * p0.v[v] * inv_count; c_ = a_ * p1.v[v] * inv_count; m_ = pm.v[v]; i_ = pi.v[v]; }
+          } else {
+            a_ = 1.f;
+          }
+          float go = a_ * g[j].v[v];
+          if (mode == 2) go = go - b_ - (act_fwd(xv, act) - m_) * i_ * c_;
           go *= act_bwd(xv, act);
           g[j].v[v] = go;                 // d(hn)
           dot += xv * go;
