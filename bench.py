@@ -221,6 +221,17 @@ def main():
                                                'launches_per_step': g['launches'] / args.steps,
                                                'avg_launch_ms': round(g['avg_ms'], 4),
                                                'mb_per_launch': round(bytes_per_launch / 1e6, 2)}
+        # HBM traffic per launch from the committed PMC passes of this same command (profiles/make_traffic_json.py); null if absent
+        try:
+            tr = json.load(open(os.path.join(ROOT, 'profiles', 'r01_traffic.json')))
+            if 'roofline' in out and 'gemm_128x128' in tr and args.flags == 'shipped' and args.maxn == 11404:
+                out['roofline']['traffic'] = round(tr['gemm_128x128']['hbm_bytes_per_launch'])
+                out['roofline']['traffic_source'] = 'profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes/launch)'
+            if 'roofline_aggregation' in out and 'spmm_wide' in tr and args.flags == 'shipped' and args.maxn == 11404:
+                out['roofline_aggregation']['traffic'] = round(tr['spmm_wide']['hbm_bytes_per_launch'])
+                out['roofline_aggregation']['traffic_source'] = 'profiles/r01_traffic.json'
+        except (OSError, ValueError, KeyError):
+            pass
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args, cpu_batches)
         print(json.dumps(out), flush=True)
