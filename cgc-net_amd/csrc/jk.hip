@@ -103,11 +103,13 @@ __global__ __launch_bounds__(JK_THREADS) void k_jk_fwd(const float* __restrict__
         acc.x = fmaf(q.x, xt[k], acc.x); acc.y = fmaf(q.y, xt[k], acc.y);
         acc.z = fmaf(q.z, xt[k], acc.z); acc.w = fmaf(q.w, xt[k], acc.w);
       }
+      if (s > 0) {          // first step of a direction: h_prev = 0, the recurrent 3/5 of the dot product vanishes
 #pragma unroll
-      for (int k = 0; k < H; ++k) {
-        const float4 q = wj[C + k];
-        acc.x = fmaf(q.x, hprev[k], acc.x); acc.y = fmaf(q.y, hprev[k], acc.y);
-        acc.z = fmaf(q.z, hprev[k], acc.z); acc.w = fmaf(q.w, hprev[k], acc.w);
+        for (int k = 0; k < H; ++k) {
+          const float4 q = wj[C + k];
+          acc.x = fmaf(q.x, hprev[k], acc.x); acc.y = fmaf(q.y, hprev[k], acc.y);
+          acc.z = fmaf(q.z, hprev[k], acc.z); acc.w = fmaf(q.w, hprev[k], acc.w);
+        }
       }
       const float gi = sigmoidf_(acc.x), gf = sigmoidf_(acc.y), gg = tanhf(acc.z), go = sigmoidf_(acc.w);
       const float cprev = (s > 0 && valid) ? CS[(size_t)((d * 3 + tprev) * H + j) * npad + r] : 0.f;
@@ -242,11 +244,13 @@ __global__ __launch_bounds__(JK_THREADS) void k_jk_bwd(const float* __restrict__
         acc.x = fmaf(q.x, xt[k], acc.x); acc.y = fmaf(q.y, xt[k], acc.y);
         acc.z = fmaf(q.z, xt[k], acc.z); acc.w = fmaf(q.w, xt[k], acc.w);
       }
+      if (s > 0) {          // first step of a direction: h_prev = 0, the recurrent 3/5 of the dot product vanishes
 #pragma unroll
-      for (int k = 0; k < H; ++k) {
-        const float4 q = wj[C + k];
-        acc.x = fmaf(q.x, hprev[k], acc.x); acc.y = fmaf(q.y, hprev[k], acc.y);
-        acc.z = fmaf(q.z, hprev[k], acc.z); acc.w = fmaf(q.w, hprev[k], acc.w);
+        for (int k = 0; k < H; ++k) {
+          const float4 q = wj[C + k];
+          acc.x = fmaf(q.x, hprev[k], acc.x); acc.y = fmaf(q.y, hprev[k], acc.y);
+          acc.z = fmaf(q.z, hprev[k], acc.z); acc.w = fmaf(q.w, hprev[k], acc.w);
+        }
       }
       const float gi = sigmoidf_(acc.x), gf = sigmoidf_(acc.y), gg = tanhf(acc.z), go = sigmoidf_(acc.w);
       const size_t slot = (size_t)((d * 3 + t) * H + j) * npad + row;
@@ -272,10 +276,12 @@ __global__ __launch_bounds__(JK_THREADS) void k_jk_bwd(const float* __restrict__
         const float4 v = wj[k];
         dxt[k] += v.x * q.x + v.y * q.y + v.z * q.z + v.w * q.w;
       }
+      if (s > 0) {          // no earlier step to hand a hidden-state gradient to
 #pragma unroll
-      for (int k = 0; k < H; ++k) {
-        const float4 v = wj[C + k];
-        dhp[k] += v.x * q.x + v.y * q.y + v.z * q.z + v.w * q.w;
+        for (int k = 0; k < H; ++k) {
+          const float4 v = wj[C + k];
+          dhp[k] += v.x * q.x + v.y * q.y + v.z * q.z + v.w * q.w;
+        }
       }
     }
     if (s > 0) {

@@ -422,7 +422,7 @@ class _DenseJK(Function):
         n = xs.shape[0]
         C = xs.shape[1] // 3
         H = 3 * C // 2
-        npad = -(-max(n, 1) // 1024) * 1024            # row padding of the transposed buffers: K slices of 1536 divide 3*npad
+        npad = -(-max(n, 1) // 1024) * 1024            # row padding of the transposed buffers: K slices of 768 divide 3*npad
         dev = xs.device
         lstm = [_f32c(p) for p in lstm]
         w_att, b_att = _f32c(w_att), _f32c(b_att)
@@ -446,8 +446,9 @@ class _DenseJK(Function):
         INT = torch.empty(2, ni, ktot, dtype=torch.float32, device=dev)
         DHC = torch.empty(2, 2, H, npad, dtype=torch.float32, device=dev)
         K().jk_bwd(xs, _f32c(dout), n, npad, C, lstm, w_att, b_att, HS, CS, dxs, DGT, INT, DHC)
-        # parameter gradients: G_d = DGT[d] @ INT[d]^T, reduced over K slices of 1536 columns (deterministic combine)
-        kp = 1536
+        # parameter gradients: G_d = DGT[d] @ INT[d]^T, reduced over K slices of 768 columns (deterministic combine);
+        # 768 divides 3*npad and gives >= 2 x 225 workgroups at C3 sizes
+        kp = 768
         parts = ktot // kp
         G = torch.empty(2, ng * ni, dtype=torch.float32, device=dev)
         ws = torch.empty(parts, ng * ni, dtype=torch.float32, device=dev)
