@@ -108,6 +108,111 @@ __global__ __launch_bounds__(256) void k_spmm(const int* __restrict__ rowptr, co
   }
 }
 
+// Wide rows (> 32 sixteen-byte chunks, "K4"): one WAVE owns (row, 1 KiB column tile), so everything about the sparsity
+// pattern is wave-uniform.  Row extents, neighbour ids and edge weights are fetched with SCALAR loads into SGPRs (no lane
+// staging, no ds_bpermute shuffles; each gather is one global_load_dwordx4 off a scalar row base), U gathers are in
+// flight before the first FMA.  Workgroups are short (4 waves x RUN rows) and dispatched in (graph, column tile, row)
+// order on XCD-contiguous ids, so the rows in flight on one XCD stay inside ONE (graph, column tile) slab
+// (1800 rows x 1 KiB = 1.8 MB) and the ~9x re-read of neighbour rows is served by that XCD's 4 MiB L2.  (A persistent,
+// strided schedule with index prefetch was measured 1.5-1.9x slower: waves drift apart and several slabs compete for L2.)
+typedef float wide_f4 __attribute__((ext_vector_type(4)));
+
+// CNT neighbour rows of one (row, column tile): ids and weights through the scalar unit, CNT gathers in flight, then FMAs.
+template <int CNT, bool VAL, bool PERM, bool PRE>
+__device__ __forceinline__ void wide_batch(const int* __restrict__ col, const int* __restrict__ perm,
+                                           const float* __restrict__ val, const float* __restrict__ pre,
+                                           const float* __restrict__ xl, int W, int k, wide_f4& acc) {
+  int cc[CNT];
+  wide_f4 xv[CNT];
+  float ww[CNT];
+#pragma unroll
+  for (int u = 0; u < CNT; ++u) cc[u] = col[k + u];
+#pragma unroll
+  for (int u = 0; u < CNT; ++u) xv[u] = *reinterpret_cast<const wide_f4*>(xl + (size_t)cc[u] * W);   // (nt loads: 2.1x slower, they skip L2)
+#pragma unroll
+  for (int u = 0; u < CNT; ++u) ww[u] = 1.f;
+  if (VAL) {
+    int pi[CNT];
+#pragma unroll
+    for (int u = 0; u < CNT; ++u) pi[u] = PERM ? perm[k + u] : k + u;
+#pragma unroll
+    for (int u = 0; u < CNT; ++u) ww[u] = val[pi[u]];
+  }
+  if (PRE) {
+    float pr[CNT];
+#pragma unroll
+    for (int u = 0; u < CNT; ++u) pr[u] = pre[cc[u]];
+#pragma unroll
+    for (int u = 0; u < CNT; ++u) ww[u] *= pr[u];
+  }
+#pragma unroll
+  for (int u = 0; u < CNT; ++u) acc += ww[u] * xv[u];
+}
+
+template <int U, bool VAL, bool PERM, bool PRE>
+__global__ __launch_bounds__(256) void k_spmm_wide(const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                   const int* __restrict__ perm, const float* __restrict__ val,
+                                                   const float* __restrict__ pre, const float* __restrict__ post,
+                                                   const float* __restrict__ x, float* __restrict__ out, int n, int W,
+                                                   int n_ctiles, int run, int blocks_per_ct, int n_chunks,
+                                                   const int* __restrict__ gptr, int order) {
+  typedef float f4v __attribute__((ext_vector_type(4)));
+  const int nb = gridDim.x, b = blockIdx.x;
+  const int vb = (nb % 8 == 0) ? (b % 8) * (nb / 8) + b / 8 : b;
+  const int per_chunk = blocks_per_ct * n_ctiles;
+  const int chunk = vb / per_chunk;
+  if (chunk >= n_chunks) return;
+  const int rem = vb - chunk * per_chunk;
+  const int ct = rem / blocks_per_ct, rb = rem - ct * blocks_per_ct;
+  const int rows_per_block = 4 * run;
+  int row0, row_end;
+  if (gptr != nullptr) {
+    // Graph visited by this dispatch slot.  order=1: the producer of x wrote the graphs in ascending order, so the LAST
+    // ones are what the 256 MB Infinity Cache still holds -- the 8 XCDs start together on the last 8 graphs and walk down.
+    int gi = chunk;
+    if (order) {
+      const int per_x = n_chunks >> 3;
+      gi = ((n_chunks & 7) == 0 && (nb & 7) == 0) ? (per_x - 1 - chunk % per_x) * 8 + chunk / per_x : n_chunks - 1 - chunk;
+    }
+    const int g0 = gptr[gi], g1 = gptr[gi + 1];
+    row0 = g0 + rb * rows_per_block;
+    row_end = min(row0 + rows_per_block, g1);
+  } else {
+    row0 = (chunk * blocks_per_ct + rb) * rows_per_block;
+    row_end = min(row0 + rows_per_block, n);
+  }
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c0 = (ct * 64 + lane) * 4;
+  if (c0 >= W) return;                       // lanes past the row end (last column tile) retire; indices stay scalar
+  const float* __restrict__ xl = x + c0;
+  int r = row0 + wave * run;
+  const int r_end = min(r + run, row_end);
+  if (r >= r_end) return;
+  int s = rowptr[r];
+  for (; r < r_end; ++r) {
+    const int e = rowptr[r + 1];
+    f4v acc = {0.f, 0.f, 0.f, 0.f};
+    int k = s;
+    static_assert(U == 9, "the tail switch below enumerates 1..U-1");
+    for (; k + U <= e; k += U) wide_batch<U, VAL, PERM, PRE>(col, perm, val, pre, xl, W, k, acc);
+    switch (e - k) {                         // row tail (wave-uniform): exactly as many gathers as entries left
+      case 1: wide_batch<1, VAL, PERM, PRE>(col, perm, val, pre, xl, W, k, acc); break;
+      case 2: wide_batch<2, VAL, PERM, PRE>(col, perm, val, pre, xl, W, k, acc); break;
+      case 3: wide_batch<3, VAL, PERM, PRE>(col, perm, val, pre, xl, W, k, acc); break;
+      case 4: wide_batch<4, VAL, PERM, PRE>(col, perm, val, pre, xl, W, k, acc); break;
+      case 5: wide_batch<5, VAL, PERM, PRE>(col, perm, val, pre, xl, W, k, acc); break;
+      case 6: wide_batch<6, VAL, PERM, PRE>(col, perm, val, pre, xl, W, k, acc); break;
+      case 7: wide_batch<7, VAL, PERM, PRE>(col, perm, val, pre, xl, W, k, acc); break;
+      case 8: wide_batch<8, VAL, PERM, PRE>(col, perm, val, pre, xl, W, k, acc); break;
+      default: break;
+    }
+    if (post != nullptr) acc *= post[r];
+    __builtin_nontemporal_store(acc, reinterpret_cast<f4v*>(out + (size_t)r * W + c0));
+    s = e;
+  }
+}
+
 // tuning knobs (read once from the environment; defaults are the measured best for ~1800-node cell graphs)
 static int knob(const char* name, int dflt) {
   const char* v = getenv(name);
@@ -134,6 +239,32 @@ static int launch_gather(const int* rowptr, const int* col, const int* perm, con
     const int chunk_rows = ceil_div(k_chunk, rows_per_block) * rows_per_block;
     blocks_per_ct = chunk_rows / rows_per_block;
     n_chunks = ceil_div(n, chunk_rows);
+  }
+  static const int k_wide = knob("CGC_SPMM_WIDE", 1), k_run = knob("CGC_SPMM_RUN", 2);
+  static const int k_order = knob("CGC_SPMM_ORDER", 1);
+  if (k_wide && vec && lpr == 64) {                   // wave-per-row: scalar index path
+    const int rpb = 4 * k_run;
+    if (gptr != nullptr) {
+      blocks_per_ct = ceil_div(nmax, rpb);
+    } else {
+      const int chunk_rows = ceil_div(k_chunk, rpb) * rpb;
+      blocks_per_ct = chunk_rows / rpb;
+      n_chunks = ceil_div(n, chunk_rows);
+    }
+    const int nbw = ceil_div(n_chunks * blocks_per_ct * n_ctiles, 8) * 8;
+#define WIDE_LAUNCH(V, P, Q)                                                                                              \
+  hipLaunchKernelGGL((k_spmm_wide<GATHER_U, V, P, Q>), dim3(nbw), dim3(CGC_BLOCK), 0, stream, rowptr, col, perm, val, pre, \
+                     post, x, out, n, width, n_ctiles, k_run, blocks_per_ct, n_chunks, gptr, k_order)
+    const bool hv = val != nullptr, hp = hv && perm != nullptr, hq = pre != nullptr;
+    if (!hv && !hq) WIDE_LAUNCH(false, false, false);
+    else if (!hv) WIDE_LAUNCH(false, false, true);
+    else if (!hp && !hq) WIDE_LAUNCH(true, false, false);
+    else if (!hp) WIDE_LAUNCH(true, false, true);
+    else if (!hq) WIDE_LAUNCH(true, true, false);
+    else WIDE_LAUNCH(true, true, true);
+#undef WIDE_LAUNCH
+    CGC_RETURN_IF_LAUNCH_FAILED();
+    return 0;
   }
   int nb = n_chunks * blocks_per_ct * n_ctiles;
   nb = ceil_div(nb, 8) * 8;

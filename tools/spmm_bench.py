@@ -37,7 +37,18 @@ for W in widths:
         e.record()
         torch.cuda.synchronize()
         ms = s.elapsed_time(e) / 10
+        # in-step conditions: x has just been written by its producer (a row softmax), only the SpMM is timed
+        src, tt = torch.randn(n, W, device=dev), []
+        for _ in range(8):
+            torch.softmax(src, -1, out=x)
+            s.record()
+            fn()
+            e.record()
+            torch.cuda.synchronize()
+            tt.append(s.elapsed_time(e))
+        after = sorted(tt[2:])[len(tt[2:]) // 2]
         by = 8.0 * n * W + 4.0 * (n + 1) + 4.0 * nnz
-        print('%-6s n=%d nnz=%d W=%5d  %8.1f us  %7.1f GB/s algorithmic (%.1f%% of 8 TB/s)  [env %s]' % (
-            name, n, nnz, W, ms * 1e3, by / ms / 1e6, by / ms / 1e6 / 80.0,
+        print('%-6s n=%d nnz=%d W=%5d  %8.1f us  %7.1f GB/s algorithmic (%.1f%% of 8 TB/s); right after its producer '
+              '%.1f us (%.1f%%)  [env %s]' % (
+            name, n, nnz, W, ms * 1e3, by / ms / 1e6, by / ms / 1e6 / 80.0, after * 1e3, by / after / 1e6 / 80.0,
             {k: v for k, v in os.environ.items() if k.startswith('CGC_SPMM')}))
