@@ -215,7 +215,7 @@ def main():
                 idx = 4.0 * (nodes + 1) + (8.0 if args.flags == 'shipped' else 4.0) * (edges + (nodes if args.flags == 'shipped' else 0))
                 bytes_per_launch = g['work_per_launch'] + idx
                 gbs = bytes_per_launch / (g['avg_ms'] * 1e-3) / 1e9
-                out['roofline_aggregation'] = {'kernel': 'k_spmm (A*S and its transpose, width %d)' % c1, 'bound': 'hbm',
+                out['roofline_aggregation'] = {'kernel': 'k_spmm_wide<9,*> (A*S and its transpose, width %d)' % c1, 'bound': 'hbm',
                                                'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                                'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': None,
                                                'launches_per_step': g['launches'] / args.steps,

@@ -167,12 +167,17 @@ __global__ __launch_bounds__(256) void k_spmm_wide(const int* __restrict__ rowpt
   const int rows_per_block = 4 * run;
   int row0, row_end;
   if (gptr != nullptr) {
-    // Graph visited by this dispatch slot.  order=1: the producer of x wrote the graphs in ascending order, so the LAST
-    // ones are what the 256 MB Infinity Cache still holds -- the 8 XCDs start together on the last 8 graphs and walk down.
+    // Graph visited by this dispatch slot (a hint about what the 256 MB Infinity Cache still holds of x, which was just
+    // written by the previous kernel).  1: x was written in ascending row order (row kernels) -- the 8 XCDs start together
+    // on the last 8 graphs and walk down.  2: x was written by a batched GEMM whose XCD-contiguous tile order left the tail
+    // of every eighth of the batch in cache -- every XCD walks its own eighth backwards.  0: ascending.
     int gi = chunk;
-    if (order) {
+    if (order == 1) {
       const int per_x = n_chunks >> 3;
       gi = ((n_chunks & 7) == 0 && (nb & 7) == 0) ? (per_x - 1 - chunk % per_x) * 8 + chunk / per_x : n_chunks - 1 - chunk;
+    } else if (order == 2) {
+      const int per_x = n_chunks >> 3;
+      gi = ((n_chunks & 7) == 0 && (nb & 7) == 0) ? (chunk / per_x) * per_x + (per_x - 1 - chunk % per_x) : n_chunks - 1 - chunk;
     }
     const int g0 = gptr[gi], g1 = gptr[gi + 1];
     row0 = g0 + rb * rows_per_block;
@@ -220,7 +225,8 @@ static int knob(const char* name, int dflt) {
 }
 
 static int launch_gather(const int* rowptr, const int* col, const int* perm, const float* val, const float* pre, const float* post,
-                         const float* x, float* out, int n, int width, const int* gptr, int B, int nmax, hipStream_t stream) {
+                         const float* x, float* out, int n, int width, const int* gptr, int B, int nmax, int visit,
+                         hipStream_t stream) {
   static const int k_passes = knob("CGC_SPMM_PASSES", 2), k_chunk = knob("CGC_SPMM_CHUNK", 2048);
   static const int k_nt = knob("CGC_SPMM_NT", 1), k_lds = knob("CGC_SPMM_LDS", 0), k_lpr = knob("CGC_SPMM_LPR", 64);
   const bool vec = (width % 4 == 0) && aligned16(x) && aligned16(out);
@@ -241,7 +247,8 @@ static int launch_gather(const int* rowptr, const int* col, const int* perm, con
     n_chunks = ceil_div(n, chunk_rows);
   }
   static const int k_wide = knob("CGC_SPMM_WIDE", 1), k_run = knob("CGC_SPMM_RUN", 2);
-  static const int k_order = knob("CGC_SPMM_ORDER", 1);
+  static const int k_order = knob("CGC_SPMM_ORDER", -1);      // >= 0 overrides the caller's visiting-order hint
+  const int order = k_order >= 0 ? k_order : visit;
   if (k_wide && vec && lpr == 64) {                   // wave-per-row: scalar index path
     const int rpb = 4 * k_run;
     if (gptr != nullptr) {
@@ -254,7 +261,7 @@ static int launch_gather(const int* rowptr, const int* col, const int* perm, con
     const int nbw = ceil_div(n_chunks * blocks_per_ct * n_ctiles, 8) * 8;
 #define WIDE_LAUNCH(V, P, Q)                                                                                              \
   hipLaunchKernelGGL((k_spmm_wide<GATHER_U, V, P, Q>), dim3(nbw), dim3(CGC_BLOCK), 0, stream, rowptr, col, perm, val, pre, \
-                     post, x, out, n, width, n_ctiles, k_run, blocks_per_ct, n_chunks, gptr, k_order)
+                     post, x, out, n, width, n_ctiles, k_run, blocks_per_ct, n_chunks, gptr, order)
     const bool hv = val != nullptr, hp = hv && perm != nullptr, hq = pre != nullptr;
     if (!hv && !hq) WIDE_LAUNCH(false, false, false);
     else if (!hv) WIDE_LAUNCH(false, false, true);
@@ -283,7 +290,7 @@ static int launch_gather(const int* rowptr, const int* col, const int* perm, con
 extern "C" int cgc_spmm(const int* rowptr, const int* col, const int* perm, const float* val, const float* pre, const float* post,
                         const float* x, float* out, int n, int width, cgc_stream_t stream) {
   if (n <= 0 || width <= 0) return 0;
-  return launch_gather(rowptr, col, perm, val, pre, post, x, out, n, width, nullptr, 0, 0, as_stream(stream));
+  return launch_gather(rowptr, col, perm, val, pre, post, x, out, n, width, nullptr, 0, 0, 0, as_stream(stream));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -389,7 +396,7 @@ static int launch_slab(const int* rowptr, const int* col, const int* perm, const
 // gather kernel.
 extern "C" int cgc_spmm_graphs(const int* rowptr, const int* col, const int* perm, const float* val, const float* pre,
                                const float* post, const float* x, float* out, int n, int width, const int* gptr, int B,
-                               int nmax, cgc_stream_t stream) {
+                               int nmax, int visit, cgc_stream_t stream) {
   if (n <= 0 || width <= 0) return 0;
   static const int k_slab = knob("CGC_SPMM_SLAB", 0);
   const size_t budget = 150 * 1024;
@@ -402,5 +409,5 @@ extern "C" int cgc_spmm_graphs(const int* rowptr, const int* col, const int* per
     if ((size_t)nmax * 4 * 4 <= budget) return k_thr >= 1024 ? launch_slab<4, 1024>(SLAB_ARGS) : launch_slab<4, 512>(SLAB_ARGS);
 #undef SLAB_ARGS
   }
-  return launch_gather(rowptr, col, perm, val, pre, post, x, out, n, width, gptr, B, nmax, as_stream(stream));
+  return launch_gather(rowptr, col, perm, val, pre, post, x, out, n, width, gptr, B, nmax, visit, as_stream(stream));
 }

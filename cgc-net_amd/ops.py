@@ -484,7 +484,7 @@ class _DiffPoolSparse(Function):
         c = s.shape[1]
         dev = s.device
         p = torch.empty_like(s)                                   # P = A S   (K4, wide SpMM)
-        K().spmm(g.rowptr, g.col, None, g.val, None, None, s, p, n, c, g.gptr, g.B, g.nmax)
+        K().spmm(g.rowptr, g.col, None, g.val, None, None, s, p, n, c, g.gptr, g.B, g.nmax, 1)     # S: fresh from the row softmax
         xo = torch.empty(g.B, c, dx, dtype=torch.float32, device=dev)
         ao = torch.empty(g.B, c, c, dtype=torch.float32, device=dev)
         # ragged-K, transposed-A contractions: per graph  [c x N_b] . [N_b x (dx | c)]
@@ -507,7 +507,7 @@ class _DiffPoolSparse(Function):
         # dS = A^T dP  (transpose SpMM) + P dA'^T + X dX'^T
         ds = torch.empty_like(s)
         K().spmm(g.t_rowptr, g.t_col, g.t_perm if g.val is not None else None, g.val, None, None, dp, ds, n, c,
-                 g.gptr, g.B, g.nmax)
+                 g.gptr, g.B, g.nmax, 2)                                                             # dP: fresh from the gemm
         # ... both products in one launch: [P | X] [dA' | dX']^T, the K = dx segment rides on the K = c product
         K().gemm(p, dao, ds, 0, c, c, False, True, c, c, c, 1.0, 1.0, None, g.B, 0, c * c, 0, g.gptr, 1, g.nmax, n,
                  extra=[(embed, dxo, dx, dx, dx, 0, c * dx)])

@@ -57,10 +57,13 @@ int cgc_spmm(const int* rowptr, const int* col, const int* perm, const float* va
              const float* post, const float* x, float* out, int n, int width, cgc_stream_t stream);
 
 /* Same contract when the rows are a batch of graphs (block-diagonal adjacency): gptr[B+1] = first row of each graph,
- * nmax = largest graph.  Lets wide rows use the LDS graph-slab kernel (each X element is read from HBM once). */
+ * nmax = largest graph.  Wide rows are then swept one (graph, 1 KiB column tile) slab at a time per XCD so that the ~9x
+ * re-read of neighbour rows is served by that XCD's L2.  visit = scheduling hint only (results identical): which graphs
+ * of x the previous kernel left in the Infinity Cache -- 0 unknown / ascending, 1 x was written in ascending row order,
+ * 2 x was written by cgc_gemm_f32 as a ragged batch. */
 int cgc_spmm_graphs(const int* rowptr, const int* col, const int* perm, const float* val, const float* pre,
                     const float* post, const float* x, float* out, int n, int width, const int* gptr, int B, int nmax,
-                    cgc_stream_t stream);
+                    int visit, cgc_stream_t stream);
 
 /* ---- A4/A5/A8: dense contractions on fp32 MFMA (v_mfma_f32_32x32x2_f32).  Replaces torch.matmul / nn.Linear at
  * model/network.py:122 (assignment Linear), :206-207 (S^T X, S^T A S), and the level-2/3 adj@x.

@@ -20,7 +20,7 @@ def per_kernel(d, counter):
 def main():
     f, w = per_kernel(sys.argv[1], 'FETCH_SIZE'), per_kernel(sys.argv[2], 'WRITE_SIZE')
     out = {}
-    for tag, match, big_only in (('gemm_128x128', 'k_gemm_f32<2, 2, 2, 2', False), ('spmm_wide', 'k_spmm<4>', True)):
+    for tag, match, big_only in (('gemm_128x128', 'k_gemm_f32<2, 2, 2, 2', False), ('spmm_wide', 'k_spmm_wide<', True)):
         fs = [v for k in f if k.startswith(match) for v in f[k]]
         ws = [v for k in w if k.startswith(match) for v in w[k]]
         if big_only:      # the wide (cluster-count) launches are the ones moving > 100 MB

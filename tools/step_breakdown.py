@@ -37,7 +37,7 @@ def wrap(name):
             ragged = a[19] if len(a) > 19 else kw.get('ragged', 0)
             tag = 'gemm %s%s M=%d N=%d K=%d b=%d r=%d' % ('T' if tA else 'N', 'T' if tB else 'N', M, N, Kd, batch, ragged)
         elif name == 'spmm':
-            tag = 'spmm W=%d' % a[9]
+            tag = 'spmm W=%d #%d' % (a[9], sum(1 for r_ in records if r_[0].startswith('spmm W=%d ' % a[9])))
         elif name in ('l2norm_act_stats', 'bn_act_apply', 'bn_bwd_reduce', 'bn_act_l2_bwd', 'colsum', 'softmax_fwd', 'softmax_bwd'):
             dims = [x for x in a if isinstance(x, int)][:3]
             tag = '%s %s' % (name, dims)
