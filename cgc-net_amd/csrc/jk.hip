@@ -9,25 +9,9 @@
 // recomputes the gate activations, back-propagates through time in registers, and writes the gate gradients and the cell
 // inputs TRANSPOSED ([4H+1][3*npad], [C+2H+1][3*npad]) so that every weight / bias / attention gradient falls out of one
 // batched NT GEMM per direction (cgc_gemm_f32) followed by the deterministic slice reduction.
-#include "common.hpp"
+#include <stdlib.h>
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
-
-template <int C>
-struct JkDims {
-  static constexpr int H = 3 * C / 2;
-  static constexpr int KIN = C + H;
-  static constexpr size_t lds_bytes = sizeof(float4) * (2 * H * KIN + 2 * H) + sizeof(float) * (2 * H + 4);
-};
-
-struct JkWeights {            // PyTorch nn.LSTM layout, gate order i,f,g,o; [0] forward direction, [1] reverse
-  const float* w_ih[2];       // [4H, C]
-  const float* w_hh[2];       // [4H, H]
-  const float* b_ih[2];       // [4H]
-  const float* b_hh[2];       // [4H]
-  const float* w_att;         // [2H]
-  const float* b_att;         // [1]
-};
+#include "jk.hpp"
 
 template <int C>
 __device__ __forceinline__ void jk_fill_lds(const JkWeights& w, float4* Wt, float4* B4, float* watt, int nthreads) {
@@ -338,6 +322,11 @@ extern "C" int cgc_jk_lstm_fwd(const float* xs, int n, int npad, int C, const fl
   if (npad < n) return CGC_EINVAL;
   JkWeights w;
   fill_weights(w, lstm, w_att, b_att);
+  static const int k_mfma = getenv("CGC_JK_MFMA") != nullptr ? atoi(getenv("CGC_JK_MFMA")) : 1;
+  if (k_mfma) {
+    const int rc = jk_mfma_fwd(xs, n, npad, C, w, out, HS, CS, as_stream(stream));
+    if (rc != CGC_EINVAL) return rc;          // unaligned buffers: the thread-per-direction kernel takes any alignment
+  }
   switch (C) {
     case 8: return launch_jk_fwd<8>(xs, n, npad, w, out, HS, CS, as_stream(stream));
     case 16: return launch_jk_fwd<16>(xs, n, npad, w, out, HS, CS, as_stream(stream));
@@ -353,6 +342,11 @@ extern "C" int cgc_jk_lstm_bwd(const float* xs, const float* dout, int n, int np
   if (npad < n) return CGC_EINVAL;
   JkWeights w;
   fill_weights(w, lstm, w_att, b_att);
+  static const int k_mfma = getenv("CGC_JK_MFMA") != nullptr ? atoi(getenv("CGC_JK_MFMA")) : 1;
+  if (k_mfma) {
+    const int rc = jk_mfma_bwd(xs, dout, n, npad, C, w, HS, CS, dxs, DGT, INT, as_stream(stream));
+    if (rc != CGC_EINVAL) return rc;
+  }
   switch (C) {
     case 8: return launch_jk_bwd<8>(xs, dout, n, npad, w, HS, CS, dxs, DGT, INT, DHC, as_stream(stream));
     case 16: return launch_jk_bwd<16>(xs, dout, n, npad, w, HS, CS, dxs, DGT, INT, DHC, as_stream(stream));

@@ -1,0 +1,506 @@
+// DenseJK (model/network.py:11-55) on the matrix cores.
+//
+// The bidirectional LSTM over a node's three layer embeddings is, per step, gates[4H] = W [4H x (C+H)] . [x_t | h_{t-1}].
+// One WAVE owns 32 nodes and one direction and computes the TRANSPOSED product  gates^T[(g,j) x node] = W . [x|h]^T  with
+// v_mfma_f32_32x32x2_f32: the M dimension is (gate g = one 32-row tile each, hidden unit j), the N dimension is the 32
+// nodes, K runs over the inputs.  In the accumulator layout of that instruction a lane holds ONE node (column = lane&31)
+// and, in its 16 registers, the units j = (r&3) + 8(r>>2) + 4(lane>>5) -- all four gates of a (node, unit) pair sit in the
+// same lane and register index, so the LSTM cell is plain per-register arithmetic, and the new hidden state h_t[r] is
+// ALREADY the B operand (k = 8q + 4(lane>>5) + t  <->  r = 4q + t) of the next step's recurrent product: the recurrence
+// never leaves the registers.  x_t fragments are 16-byte global loads with the same k permutation; the weights (A operand,
+// row = unit) are staged once per workgroup in LDS in fragment order and read back as conflict-free ds_read_b128.
+// fp32 MFMA keeps the exact fp32 FMA chain (1e-4 parity budget); the thread-per-direction kernels in jk.hip ran at ~7 %
+// of the fp32 peak (1 wave/SIMD, LDS-broadcast bound), these run the same arithmetic at matrix-core rate.
+#include "jk.hpp"
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+#ifndef JKM_WAVES
+#define JKM_WAVES 2      // workgroups per CU the register allocation aims for (2 x 57 KB of LDS)
+#endif
+#ifndef JKB_TILES
+#define JKB_TILES 2          // node tiles per backward workgroup (x 2 directions = 4 waves, one per SIMD; 4 tiles = 2 waves per
+                             // SIMD under a 256-register cap measured 10-100 % slower: spills and coarser work units)
+#endif
+#define JKB_THREADS (JKB_TILES * 128)
+
+template <int C>
+struct JkM {
+  static constexpr int H = 3 * C / 2;
+  static constexpr int XG = (C + 7) / 8;      // 8-wide k groups of the x part (zero padded)
+  static constexpr int HG = (H + 7) / 8;      // ... of the recurrent part
+  static constexpr int NQ = XG + HG;
+  static constexpr int W_FLOATS = 2 * 4 * NQ * 32 * 8;        // [d][g][q][unit 32][lane half 2][t 4]
+  static constexpr int B_OFF = W_FLOATS;                       // bias  [d][g][32]
+  static constexpr int A_OFF = B_OFF + 2 * 4 * 32;             // w_att [d][32], then b_att
+  static constexpr int S_OFF = A_OFF + 2 * 32 + 4;             // score exchange [node half 2][d 2][t 3][32]
+  static constexpr int TOTAL = S_OFF + 2 * 2 * 3 * 32;
+  static constexpr size_t lds_bytes = sizeof(float) * TOTAL;
+  static_assert(H <= 32 && C % 4 == 0, "one 32-row tile per gate; 16-byte x fragments");
+};
+
+__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 2.f * __frcp_rn(1.f + __expf(-2.f * x)) - 1.f; }
+
+template <int C>
+__device__ __forceinline__ void jkm_fill(const JkWeights& w, float* lds, int nthreads) {
+  using M = JkM<C>;
+  constexpr int H = M::H, XG = M::XG, NQ = M::NQ;
+  // 256 threads = one (d, g, q) block of 32 units x 2 lane halves x 4 k per pass: (unit, half, k) are fixed per thread and
+  // (d, g, q) are compile-time per pass, so the 8*NQ global loads of a thread are independent and issue back to back
+  {
+    const int tt = threadIdx.x & 3, lhi = (threadIdx.x >> 2) & 1, j = (threadIdx.x >> 3) & 31;
+    float v[2 * 4 * NQ];
+#pragma unroll
+    for (int it = 0; it < 2 * 4 * NQ; ++it) {
+      const int q = it % NQ, g = (it / NQ) & 3, d = it / (4 * NQ);
+      v[it] = 0.f;
+      if (q < XG) {
+        const int k = 8 * q + 4 * lhi + tt;
+        if (j < H && k < C) v[it] = w.w_ih[d][(g * H + j) * C + k];
+      } else {
+        const int k = 8 * (q - XG) + 4 * lhi + tt;
+        if (j < H && k < H) v[it] = w.w_hh[d][(g * H + j) * H + k];
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < 2 * 4 * NQ; ++it) lds[it * 256 + threadIdx.x] = v[it];
+  }
+  for (int idx = threadIdx.x; idx < 2 * 4 * 32; idx += nthreads) {
+    const int j = idx & 31, g = (idx >> 5) & 3, d = idx >> 7;
+    lds[M::B_OFF + idx] = j < H ? w.b_ih[d][g * H + j] + w.b_hh[d][g * H + j] : 0.f;
+  }
+  for (int idx = threadIdx.x; idx < 2 * 32; idx += nthreads) {
+    const int j = idx & 31, d = idx >> 5;
+    lds[M::A_OFF + idx] = j < H ? w.w_att[d * H + j] : 0.f;
+  }
+  if (threadIdx.x == 0) lds[M::A_OFF + 64] = w.b_att[0];
+}
+
+template <int C>
+__global__ __launch_bounds__(256, JKM_WAVES) void k_jk_fwd_mfma(const float* __restrict__ xs, int n, int npad, const JkWeights w,
+                                                     float* __restrict__ out, float* __restrict__ HS, float* __restrict__ CS) {
+  using M = JkM<C>;
+  constexpr int H = M::H, XG = M::XG, HG = M::HG, NQ = M::NQ;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  jkm_fill<C>(w, lds, 256);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, l31 = lane & 31, lhi = lane >> 5;
+  const int wave = threadIdx.x >> 6, d = wave & 1, half = wave >> 1;
+  const float4* Wl = reinterpret_cast<const float4*>(lds) + (size_t)d * 4 * NQ * 64 + l31 * 2 + lhi;   // + (g*NQ + q)*64
+  const float* Bl = lds + M::B_OFF + d * 128 + 4 * lhi;          // + g*32 + 8q'
+  const float* Al = lds + M::A_OFF + d * 32 + 4 * lhi;           // + 8q'
+  float* Sx = lds + M::S_OFF + half * 192;                       // [d][t][32]
+  const int ntiles = (n + 31) / 32;
+
+  for (int base = blockIdx.x * 2; base < ntiles; base += gridDim.x * 2) {
+    const int node = (base + half) * 32 + l31;
+    const bool valid = node < n, keep = node < npad && base + half < ntiles;
+    const float* xrow = xs + (size_t)(valid ? node : 0) * 3 * C + 4 * lhi;
+    floatx16 cst, hst;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { cst[r] = 0.f; hst[r] = 0.f; }
+
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      const int t = d ? 2 - s : s;
+      floatx16 acc[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 b = *reinterpret_cast<const float4*>(Bl + g * 32 + 8 * q);
+          acc[g][4 * q + 0] = b.x; acc[g][4 * q + 1] = b.y; acc[g][4 * q + 2] = b.z; acc[g][4 * q + 3] = b.w;
+        }
+      // input part: B operand = x_t fragment of this lane's node
+#pragma unroll
+      for (int q = 0; q < XG; ++q) {
+        float4 xf = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid && (8 * q + 4 * lhi < C)) xf = *reinterpret_cast<const float4*>(xrow + t * C + 8 * q);
+        float4 a[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) a[g] = Wl[(g * NQ + q) * 64];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].x, xf.x, acc[g], 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].y, xf.y, acc[g], 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].z, xf.z, acc[g], 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].w, xf.w, acc[g], 0, 0, 0);
+      }
+      // recurrent part: B operand = h_{t-1}, straight from the registers the previous step left it in (zero at s = 0)
+      if (s > 0) {
+#pragma unroll
+        for (int q = 0; q < HG; ++q) {
+          float4 a[4];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) a[g] = Wl[(g * NQ + XG + q) * 64];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].x, hst[4 * q + 0], acc[g], 0, 0, 0);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].y, hst[4 * q + 1], acc[g], 0, 0, 0);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].z, hst[4 * q + 2], acc[g], 0, 0, 0);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].w, hst[4 * q + 3], acc[g], 0, 0, 0);
+        }
+      }
+      // LSTM cell, register by register (unit j = (r&3) + 8(r>>2) + 4*lhi of this lane's node)
+      float p = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 wa = *reinterpret_cast<const float4*>(Al + 8 * q);
+        const float was[4] = {wa.x, wa.y, wa.z, wa.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int r = 4 * q + u, j = u + 8 * q + 4 * lhi;
+          const float gi = fast_sigmoid(acc[0][r]), gf = fast_sigmoid(acc[1][r]);
+          const float gg = fast_tanh(acc[2][r]), go = fast_sigmoid(acc[3][r]);
+          const float c = gf * cst[r] + gi * gg;
+          const float h = go * fast_tanh(c);
+          cst[r] = c;
+          hst[r] = h;
+          p = fmaf(was[u], h, p);
+          if (8 * q + u < H && j < H && keep) {      // (first clause prunes whole padded groups at compile time)
+            const size_t slot = (size_t)((d * 3 + t) * H + j) * npad + node;
+            HS[slot] = h;
+            CS[slot] = c;
+          }
+        }
+      }
+      p += __shfl_xor(p, 32);
+      if (lhi == 0) Sx[(d * 3 + t) * 32 + l31] = p;
+    }
+    __syncthreads();
+    float sc[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) sc[t] = Sx[t * 32 + l31] + Sx[(3 + t) * 32 + l31] + lds[M::A_OFF + 64];
+    const float m = fmaxf(sc[0], fmaxf(sc[1], sc[2]));
+    float a3[3], den = 0.f;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) { a3[t] = __expf(sc[t] - m); den += a3[t]; }
+    const float inv = 1.f / den;
+    if (d == 0 && valid) {
+#pragma unroll
+      for (int q = 0; q < XG; ++q) {
+        if (8 * q + 4 * lhi < C) {
+          const float4 x0 = *reinterpret_cast<const float4*>(xrow + 0 * C + 8 * q);
+          const float4 x1 = *reinterpret_cast<const float4*>(xrow + 1 * C + 8 * q);
+          const float4 x2 = *reinterpret_cast<const float4*>(xrow + 2 * C + 8 * q);
+          float4 o;
+          o.x = (a3[0] * x0.x + a3[1] * x1.x + a3[2] * x2.x) * inv;
+          o.y = (a3[0] * x0.y + a3[1] * x1.y + a3[2] * x2.y) * inv;
+          o.z = (a3[0] * x0.z + a3[1] * x1.z + a3[2] * x2.z) * inv;
+          o.w = (a3[0] * x0.w + a3[1] * x1.w + a3[2] * x2.w) * inv;
+          *reinterpret_cast<float4*>(out + (size_t)node * C + 8 * q + 4 * lhi) = o;
+        }
+      }
+    }
+    __syncthreads();          // the score exchange buffer is rewritten by the next tile
+  }
+}
+
+// Backward on the matrix cores.  Same tiling (one wave = 32 nodes x one direction, lane = node).  Per recurrence step, last
+// to first: the gate pre-activations are recomputed with the forward's MFMAs (h_{t-1}, c_{t-1} come back from HS / CS as
+// coalesced loads already in operand layout), the cell backward runs per register, and the four gate-gradient tiles q_g --
+// still "lane = node, register = unit" -- are directly the B operand of  d[h_{t-1} | x_t]^T = W^T . q  (A operand = W^T,
+// read out of the SAME LDS image the forward uses, strided: 4-way bank conflicts, irrelevant next to 128 MFMAs), whose
+// accumulator layout hands dh_{t-1} to the next step in registers and dx_t as 16-byte fragments.  Gate gradients and cell
+// inputs are written transposed (DGT / INT, see jk.hip) for the parameter-gradient GEMM.
+template <int C>
+__global__ __launch_bounds__(JKB_THREADS) void k_jk_bwd_mfma(const float* __restrict__ xs, const float* __restrict__ dout, int n, int npad,
+                                                     const JkWeights w, const float* __restrict__ HS, const float* __restrict__ CS,
+                                                     float* __restrict__ dxs, float* __restrict__ DGT, float* __restrict__ INT) {
+  using M = JkM<C>;
+  constexpr int H = M::H, XG = M::XG, HG = M::HG, NQ = M::NQ;
+  constexpr int NG = 4 * H + 1, NI = C + 2 * H + 1;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  if (threadIdx.x < 256) jkm_fill<C>(w, lds, 256);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, l31 = lane & 31, lhi = lane >> 5;
+  const int wave = threadIdx.x >> 6, d = wave & 1, half = wave >> 1;          // half = node tile of this workgroup pass (0..JKB_TILES-1)
+  const float4* Wl = reinterpret_cast<const float4*>(lds) + (size_t)d * 4 * NQ * 64 + l31 * 2 + lhi;   // forward fragments
+  const float* Bl = lds + M::B_OFF + d * 128 + 4 * lhi;
+  const float* Al = lds + M::A_OFF + d * 32 + 4 * lhi;
+  float* Sx = lds + M::TOTAL + half * 192;                                                           // [d][t][32]
+  float4* Ex = reinterpret_cast<float4*>(lds + M::TOTAL + JKB_TILES * 192) + (size_t)(half * 2 + d) * 3 * XG * 64 + lane;   // + (t*XG + q)*64
+  // W^T fragments out of the forward image: row kin = l31 of the (h | x) tile, k = (g, unit)
+  const int kh = l31 < 8 * HG ? l31 : 8 * HG - 1, kx = l31 < 8 * XG ? l31 : 8 * XG - 1;
+  const float* WtH = lds + (size_t)d * 4 * NQ * 256 + (XG + kh / 8) * 256 + (kh & 7) + 32 * lhi;   // + g*NQ*256 + (8q'+tt)*8
+  const float* WtX = lds + (size_t)d * 4 * NQ * 256 + (kx / 8) * 256 + (kx & 7) + 32 * lhi;
+  const size_t ktot = (size_t)3 * npad;
+  float* dgt = DGT + (size_t)d * NG * ktot;
+  float* inT = INT + (size_t)d * NI * ktot;
+  const int ntiles = npad / 32;
+
+  for (int base = blockIdx.x * JKB_TILES; base < ntiles; base += gridDim.x * JKB_TILES) {
+    const int node = (base + half) * 32 + l31;
+    if (base * 32 >= n) {            // all tiles of this workgroup pass are padding columns: they must read as zero in the GEMM
+      for (int t = 0; t < 3; ++t) {
+        const size_t col = (size_t)t * npad + node;
+        for (int r = lhi; r < NG; r += 2) dgt[(size_t)r * ktot + col] = 0.f;
+        for (int r = lhi; r < NI; r += 2) inT[(size_t)r * ktot + col] = 0.f;
+      }
+      continue;
+    }
+    const bool valid = node < n;
+    const float* xrow = xs + (size_t)(valid ? node : 0) * 3 * C + 4 * lhi;
+
+    // ---- attention: scores from the saved hidden states (own direction; the partner wave supplies the other half)
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      float p = 0.f;
+#pragma unroll
+      for (int q = 0; q < HG; ++q) {
+        const float4 wa = *reinterpret_cast<const float4*>(Al + 8 * q);
+        const float was[4] = {wa.x, wa.y, wa.z, wa.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int j = u + 8 * q + 4 * lhi;
+          if (8 * q + u < H && j < H && valid) p = fmaf(was[u], HS[(size_t)((d * 3 + t) * H + j) * npad + node], p);
+        }
+      }
+      p += __shfl_xor(p, 32);
+      if (lhi == 0) Sx[(d * 3 + t) * 32 + l31] = p;
+    }
+    __syncthreads();
+    float a3[3], ds3[3];
+    {
+      float sc[3];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) sc[t] = Sx[t * 32 + l31] + Sx[(3 + t) * 32 + l31] + lds[M::A_OFF + 64];
+      const float m = fmaxf(sc[0], fmaxf(sc[1], sc[2]));
+      float den = 0.f;
+#pragma unroll
+      for (int t = 0; t < 3; ++t) { a3[t] = __expf(sc[t] - m); den += a3[t]; }
+      const float inv = 1.f / den;
+      float da[3] = {0.f, 0.f, 0.f}, mean = 0.f;
+#pragma unroll
+      for (int q = 0; q < XG; ++q) {
+        if (valid && (8 * q + 4 * lhi < C)) {
+          const float4 dy = *reinterpret_cast<const float4*>(dout + (size_t)node * C + 8 * q + 4 * lhi);
+#pragma unroll
+          for (int t = 0; t < 3; ++t) {
+            const float4 x = *reinterpret_cast<const float4*>(xrow + t * C + 8 * q);
+            da[t] += dy.x * x.x + dy.y * x.y + dy.z * x.z + dy.w * x.w;
+          }
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        da[t] += __shfl_xor(da[t], 32);
+        a3[t] *= inv;
+        mean = fmaf(a3[t], da[t], mean);
+      }
+#pragma unroll
+      for (int t = 0; t < 3; ++t) ds3[t] = valid ? a3[t] * (da[t] - mean) : 0.f;
+    }
+
+    floatx16 dhc, dcc;                 // recurrent carries d loss / d h_{t}, d c_{t} arriving from the later step
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dhc[r] = 0.f; dcc[r] = 0.f; }
+
+#pragma unroll
+    for (int s = 2; s >= 0; --s) {
+      const int t = d ? 2 - s : s, tprev = d ? t + 1 : t - 1;
+      const size_t col = (size_t)t * npad + node;
+      const float dst = d ? ds3[2 - s] : ds3[s];
+      float4 xt[XG];
+#pragma unroll
+      for (int q = 0; q < XG; ++q)
+        xt[q] = (valid && (8 * q + 4 * lhi < C)) ? *reinterpret_cast<const float4*>(xrow + t * C + 8 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+      floatx16 hprev, cprev;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        hprev[r] = 0.f;
+        cprev[r] = 0.f;
+        if (s > 0 && (r & 3) + 8 * (r >> 2) < H && j < H && valid) {
+          const size_t slot = (size_t)((d * 3 + tprev) * H + j) * npad + node;
+          hprev[r] = HS[slot];
+          cprev[r] = CS[slot];
+        }
+      }
+      // ---- gate pre-activations again (the forward's products)
+      floatx16 acc[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 b = *reinterpret_cast<const float4*>(Bl + g * 32 + 8 * q);
+          acc[g][4 * q + 0] = b.x; acc[g][4 * q + 1] = b.y; acc[g][4 * q + 2] = b.z; acc[g][4 * q + 3] = b.w;
+        }
+#pragma unroll
+      for (int q = 0; q < XG; ++q) {
+        float4 a[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) a[g] = Wl[(g * NQ + q) * 64];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].x, xt[q].x, acc[g], 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].y, xt[q].y, acc[g], 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].z, xt[q].z, acc[g], 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].w, xt[q].w, acc[g], 0, 0, 0);
+      }
+      if (s > 0) {
+#pragma unroll
+        for (int q = 0; q < HG; ++q) {
+          float4 a[4];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) a[g] = Wl[(g * NQ + XG + q) * 64];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].x, hprev[4 * q + 0], acc[g], 0, 0, 0);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].y, hprev[4 * q + 1], acc[g], 0, 0, 0);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].z, hprev[4 * q + 2], acc[g], 0, 0, 0);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].w, hprev[4 * q + 3], acc[g], 0, 0, 0);
+        }
+      }
+      // ---- cell backward per (node, unit); acc[g] is overwritten with d loss / d pre-activation of gate g
+      if (lhi == 0) {
+        dgt[(size_t)(4 * H) * ktot + col] = dst;
+        inT[(size_t)(C + H) * ktot + col] = 1.f;
+      }
+#pragma unroll
+      for (int q = 0; q < XG; ++q) {
+        if (8 * q + 4 * lhi < C) {
+          inT[(size_t)(8 * q + 4 * lhi + 0) * ktot + col] = xt[q].x;
+          inT[(size_t)(8 * q + 4 * lhi + 1) * ktot + col] = xt[q].y;
+          inT[(size_t)(8 * q + 4 * lhi + 2) * ktot + col] = xt[q].z;
+          inT[(size_t)(8 * q + 4 * lhi + 3) * ktot + col] = xt[q].w;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < HG; ++q) {
+        const float4 wa = *reinterpret_cast<const float4*>(Al + 8 * q);
+        const float was[4] = {wa.x, wa.y, wa.z, wa.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int r = 4 * q + u, j = u + 8 * q + 4 * lhi;
+          const float gi = fast_sigmoid(acc[0][r]), gf = fast_sigmoid(acc[1][r]);
+          const float gg = fast_tanh(acc[2][r]), go = fast_sigmoid(acc[3][r]);
+          const float c = gf * cprev[r] + gi * gg;
+          const float th = fast_tanh(c);
+          const float dh = fmaf(dst, was[u], dhc[r]);
+          const float dc = fmaf(dh * go, 1.f - th * th, dcc[r]);
+          dcc[r] = dc * gf;
+          const float qi = dc * gg * gi * (1.f - gi), qf = dc * cprev[r] * gf * (1.f - gf);
+          const float qg = dc * gi * (1.f - gg * gg), qo = dh * th * go * (1.f - go);
+          acc[0][r] = qi; acc[1][r] = qf; acc[2][r] = qg; acc[3][r] = qo;
+          if (8 * q + u < H && j < H) {
+            dgt[(size_t)(0 * H + j) * ktot + col] = qi;
+            dgt[(size_t)(1 * H + j) * ktot + col] = qf;
+            dgt[(size_t)(2 * H + j) * ktot + col] = qg;
+            dgt[(size_t)(3 * H + j) * ktot + col] = qo;
+            inT[(size_t)(C + j) * ktot + col] = hprev[r];
+            inT[(size_t)(C + H + 1 + j) * ktot + col] = go * th;
+          }
+        }
+      }
+      // ---- d[h_{t-1} | x_t]^T = W^T q : A = W^T rows (h unit | x feature) = l31, B = q straight from the registers
+      floatx16 dh2, dx2;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dh2[r] = 0.f; dx2[r] = 0.f; }
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int q = 0; q < HG; ++q) {
+          float ah[4], ax[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            ax[u] = WtX[g * NQ * 256 + (8 * q + u) * 8];
+            ah[u] = s > 0 ? WtH[g * NQ * 256 + (8 * q + u) * 8] : 0.f;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            dx2 = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[u], acc[g][4 * q + u], dx2, 0, 0, 0);
+            if (s > 0) dh2 = __builtin_amdgcn_mfma_f32_32x32x2f32(ah[u], acc[g][4 * q + u], dh2, 0, 0, 0);
+          }
+        }
+      if (s > 0) dhc = dh2;
+#pragma unroll
+      for (int q = 0; q < XG; ++q) Ex[(t * XG + q) * 64] = make_float4(dx2[4 * q + 0], dx2[4 * q + 1], dx2[4 * q + 2], dx2[4 * q + 3]);
+    }
+
+    // ---- input gradient: attention term + both directions' LSTM terms (parked in LDS per time slot)
+    __syncthreads();
+    if (d == 0 && valid) {
+      const float4* Eo = Ex + 3 * XG * 64;           // the reverse-direction wave of the same node tile
+#pragma unroll
+      for (int q = 0; q < XG; ++q) {
+        if (8 * q + 4 * lhi < C) {
+          const float4 dy = *reinterpret_cast<const float4*>(dout + (size_t)node * C + 8 * q + 4 * lhi);
+#pragma unroll
+          for (int t = 0; t < 3; ++t) {
+            const float4 p0 = Ex[(t * XG + q) * 64], p1 = Eo[(t * XG + q) * 64];
+            float4 v;
+            v.x = fmaf(a3[t], dy.x, p0.x + p1.x); v.y = fmaf(a3[t], dy.y, p0.y + p1.y);
+            v.z = fmaf(a3[t], dy.z, p0.z + p1.z); v.w = fmaf(a3[t], dy.w, p0.w + p1.w);
+            *reinterpret_cast<float4*>(dxs + (size_t)node * 3 * C + t * C + 8 * q + 4 * lhi) = v;
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int C>
+static int launch_fwd(const float* xs, int n, int npad, const JkWeights& w, float* out, float* HS, float* CS, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_jk_fwd_mfma<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)JkM<C>::lds_bytes);
+    attr_set = true;
+  }
+  const int ntiles = ceil_div(n, 32);
+  int grid = ceil_div(ntiles, 2);
+  if (grid > 512) grid = 512;                 // 2 workgroups per CU (LDS), persistent over the 64-node tile pairs
+  hipLaunchKernelGGL(k_jk_fwd_mfma<C>, dim3(grid), dim3(256), JkM<C>::lds_bytes, st, xs, n, npad, w, out, HS, CS);
+  CGC_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}
+
+int jk_mfma_fwd(const float* xs, int n, int npad, int C, const JkWeights& w, float* out, float* HS, float* CS, hipStream_t st) {
+  if ((reinterpret_cast<uintptr_t>(xs) & 15u) || (reinterpret_cast<uintptr_t>(out) & 15u)) return CGC_EINVAL;
+  switch (C) {
+    case 8: return launch_fwd<8>(xs, n, npad, w, out, HS, CS, st);
+    case 16: return launch_fwd<16>(xs, n, npad, w, out, HS, CS, st);
+    case 20: return launch_fwd<20>(xs, n, npad, w, out, HS, CS, st);
+    default: return CGC_EINVAL;
+  }
+}
+
+template <int C>
+static int launch_bwd(const float* xs, const float* dout, int n, int npad, const JkWeights& w, const float* HS, const float* CS,
+                      float* dxs, float* DGT, float* INT, hipStream_t st) {
+  const size_t lds = sizeof(float) * (JkM<C>::TOTAL + JKB_TILES * 192) + sizeof(float4) * JKB_TILES * 2 * 3 * JkM<C>::XG * 64;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_jk_bwd_mfma<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  int grid = ceil_div(npad / 32, JKB_TILES);
+  if (grid > 256) grid = 256;                 // one workgroup per CU
+  hipLaunchKernelGGL(k_jk_bwd_mfma<C>, dim3(grid), dim3(JKB_THREADS), lds, st, xs, dout, n, npad, w, HS, CS, dxs, DGT, INT);
+  CGC_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}
+
+int jk_mfma_bwd(const float* xs, const float* dout, int n, int npad, int C, const JkWeights& w, const float* HS, const float* CS,
+                float* dxs, float* DGT, float* INT, hipStream_t st) {
+  if ((reinterpret_cast<uintptr_t>(xs) & 15u) || (reinterpret_cast<uintptr_t>(dout) & 15u) || (reinterpret_cast<uintptr_t>(dxs) & 15u) ||
+      npad % (32 * JKB_TILES) != 0)
+    return CGC_EINVAL;
+  switch (C) {
+    case 8: return launch_bwd<8>(xs, dout, n, npad, w, HS, CS, dxs, DGT, INT, st);
+    case 16: return launch_bwd<16>(xs, dout, n, npad, w, HS, CS, dxs, DGT, INT, st);
+    case 20: return launch_bwd<20>(xs, dout, n, npad, w, HS, CS, dxs, DGT, INT, st);
+    default: return CGC_EINVAL;
+  }
+}
