@@ -342,14 +342,23 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const GemmArgs a) {   // 2 
       const int col = n0 + (wn * TN + j) * 32 + l31;
       if (col >= N) continue;
       const float bia = a.bias != nullptr ? a.bias[col] : 0.f;
+      if (beta != 0.f) {                     // accumulate mode: all 16 reads of the sub-tile in flight before the first write
+        float cold[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-        if (row < M) {
-          float* p = C + (size_t)row * a.ldc + col;
-          float v = alpha * acc[i][j][r] + bia;
-          if (beta != 0.f) v += beta * (*p);
-          *p = v;
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+          cold[r] = row < M ? C[(size_t)row * a.ldc + col] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+          if (row < M) C[(size_t)row * a.ldc + col] = fmaf(beta, cold[r], alpha * acc[i][j][r] + bia);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+          if (row < M) C[(size_t)row * a.ldc + col] = alpha * acc[i][j][r] + bia;
         }
       }
     }
@@ -462,14 +471,23 @@ __global__ __launch_bounds__(256, 3) void k_gemm_f32_shortk(const GemmArgs a) {
       const int col = n0 + (wn * TN + j) * 32 + l31;
       if (col >= N) continue;
       const float bia = a.bias != nullptr ? a.bias[col] : 0.f;
+      if (beta != 0.f) {                     // accumulate mode: all 16 reads of the sub-tile in flight before the first write
+        float cold[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-        if (row < M) {
-          float* p = C + (size_t)row * a.ldc + col;
-          float v = alpha * acc[i][j][r] + bia;
-          if (beta != 0.f) v += beta * (*p);
-          *p = v;
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+          cold[r] = row < M ? C[(size_t)row * a.ldc + col] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+          if (row < M) C[(size_t)row * a.ldc + col] = fmaf(beta, cold[r], alpha * acc[i][j][r] + bia);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+          if (row < M) C[(size_t)row * a.ldc + col] = alpha * acc[i][j][r] + bia;
         }
       }
     }
