@@ -6,6 +6,9 @@ P, I, F, D, L = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_int64
 PROTOTYPES = {
     'cgc_abi_version': [],
     'cgc_csr_build': [P, L, I, I, P, P, P, P, P, P, P, P],
+    'cgc_radius_knn_ws_ints': [I, I],
+    'cgc_radius_knn': [P, P, I, I, F, I, I, P, P, P, P, P],
+    'cgc_knn_emit_edges': [P, P, I, I, L, P, P],
     'cgc_edge_renorm': [P, P, I, F, P, P],
     'cgc_csr_invdeg': [P, P, I, P, P],
     'cgc_spmm': [P, P, P, P, P, P, P, P, I, I, P],
@@ -40,4 +43,4 @@ def declare(lib):
     for name, argtypes in PROTOTYPES.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
-        fn.restype = C.c_int
+        fn.restype = C.c_int64 if name.endswith('_ws_ints') else C.c_int

@@ -109,8 +109,19 @@ def radius_graph(pos, r, batch=None, loop=False, max_num_neighbors=32):
     distance_upper_bound = r + 1e-8), SURVEY B.5.  Returns int64 [2, nnz] with
     row = query / aggregating centre and col = neighbour.
     """
+    if pos.is_cuda:                     # GPU construction (csrc/knn.hip): any number of graphs per call
+        from . import kernels
+        n = pos.shape[0]
+        if batch is None:
+            gptr, B = torch.tensor([0, n], dtype=torch.int32, device=pos.device), 1
+        else:                           # ``batch`` sorted ascending, as in every PyG Batch
+            B = int(batch[-1].item()) + 1 if n > 0 else 1
+            counts = torch.bincount(batch, minlength=B)
+            gptr = torch.zeros(B + 1, dtype=torch.int32, device=pos.device)
+            gptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
+        return kernels.get().radius_knn(pos[:, :2], gptr, B, float(r), int(max_num_neighbors), bool(loop))
     if batch is not None:
-        raise NotImplementedError('per-graph construction only (as the reference calls it: batch=None)')
+        raise NotImplementedError('host path: per-graph construction only (as the reference calls it: batch=None)')
     p = pos.detach().cpu().numpy().astype(np.float64)
     tree = cKDTree(p)
     k = max_num_neighbors + 1

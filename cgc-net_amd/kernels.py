@@ -34,6 +34,13 @@ class KernelSpec(object):
         """
         raise NotImplementedError
 
+    def radius_knn(self, pos, gptr, num_graphs, r, k, loop):
+        """Cell-graph construction for a batch of graphs (torch_cluster.radius_graph(pos, r, None, loop, k) per graph,
+        dataflow/data.py:348): pos [n,2] f32, gptr int32 [B+1].  Per node its <= k nearest others within r (+ itself iff
+        loop), restricted to its own graph.  Returns edge_index int64 [2, nnz] (row = centre, ascending; neighbours by
+        distance, ties by index) with global node ids."""
+        raise NotImplementedError
+
     def edge_renorm(self, rowptr, col, n, p, val_out):
         """Level-1 ``_re_norm_adj`` (model/network.py:183-191) on a 0/1 CSR that holds its diagonal:
         val[k] = p if col[k]==row else (1/(c+1e-15))*(1-p), c = number of off-diagonal entries of the row."""
@@ -262,6 +269,24 @@ class HipKernels(KernelSpec):
         self._chk(rc, 'cgc_csr_build')
         out['cap'] = cap
         return out
+
+    def radius_knn(self, pos, gptr, num_graphs, r, k, loop):
+        self._dev(pos, gptr)
+        pos = pos.to(torch.float32).contiguous()
+        n, dev = pos.shape[0], pos.device
+        i32 = dict(dtype=torch.int32, device=dev)
+        if n == 0:
+            return torch.zeros(2, 0, dtype=torch.int64, device=dev)
+        assert pos.dim() == 2 and pos.shape[1] == 2 and gptr.dtype == torch.int32
+        nbr, cnt, rowptr = torch.empty(n, k + 1, **i32), torch.empty(n, **i32), torch.empty(n + 1, **i32)
+        ws = torch.empty(int(self.lib.cgc_radius_knn_ws_ints(n, num_graphs)), **i32)
+        self._chk(self.lib.cgc_radius_knn(_ptr(pos), _ptr(gptr), num_graphs, n, ctypes.c_float(r), k, int(bool(loop)),
+                                          _ptr(nbr), _ptr(cnt), _ptr(rowptr), _ptr(ws), self._stream()), 'cgc_radius_knn')
+        nnz = int(rowptr[n].item())                    # the one host sync of graph construction: the edge count
+        ei = torch.empty(2, nnz, dtype=torch.int64, device=dev)
+        self._chk(self.lib.cgc_knn_emit_edges(_ptr(nbr), _ptr(rowptr), n, k, ctypes.c_int64(nnz), _ptr(ei), self._stream()),
+                  'cgc_knn_emit_edges')
+        return ei
 
     def edge_renorm(self, rowptr, col, n, p, val_out):
         self._dev(rowptr, col, val_out)

@@ -41,6 +41,19 @@ int cgc_csr_build(const int64_t* edge_index, int64_t E, int n, int add_diag,
                   int* rowptr, int* col, int* rowidx, int* t_rowptr, int* t_col, int* t_perm,
                   int* ws, cgc_stream_t stream);
 
+/* ---- F2 (the step before the path): cell-graph construction.  Replaces torch_cluster.radius_graph(pos, r, None, loop,
+ * max_num_neighbors) = cKDTree.query(k+1, distance_upper_bound = r+1e-8) per graph on the host (dataflow/data.py:246,255,
+ * 297,348; dataflow/prepare_cv_dataset.py:102) for a whole batch of graphs: pos [n,2] f32, gptr [B+1] first node of each
+ * graph (a node only sees its own graph).  Per node the <= k (<= 32) nearest others within r (fp64 distances, ties by
+ * index) plus itself iff loop.  Out: nbr [n, k+1] (global node ids, by distance), cnt [n], rowptr [n+1] (exclusive scan of
+ * cnt; rowptr[n] = nnz).  ws: cgc_radius_knn_ws_ints(n, B) ints. */
+int64_t cgc_radius_knn_ws_ints(int n, int B);
+int cgc_radius_knn(const float* pos, const int* gptr, int B, int n, float r, int k, int loop, int* nbr, int* cnt, int* rowptr,
+                   int* ws, cgc_stream_t stream);
+/* ELL rows of cgc_radius_knn -> edge_index [2, nnz] int64 (row = centre, ascending; col = neighbour), the layout
+ * Batch.from_data_list / cgc_csr_build consume (dataflow/data.py:347-353). */
+int cgc_knn_emit_edges(const int* nbr, const int* rowptr, int n, int k, int64_t nnz, int64_t* edge_index, cgc_stream_t stream);
+
 /* ---- A6 (level 1): _re_norm_adj on the CSR (model/network.py:183-191): val[k] = p on the diagonal,
  * (1/(c+1e-15))*(1-p) elsewhere, c = off-diagonal entries of the row.  The CSR must hold its diagonal. */
 int cgc_edge_renorm(const int* rowptr, const int* col, int n, float p, float* val, cgc_stream_t stream);

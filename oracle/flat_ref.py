@@ -76,6 +76,29 @@ class TorchKernels(KernelSpec):
         cnt = (rowptr[1:] - rowptr[:-1]).long()
         return torch.repeat_interleave(torch.arange(n, device=rowptr.device), cnt), int(rowptr[n])
 
+    def radius_knn(self, pos, gptr, num_graphs, r, k, loop):
+        """cKDTree.query(k+1, distance_upper_bound=r+1e-8) per graph (torch_cluster 1.4.2's CPU radius_graph, SURVEY B.5;
+        call site dataflow/data.py:348), graph by graph with global node ids; neighbours by (distance, index)."""
+        import numpy as np
+        from scipy.spatial import cKDTree
+        p = pos.detach().cpu().numpy().astype(np.float64)
+        gp = gptr.cpu().numpy()
+        rows, cols = [], []
+        for g in range(num_graphs):
+            lo, hi = int(gp[g]), int(gp[g + 1])
+            if hi <= lo:
+                continue
+            q = p[lo:hi]
+            kk = min(k + 1, hi - lo)
+            d, c = cKDTree(q).query(q, k=kk, distance_upper_bound=r + 1e-8)
+            d, c = d.reshape(hi - lo, kk), c.reshape(hi - lo, kk)
+            for i in range(hi - lo):
+                cand = [(d[i, u], int(c[i, u])) for u in range(kk) if c[i, u] < hi - lo and (loop or c[i, u] != i)]
+                cand.sort()
+                rows += [lo + i] * len(cand)
+                cols += [lo + j for _, j in cand]
+        return torch.tensor([rows, cols], dtype=torch.int64).reshape(2, -1)
+
     def edge_renorm(self, rowptr, col, n, p, val_out):
         rows, nnz = self._rows(rowptr, n)
         c = col[:nnz].long()

@@ -421,3 +421,62 @@ def test_dense_jk_kernels(C, n):
     close(res['ref']['out'], want_out, 1e-5, 'twin vs torch.nn.LSTM')
     for k in res['ref']:
         close(res['hip'][k], res['ref'][k], 2e-4 if k == 'G' else 2e-5, 'jk ' + k)
+
+
+# ------------------------------------------------------------------ F2: cell-graph construction (radius k-NN)
+def _rows_as_sets(ei, n):
+    rows = [[] for _ in range(n)]
+    for r_, c_ in zip(ei[0].tolist(), ei[1].tolist()):
+        rows[r_].append(c_)
+    return rows
+
+
+@pytest.mark.parametrize('counts,side,k,loop', [([300], 700.0, 8, True), ([1800, 1500, 2100], 1800.0, 8, True),
+                                                ([257, 1, 0, 64, 5], 300.0, 8, True), ([400, 380], 900.0, 8, False),
+                                                ([500], 900.0, 16, True), ([200, 200], 4000.0, 4, True)])
+def test_radius_knn_matches_the_host_tree(counts, side, k, loop):
+    """csrc/knn.hip against cKDTree.query(k+1, r+1e-8) per graph (the reference's torch_cluster CPU path)."""
+    rng = np.random.RandomState(sum(counts) + k)
+    n = sum(counts)
+    pos = torch.from_numpy(rng.uniform(0.0, side, size=(n, 2)).astype(np.float32))
+    gptr = torch.tensor(np.cumsum([0] + counts), dtype=torch.int32)
+    want = REF.radius_knn(pos, gptr, len(counts), 100.0, k, loop)
+    got = hip().radius_knn(g(pos), g(gptr), len(counts), 100.0, k, loop).cpu()
+    assert got.dtype == torch.int64 and got.shape == want.shape
+    assert torch.equal(got[0], want[0])                              # same degree per node, rows ascending
+    # neighbour order: by distance; compare as ordered lists (random positions: no distance ties)
+    assert torch.equal(got[1], want[1])
+
+
+def test_radius_knn_degenerate_layouts():
+    """Coincident points, a single line of points, and a far-away cluster (huge bounding box) stay exact and bounded."""
+    rng = np.random.RandomState(3)
+    line = np.stack([np.linspace(0, 5.0e5, 300), np.zeros(300)], 1)
+    cluster = np.concatenate([rng.uniform(0, 200, (150, 2)), rng.uniform(0, 200, (150, 2)) + 3.0e6])
+    same = np.zeros((40, 2))
+    pos = torch.from_numpy(np.concatenate([line, cluster, same]).astype(np.float32))
+    counts = [300, 300, 40]
+    gptr = torch.tensor(np.cumsum([0] + counts), dtype=torch.int32)
+    got = hip().radius_knn(g(pos), g(gptr), 3, 100.0, 8, True).cpu()
+    want = REF.radius_knn(pos, gptr, 3, 100.0, 8, True)
+    rows_g, rows_w = _rows_as_sets(got, 640), _rows_as_sets(want, 640)
+    for i in range(600):                                             # distinct points: exact lists
+        assert rows_g[i] == rows_w[i], i
+    for i in range(600, 640):                                        # 40 coincident points: any 9 of them, self included
+        assert len(rows_g[i]) == 9 and i in rows_g[i] and all(600 <= j < 640 for j in rows_g[i])
+
+
+def test_radius_graph_front_end_on_device():
+    """data.radius_graph dispatches CUDA positions to the HIP kernels and agrees with its own host path per graph."""
+    from cgc_net_amd.data import radius_graph
+    rng = np.random.RandomState(11)
+    pos = torch.from_numpy(rng.uniform(0, 1200.0, size=(900, 2)).astype(np.float32))
+    host = radius_graph(pos, 100.0, None, True, 8)
+    dev = radius_graph(pos.to(DEV), 100.0, None, True, 8).cpu()
+    key = lambda e: sorted(zip(e[0].tolist(), e[1].tolist()))
+    assert key(host) == key(dev)
+    batch = torch.cat([torch.zeros(500, dtype=torch.int64), torch.ones(400, dtype=torch.int64)])
+    both = radius_graph(pos.to(DEV), 100.0, batch.to(DEV), True, 8).cpu()
+    a = radius_graph(pos[:500], 100.0, None, True, 8)
+    b = radius_graph(pos[500:], 100.0, None, True, 8) + 500
+    assert key(both) == key(torch.cat([a, b], 1))
