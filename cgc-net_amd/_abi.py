@@ -6,6 +6,7 @@ P, I, F, D, L = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_int64
 PROTOTYPES = {
     'cgc_abi_version': [],
     'cgc_csr_build': [P, L, I, I, P, P, P, P, P, P, P, P],
+    'cgc_collate': [P, I, I, P, P, P, I, P, P, L, P, P],
     'cgc_radius_knn_ws_ints': [I, I],
     'cgc_radius_knn': [P, P, I, I, F, I, I, P, P, P, P, P],
     'cgc_knn_emit_edges': [P, P, I, I, L, P, P],

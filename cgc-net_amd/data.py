@@ -11,7 +11,8 @@ and training loop touch:
 * ``radius_graph(pos, r, batch, loop, max_num_neighbors)``
                                                      -- dataflow/data.py:348, prepare_cv_dataset.py:102
 
-Nothing here runs on the GPU; the device-side structure (CSR etc.) is built in graph.py.
+The host paths mirror torch_geometric; ``Batch.from_data_list(..., device=)`` and ``radius_graph`` on CUDA positions are the
+device front-end (csrc/collate.hip, csrc/knn.hip).  The CSR the model consumes is built in graph.py.
 """
 import numpy as np
 import torch
@@ -66,7 +67,18 @@ class Batch(Data):
     """Several graphs as one disconnected graph; ``batch[i]`` = graph id of node i (sorted)."""
 
     @staticmethod
-    def from_data_list(data_list):
+    def from_data_list(data_list, device=None, knn=None, mean=None, std=None):
+        """Collate a python list of ``Data`` (what ``DataListLoader`` yields, train.py:52,175).
+
+        Plain call (``device`` None): the torch_geometric behaviour, on the host.  With ``device``: the loader front-end on
+        the accelerator -- every per-graph array is packed into ONE pinned staging buffer, copied with ONE host-to-device
+        transfer, and finished by one kernel (``batch`` vector, node offsets on ``edge_index``, and -- if ``mean``/``std``
+        are given -- the z-scoring ``x = (x - mean) / std`` of dataflow/data.py:353).  ``knn = (radius, max_neighbours)``
+        builds ``edge_index`` on the device from ``pos`` instead (dataflow/data.py:348 ``radius_graph(pos, r, None, True,
+        k)`` per graph), so the items need not carry edges at all."""
+        if device is not None:
+            return _collate_on_device(data_list, torch.device(device), knn, mean, std)
+        assert knn is None and mean is None and std is None, 'host collate: items arrive finished (dataflow/data.py:330-354)'
         out = Batch()
         keys = data_list[0].keys
         offset, cat, batch_vec = 0, {k: [] for k in keys}, []
@@ -88,6 +100,91 @@ class Batch(Data):
         out.num_graphs = len(data_list)
         out._node_counts = [d.num_nodes for d in data_list]   # host-side: lets graph.py skip a device sync
         return out
+
+
+class _Stager(object):
+    """Two pinned staging buffers used alternately: the host fills one while the copy out of the other may still be in
+    flight (an event per buffer guards the reuse)."""
+
+    def __init__(self):
+        self.buf, self.evt, self.turn = [None, None], [None, None], 0
+
+    def get(self, nbytes, pinned):
+        self.turn ^= 1
+        t = self.turn
+        if self.evt[t] is not None:
+            self.evt[t].synchronize()
+        if self.buf[t] is None or self.buf[t].numel() < nbytes or self.buf[t].is_pinned() != pinned:
+            self.buf[t] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, pin_memory=pinned)
+        return self.buf[t][:nbytes], t
+
+    def sent(self, t, device):
+        if device.type == 'cuda':
+            self.evt[t] = torch.cuda.Event()
+            self.evt[t].record(torch.cuda.current_stream(device))
+
+
+_stager = _Stager()
+
+
+def _collate_on_device(data_list, device, knn, mean, std):
+    from . import kernels
+    K = kernels.get()
+    B = len(data_list)
+    counts = [d.num_nodes for d in data_list]
+    n = sum(counts)
+    first = data_list[0]
+    keys = [k for k in first.keys if not (k == 'edge_index' and knn is not None)]
+    plan = []                                          # (key, per-graph tensors, cat dim)
+    for k in keys:
+        v = first[k]
+        if torch.is_tensor(v):
+            plan.append((k, [d[k] if k != 'x' else d[k].to(torch.float32) for d in data_list], 1 if k == 'edge_index' else 0))
+    has_edges = any(k == 'edge_index' for k, _, _ in plan)
+    gptr_h = torch.tensor(np.concatenate([[0], np.cumsum(counts)]), dtype=torch.int32)
+    small = [('_gptr', gptr_h)]
+    if has_edges:
+        ecounts = [d.edge_index.shape[1] for d in data_list]
+        small.append(('_eptr', torch.tensor(np.concatenate([[0], np.cumsum(ecounts)]), dtype=torch.int32)))
+    for name, v in (('_mean', mean), ('_std', std)):
+        if v is not None:
+            small.append((name, torch.as_tensor(v, dtype=torch.float32).reshape(-1).cpu()))
+    # ---- layout of the staging buffer (16-byte aligned segments)
+    segs, off = [], 0
+    for k, parts, dim in plan:
+        shape = list(parts[0].shape)
+        shape[dim] = sum(p.shape[dim] for p in parts)
+        nbytes = int(np.prod(shape)) * parts[0].element_size()
+        segs.append((k, parts, dim, shape, parts[0].dtype, off, nbytes))
+        off = (off + nbytes + 15) // 16 * 16
+    for name, v in small:
+        segs.append((name, [v], 0, list(v.shape), v.dtype, off, v.numel() * v.element_size()))
+        off = (off + v.numel() * v.element_size() + 15) // 16 * 16
+    stage, turn = _stager.get(off, device.type == 'cuda')
+    for k, parts, dim, shape, dtype, o, nbytes in segs:
+        if nbytes:
+            torch.cat(parts, dim=dim, out=stage[o:o + nbytes].view(dtype).view(shape))
+    dbuf = stage.to(device, non_blocking=True)         # the ONE host-to-device copy
+    _stager.sent(turn, device)
+    dv = {k: dbuf[o:o + nbytes].view(dtype).view(shape) for k, _, _, shape, dtype, o, nbytes in segs}
+    out = Batch()
+    for k in first.keys:
+        if k in dv:
+            out[k] = dv[k]
+        elif not torch.is_tensor(first[k]):
+            out[k] = [d[k] for d in data_list]
+    batch_vec = torch.empty(n, dtype=torch.int64, device=device)
+    x = dv.get('x')
+    if x is None:
+        raise ValueError('device collate needs node features x')
+    K.collate(x, dv.get('_mean'), dv.get('_std'), dv['_gptr'], B, batch_vec, dv.get('edge_index'), dv.get('_eptr'))
+    if knn is not None:
+        radius, kmax = knn
+        out.edge_index = K.radius_knn(dv['pos'][:, :2], dv['_gptr'], B, float(radius), int(kmax), True)
+    out.batch = batch_vec
+    out.num_graphs = B
+    out._node_counts = counts
+    return out
 
 
 def _identity_collate(items):

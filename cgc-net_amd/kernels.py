@@ -34,6 +34,12 @@ class KernelSpec(object):
         """
         raise NotImplementedError
 
+    def collate(self, x, mean, std, gptr, num_graphs, batch_out, edge_index, eptr):
+        """Device-side finish of Batch.from_data_list: x [n,F] z-scored in place with mean/std [F] (None: untouched),
+        batch_out int64 [n] = graph id per node (None: skipped), edge_index int64 [2,E] with per-graph local ids gets the
+        node offset gptr[g] of its graph, the edges of graph g being [eptr[g], eptr[g+1]) (None: skipped)."""
+        raise NotImplementedError
+
     def radius_knn(self, pos, gptr, num_graphs, r, k, loop):
         """Cell-graph construction for a batch of graphs (torch_cluster.radius_graph(pos, r, None, loop, k) per graph,
         dataflow/data.py:348): pos [n,2] f32, gptr int32 [B+1].  Per node its <= k nearest others within r (+ itself iff
@@ -269,6 +275,15 @@ class HipKernels(KernelSpec):
         self._chk(rc, 'cgc_csr_build')
         out['cap'] = cap
         return out
+
+    def collate(self, x, mean, std, gptr, num_graphs, batch_out, edge_index, eptr):
+        self._dev(x, mean, std, gptr, batch_out, edge_index, eptr)
+        assert x.is_contiguous() and x.dtype == torch.float32
+        E = edge_index.shape[1] if edge_index is not None else 0
+        assert edge_index is None or (edge_index.is_contiguous() and edge_index.dtype == torch.int64)
+        self._chk(self.lib.cgc_collate(_ptr(x), x.shape[0], x.shape[1], _ptr(mean), _ptr(std), _ptr(gptr), num_graphs,
+                                       _ptr(batch_out), _ptr(edge_index), ctypes.c_int64(E), _ptr(eptr), self._stream()),
+                  'cgc_collate')
 
     def radius_knn(self, pos, gptr, num_graphs, r, k, loop):
         self._dev(pos, gptr)

@@ -41,6 +41,13 @@ int cgc_csr_build(const int64_t* edge_index, int64_t E, int n, int add_diag,
                   int* rowptr, int* col, int* rowidx, int* t_rowptr, int* t_col, int* t_perm,
                   int* ws, cgc_stream_t stream);
 
+/* ---- F1 (loader front-end): device-side finish of Batch.from_data_list after ONE host-to-device copy of the packed
+ * batch.  x [n,F] is z-scored in place, x = (x - mean[f]) / std[f] (dataflow/data.py:353; mean/std NULL: untouched);
+ * batch[i] = graph of node i from gptr [B+1] (NULL: skipped); edge_index [2,E] holds per-graph LOCAL node ids, the edges of
+ * graph g at [eptr[g], eptr[g+1]): both rows get + gptr[g] (torch_geometric Batch.from_data_list; NULL: skipped). */
+int cgc_collate(float* x, int n, int F, const float* mean, const float* stdv, const int* gptr, int B, int64_t* batch,
+                int64_t* edge_index, int64_t E, const int* eptr, cgc_stream_t stream);
+
 /* ---- F2 (the step before the path): cell-graph construction.  Replaces torch_cluster.radius_graph(pos, r, None, loop,
  * max_num_neighbors) = cKDTree.query(k+1, distance_upper_bound = r+1e-8) per graph on the host (dataflow/data.py:246,255,
  * 297,348; dataflow/prepare_cv_dataset.py:102) for a whole batch of graphs: pos [n,2] f32, gptr [B+1] first node of each

@@ -76,6 +76,18 @@ class TorchKernels(KernelSpec):
         cnt = (rowptr[1:] - rowptr[:-1]).long()
         return torch.repeat_interleave(torch.arange(n, device=rowptr.device), cnt), int(rowptr[n])
 
+    def collate(self, x, mean, std, gptr, num_graphs, batch_out, edge_index, eptr):
+        """dataflow/data.py:353 (z-score) + torch_geometric Batch.from_data_list (batch vector, edge offsets)."""
+        if mean is not None:
+            x.copy_((x - mean) / std)
+        gp = gptr.long()
+        counts = gp[1:] - gp[:-1]
+        if batch_out is not None:
+            batch_out.copy_(torch.repeat_interleave(torch.arange(num_graphs), counts))
+        if edge_index is not None:
+            ep = eptr.long()
+            edge_index += torch.repeat_interleave(gp[:-1], ep[1:] - ep[:-1]).unsqueeze(0)
+
     def radius_knn(self, pos, gptr, num_graphs, r, k, loop):
         """cKDTree.query(k+1, distance_upper_bound=r+1e-8) per graph (torch_cluster 1.4.2's CPU radius_graph, SURVEY B.5;
         call site dataflow/data.py:348), graph by graph with global node ids; neighbours by (distance, index)."""

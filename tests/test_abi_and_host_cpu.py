@@ -108,3 +108,22 @@ def test_oracle_matches_golden():
         assert rel_err(logits, out['logits']) < 1e-5 and rel_err(loss, out['loss']) < 1e-5
         for k, p in m.named_parameters():
             assert rel_err(p.grad, grad[k]) < 1e-5, (name, k)
+
+
+def test_device_collate_front_end_matches_host_collate(torch_kernels):
+    """Batch.from_data_list(..., device=): one packed copy + one finishing kernel == the host collate, z-score and per-graph
+    radius_graph (kernel entry points through the CPU twin here; the HIP path is tests/test_kernels_gpu.py)."""
+    ds = SyntheticCellGraphs(5, 120, 6, base_seed=4)
+    items = [ds[i] for i in range(5)]
+    mean, std = torch.linspace(-0.5, 0.5, 6), torch.linspace(0.5, 2.0, 6)
+    host = Batch.from_data_list([Data(x=(d.x - mean) / std, pos=d.pos, y=d.y, edge_index=d.edge_index) for d in items])
+    dev = Batch.from_data_list(items, device='cpu', mean=mean, std=std)
+    assert torch.equal(dev.x, host.x) and torch.equal(dev.pos, host.pos) and torch.equal(dev.y, host.y)
+    assert torch.equal(dev.batch, host.batch) and torch.equal(dev.edge_index, host.edge_index)
+    assert dev._node_counts == host._node_counts and dev.num_graphs == 5
+    # edges built at collate time from the positions (items without edge_index)
+    bare = [Data(x=d.x, pos=d.pos, y=d.y) for d in items]
+    built = Batch.from_data_list(bare, device='cpu', knn=(100.0, 8))
+    key = lambda e: sorted(zip(e[0].tolist(), e[1].tolist()))
+    assert key(built.edge_index) == key(host.edge_index)
+    assert torch.equal(built.x, torch.cat([d.x for d in items]))

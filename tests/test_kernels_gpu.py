@@ -480,3 +480,38 @@ def test_radius_graph_front_end_on_device():
     a = radius_graph(pos[:500], 100.0, None, True, 8)
     b = radius_graph(pos[500:], 100.0, None, True, 8) + 500
     assert key(both) == key(torch.cat([a, b], 1))
+
+
+# ------------------------------------------------------------------ F1: loader front-end on the device
+def test_device_collate_matches_host_collate_bit_for_bit():
+    from cgc_net_amd.data import Batch, Data, SyntheticCellGraphs
+    ds = SyntheticCellGraphs(6, 400, 16, base_seed=9)
+    items = [ds[i] for i in range(6)]
+    mean, std = torch.linspace(-1.0, 1.0, 16), torch.linspace(0.3, 3.0, 16)
+    host = Batch.from_data_list([Data(x=(d.x - mean) / std, pos=d.pos, y=d.y, edge_index=d.edge_index) for d in items])
+    for rep in range(3):                                             # staging buffers are reused across calls
+        dev = Batch.from_data_list(items, device=DEV, mean=mean, std=std)
+        assert dev.x.is_cuda and dev.edge_index.is_cuda and dev.batch.is_cuda
+        assert torch.equal(dev.x.cpu(), host.x)                      # IEEE division on both sides
+        assert torch.equal(dev.pos.cpu(), host.pos) and torch.equal(dev.y.cpu(), host.y)
+        assert torch.equal(dev.batch.cpu(), host.batch) and torch.equal(dev.edge_index.cpu(), host.edge_index)
+        assert dev._node_counts == host._node_counts
+    bare = [Data(x=d.x, pos=d.pos, y=d.y) for d in items]
+    built = Batch.from_data_list(bare, device=DEV, knn=(100.0, 8))
+    key = lambda e: sorted(zip(e[0].tolist(), e[1].tolist()))
+    assert key(built.edge_index.cpu()) == key(host.edge_index)
+    assert torch.equal(built.x.cpu(), torch.cat([d.x for d in items]))
+
+
+def test_model_step_from_device_front_end():
+    """The whole front of the path on the device (collate + graph construction) feeds the model: same loss as host-built."""
+    from cgc_net_amd.data import Batch, Data, SyntheticCellGraphs
+    from cgc_net_amd import network
+    ds = SyntheticCellGraphs(4, 300, 16, base_seed=2)
+    items = [ds[i] for i in range(4)]
+    torch.manual_seed(0)
+    model = network.SoftPoolingGcnEncoder(600, 16, 20, 20, True, True, 20, 3, 0.1, [50], concat=True, load_data_sparse=True).to(DEV)
+    model.train()
+    _, l_host = model(Batch.from_data_list(items).to(DEV))
+    _, l_dev = model(Batch.from_data_list([Data(x=d.x, pos=d.pos, y=d.y) for d in items], device=DEV, knn=(100.0, 8)))
+    assert abs(l_host.item() - l_dev.item()) <= 1e-6 * max(1.0, abs(l_host.item()))
