@@ -164,7 +164,7 @@ def _collate_on_device(data_list, device, knn, mean, std):
     for k, parts, dim, shape, dtype, o, nbytes in segs:
         if nbytes:
             torch.cat(parts, dim=dim, out=stage[o:o + nbytes].view(dtype).view(shape))
-    dbuf = stage.to(device, non_blocking=True)         # the ONE host-to-device copy
+    dbuf = stage.to(device, non_blocking=True) if device.type != 'cpu' else stage.clone()    # the ONE host-to-device copy
     _stager.sent(turn, device)
     dv = {k: dbuf[o:o + nbytes].view(dtype).view(shape) for k, _, _, shape, dtype, o, nbytes in segs}
     out = Batch()

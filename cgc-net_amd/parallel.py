@@ -23,9 +23,11 @@ from .data import Batch, partition_by_nodes
 
 
 class DataParallel(nn.Module):
-    def __init__(self, module, device_ids=None, output_device=None, shard_input=True, process_group=None):
+    def __init__(self, module, device_ids=None, output_device=None, shard_input=True, process_group=None, front_end=None):
         super().__init__()
         self.module = module
+        # optional keyword arguments of Batch.from_data_list for the device front-end: knn=(radius, k), mean=, std=
+        self.front_end = dict(front_end or {})
         self.shard_input = shard_input
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
@@ -84,5 +86,7 @@ class DataParallel(nn.Module):
             return self.module(data_list)
         if len(data_list) == 0:
             raise ValueError('empty batch')
-        batch = Batch.from_data_list(self.local_chunk(data_list)).to(self.device)
+        # loader front-end on the device: one packed copy + one kernel (data.py / csrc/collate.hip), optionally with the
+        # k-NN graph construction and the feature z-scoring the reference does per item on the host
+        batch = Batch.from_data_list(self.local_chunk(data_list), device=self.device, **self.front_end)
         return self.module(batch)
