@@ -216,8 +216,10 @@ extern "C" int cgc_l2norm_act_stats(const float* h, int n, int F, int normalize,
 // BatchNorm statistics -> mean / inverse std (+ running statistics)
 // ------------------------------------------------------------------------------------------------
 __global__ void k_bn_finalize(const double* __restrict__ stats, int F, double count, float eps, float momentum,
-                              float* running_mean, float* running_var, float* __restrict__ mean, float* __restrict__ istd) {
+                              float* running_mean, float* running_var, float* __restrict__ mean, float* __restrict__ istd,
+                              long long* nbt) {
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f == 0 && nbt != nullptr) *nbt += 1;       // nn.BatchNorm1d's num_batches_tracked
   if (f >= F) return;
   const double m = stats[f] / count;
   double var = stats[F + f] / count - m * m;   // biased; the padded zero rows are part of `count`
@@ -235,7 +237,25 @@ extern "C" int cgc_bn_finalize(const double* stats, int F, double count, float e
                                float* running_var, float* mean, float* istd, cgc_stream_t stream) {
   if (F <= 0) return 0;
   hipLaunchKernelGGL(k_bn_finalize, dim3(ceil_div(F, 256)), dim3(256), 0, as_stream(stream), stats, F, count, eps, momentum,
-                     running_mean, running_var, mean, istd);
+                     running_mean, running_var, mean, istd, (long long*)nullptr);
+  CGC_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}
+
+// The training forward's statistics as ONE call: l2norm + activation sums, second stage, finalize, running statistics and
+// num_batches_tracked += 1 (three launches; one host call instead of three plus torch's counter increment).
+// ws: cgc_stats_blocks(n,F)*2F floats for the slots + 4F + 2 floats for the fp64 sums.
+extern "C" int cgc_l2norm_act_bn(const float* h, int n, int F, int normalize, int act, float* hn, float* rinv, float* ws,
+                                 double count, float eps, float momentum, float* running_mean, float* running_var,
+                                 int64_t* num_batches_tracked, float* mean, float* istd, cgc_stream_t stream) {
+  if (F <= 0) return 0;
+  if (ws == nullptr || mean == nullptr || istd == nullptr) return CGC_EINVAL;
+  const size_t slot_floats = (size_t)(cgc_stats_blocks(n, F) > 0 ? cgc_stats_blocks(n, F) : 1) * 2 * F;
+  double* stats = reinterpret_cast<double*>(ws + slot_floats + (slot_floats & 1));        // 8-byte aligned
+  const int rc = cgc_l2norm_act_stats(h, n, F, normalize, act, hn, rinv, stats, ws, stream);
+  if (rc != 0) return rc;
+  hipLaunchKernelGGL(k_bn_finalize, dim3(ceil_div(F, 256)), dim3(256), 0, as_stream(stream), stats, F, count, eps, momentum,
+                     running_mean, running_var, mean, istd, reinterpret_cast<long long*>(num_batches_tracked));
   CGC_RETURN_IF_LAUNCH_FAILED();
   return 0;
 }

@@ -94,6 +94,12 @@ class KernelSpec(object):
         FLOAT64 [2,F]: the variance is a difference of these two sums."""
         raise NotImplementedError
 
+    def l2norm_act_bn(self, h, n, F, normalize, act, hn_out, rinv_out, count, eps, momentum, running_mean, running_var,
+                      num_batches_tracked, mean_out, istd_out):
+        """l2norm_act_stats + bn_finalize as one call (the training forward): also increments num_batches_tracked
+        (int64 scalar tensor or None), as nn.BatchNorm1d.forward does."""
+        raise NotImplementedError
+
     def bn_finalize(self, stats, count, eps, momentum, running_mean, running_var, mean_out, istd_out):
         """mean = s0/count, var = s1/count - mean^2 (biased), istd = rsqrt(var+eps); running stats get
         momentum updates with the unbiased var*count/(count-1).  ``count`` = B*Nmax INCLUDING the
@@ -193,6 +199,16 @@ def is_native():
     return isinstance(_instance, HipKernels)
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+_cur_device = getattr(torch._C, '_cuda_getDevice', None)
+if _raw_stream is None or _cur_device is None:          # older / newer torch without the private accessors
+    def _raw_stream(_idx):
+        return torch.cuda.current_stream().cuda_stream
+
+    def _cur_device():
+        return 0
+
+
 def _ptr(t):
     return ctypes.c_void_p(t.data_ptr() if t is not None else 0)
 
@@ -244,7 +260,9 @@ class HipKernels(KernelSpec):
     # -- helpers
     @staticmethod
     def _stream():
-        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        # torch's current stream of the current device as a raw hipStream_t (the C call: torch.cuda.current_stream() costs
+        # ~8 us of Python per launch, which is what bounds the small-graph regime)
+        return ctypes.c_void_p(_raw_stream(_cur_device()))
 
     @staticmethod
     def _chk(rc, name):
@@ -394,6 +412,18 @@ class HipKernels(KernelSpec):
         self._dev(hn, mean, istd, gamma, beta, y_out)
         self._chk(self.lib.cgc_bn_act_apply(_ptr(hn), n, F, act, _ptr(mean), _ptr(istd), _ptr(gamma), _ptr(beta),
                                             _ptr(y_out), ldy, self._stream()), 'cgc_bn_act_apply')
+
+    def l2norm_act_bn(self, h, n, F, normalize, act, hn_out, rinv_out, count, eps, momentum, running_mean, running_var,
+                      num_batches_tracked, mean_out, istd_out):
+        self._dev(h, hn_out, rinv_out, running_mean, running_var, num_batches_tracked, mean_out, istd_out)
+        nblk = self.lib.cgc_stats_blocks(n, F)
+        ws = torch.empty(max(nblk, 1) * 2 * F + 4 * F + 2, dtype=torch.float32, device=h.device)
+        assert num_batches_tracked is None or num_batches_tracked.dtype == torch.int64
+        self._chk(self.lib.cgc_l2norm_act_bn(_ptr(h), n, F, int(normalize), act, _ptr(hn_out), _ptr(rinv_out), _ptr(ws),
+                                             ctypes.c_double(count), ctypes.c_float(eps),
+                                             ctypes.c_float(momentum), _ptr(running_mean), _ptr(running_var),
+                                             _ptr(num_batches_tracked), _ptr(mean_out), _ptr(istd_out), self._stream()),
+                  'cgc_l2norm_act_bn')
 
     def bn_bwd_reduce(self, dy, ldy, hn, n, F, act, mean, istd, sums_out):
         self._dev(dy, hn, mean, istd, sums_out)

@@ -229,7 +229,7 @@ def linear_cat(xs, weight, bias=None, softmax=False):
 # ----------------------------------------------------------------------------------------------
 class _L2ActBN(Function):
     @staticmethod
-    def forward(ctx, h, gamma, beta, running_mean, running_var, count, act, normalize, bn_mode, eps, momentum):
+    def forward(ctx, h, gamma, beta, running_mean, running_var, count, act, normalize, bn_mode, eps, momentum, nbt=None):
         h = _f32c(h)
         n, F = h.shape
         dev = h.device
@@ -237,11 +237,10 @@ class _L2ActBN(Function):
         rinv = torch.empty(n, dtype=torch.float32, device=dev)
         mean = istd = None
         if bn_mode == 2:
-            stats = torch.empty(2, F, dtype=torch.float64, device=dev)
-            K().l2norm_act_stats(h, n, F, normalize, act, hn, rinv, stats)
             mean = torch.empty(F, dtype=torch.float32, device=dev)
             istd = torch.empty(F, dtype=torch.float32, device=dev)
-            K().bn_finalize(stats, float(count), eps, momentum, running_mean, running_var, mean, istd)
+            K().l2norm_act_bn(h, n, F, normalize, act, hn, rinv, float(count), eps, momentum, running_mean, running_var, nbt,
+                              mean, istd)
         else:
             K().l2norm_act_stats(h, n, F, normalize, act, hn, rinv, None)
             if bn_mode == 1:
@@ -265,7 +264,18 @@ class _L2ActBN(Function):
             dbeta, dgamma = sums[0], sums[1]
         dh = torch.empty_like(hn)
         K().bn_act_l2_bwd(dy, ld, hn, rinv, n, F, act, normalize, bn_mode, mean, istd, gamma, sums, count, dh)
-        return dh, dgamma, dbeta, None, None, None, None, None, None, None, None
+        return dh, dgamma, dbeta, None, None, None, None, None, None, None, None, None
+
+
+def _bn_momentum(bn, count_batch):
+    """nn.BatchNorm1d's bookkeeping: num_batches_tracked += 1 per training forward; momentum=None means the cumulative
+    moving average 1/num_batches_tracked.  Returns (momentum, counter tensor for the KERNEL to increment or None)."""
+    nbt = bn.num_batches_tracked if count_batch else None
+    if bn.momentum is not None:
+        return bn.momentum, nbt                     # the counter rides along with the statistics kernel
+    if nbt is not None:
+        nbt.add_(1)                                  # cumulative average: the value is needed on the host first
+    return 1.0 / float(max(int(bn.num_batches_tracked), 1)), None
 
 
 def l2_act_bn(h, bn, count, act='relu', normalize=True, training=True):
@@ -278,12 +288,10 @@ def l2_act_bn(h, bn, count, act='relu', normalize=True, training=True):
     if bn is None:
         return _L2ActBN.apply(h, None, None, None, None, count, code, normalize, 0, 0.0, 0.0)
     use_batch = training or bn.running_mean is None
-    if use_batch and training and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
-    momentum = bn.momentum if bn.momentum is not None else 1.0 / float(max(int(bn.num_batches_tracked), 1))
+    momentum, nbt = _bn_momentum(bn, use_batch and training)
     rm, rv = (bn.running_mean, bn.running_var) if (training and bn.track_running_stats) else (None, None)
     if use_batch:
-        return _L2ActBN.apply(h, bn.weight, bn.bias, rm, rv, count, code, normalize, 2, bn.eps, momentum)
+        return _L2ActBN.apply(h, bn.weight, bn.bias, rm, rv, count, code, normalize, 2, bn.eps, momentum, nbt)
     return _L2ActBN.apply(h, bn.weight, bn.bias, bn.running_mean, bn.running_var, count, code, normalize, 1,
                           bn.eps, 0.0)
 
@@ -294,7 +302,8 @@ class _SageProject(Function):
     sums (= db), then dW (row-split GEMM) and d agg."""
 
     @staticmethod
-    def forward(ctx, agg, weight, bias, gamma, beta, running_mean, running_var, count, act, normalize, bn_mode, eps, momentum):
+    def forward(ctx, agg, weight, bias, gamma, beta, running_mean, running_var, count, act, normalize, bn_mode, eps, momentum,
+                nbt=None):
         agg, weight = _f32c(agg), _f32c(weight)
         n, fin = agg.shape
         F = weight.shape[1]
@@ -304,11 +313,10 @@ class _SageProject(Function):
         rinv = torch.empty(n, dtype=torch.float32, device=dev)
         mean = istd = None
         if bn_mode == 2:
-            stats = torch.empty(2, F, dtype=torch.float64, device=dev)
-            K().l2norm_act_stats(h, n, F, normalize, act, h, rinv, stats)          # in place: h becomes hn
             mean = torch.empty(F, dtype=torch.float32, device=dev)
             istd = torch.empty(F, dtype=torch.float32, device=dev)
-            K().bn_finalize(stats, float(count), eps, momentum, running_mean, running_var, mean, istd)
+            K().l2norm_act_bn(h, n, F, normalize, act, h, rinv, float(count), eps, momentum, running_mean, running_var, nbt,
+                              mean, istd)                                          # in place: h becomes hn
         else:
             K().l2norm_act_stats(h, n, F, normalize, act, h, rinv, None)
             if bn_mode == 1:
@@ -342,7 +350,7 @@ class _SageProject(Function):
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(weight)
             gemm_tn_rows(agg, fin, fin, dh, F, F, n, dw)
-        return dagg, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None
+        return dagg, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None
 
 
 def sage_project(agg, weight, bias, bn, count, act='relu', normalize=True, training=True):
@@ -351,12 +359,11 @@ def sage_project(agg, weight, bias, bn, count, act='relu', normalize=True, train
     if bn is None:
         return _SageProject.apply(agg, weight, bias, None, None, None, None, count, code, normalize, 0, 0.0, 0.0)
     use_batch = training or bn.running_mean is None
-    if use_batch and training and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
-    momentum = bn.momentum if bn.momentum is not None else 1.0 / float(max(int(bn.num_batches_tracked), 1))
+    momentum, nbt = _bn_momentum(bn, use_batch and training)
     rm, rv = (bn.running_mean, bn.running_var) if (training and bn.track_running_stats) else (None, None)
     if use_batch:
-        return _SageProject.apply(agg, weight, bias, bn.weight, bn.bias, rm, rv, count, code, normalize, 2, bn.eps, momentum)
+        return _SageProject.apply(agg, weight, bias, bn.weight, bn.bias, rm, rv, count, code, normalize, 2, bn.eps, momentum,
+                                  nbt)
     return _SageProject.apply(agg, weight, bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, count, code,
                               normalize, 1, bn.eps, 0.0)
 

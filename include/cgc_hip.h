@@ -120,6 +120,11 @@ int cgc_l2norm_act_stats(const float* h, int n, int F, int normalize, int act, f
                          double* stats /*[2,F] fp64 or NULL*/, float* ws, cgc_stream_t stream);
 int cgc_bn_finalize(const double* stats /*[2,F] fp64: the variance is a difference of these sums*/, int F, double count, float eps, float momentum,
                     float* running_mean /*NULL ok*/, float* running_var, float* mean, float* istd, cgc_stream_t stream);
+/* The two calls above as ONE (what the training forward uses): hn, rinv, batch statistics over `count` rows, mean / istd,
+ * running statistics and num_batches_tracked += 1 (NULL ok).  ws: cgc_stats_blocks(n,F)*2F + 4F + 2 floats. */
+int cgc_l2norm_act_bn(const float* h, int n, int F, int normalize, int act, float* hn, float* rinv, float* ws, double count,
+                      float eps, float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                      float* mean, float* istd, cgc_stream_t stream);
 int cgc_bn_act_apply(const float* hn, int n, int F, int act, const float* mean /*NULL: no BN*/, const float* istd,
                      const float* gamma, const float* beta, float* y, int ldy, cgc_stream_t stream);
 int cgc_bn_bwd_reduce(const float* dy, int ldy, const float* hn, int n, int F, int act, const float* mean,

@@ -200,6 +200,14 @@ class TorchKernels(KernelSpec):
             stats_out[0] = o.double().sum(0)
             stats_out[1] = (o.double() * o.double()).sum(0)
 
+    def l2norm_act_bn(self, h, n, F_, normalize, act, hn_out, rinv_out, count, eps, momentum, running_mean, running_var,
+                      num_batches_tracked, mean_out, istd_out):
+        stats = torch.zeros(2, F_, dtype=torch.float64, device=h.device)
+        self.l2norm_act_stats(h, n, F_, normalize, act, hn_out, rinv_out, stats)
+        self.bn_finalize(stats, count, eps, momentum, running_mean, running_var, mean_out, istd_out)
+        if num_batches_tracked is not None:
+            num_batches_tracked += 1
+
     def bn_finalize(self, stats, count, eps, momentum, running_mean, running_var, mean_out, istd_out):
         mean = stats[0].double() / count
         var = (stats[1].double() / count - mean * mean).clamp(min=0)

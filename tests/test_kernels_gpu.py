@@ -301,6 +301,29 @@ def test_conv_epilogue_chain(n, F, act):
             close(a, b, tol, key)
 
 
+@pytest.mark.parametrize('n,F', [(50, 8), (333, 20), (5000, 20), (4100, 60), (2000, 128), (300, 1140), (1, 16)])
+def test_fused_statistics_and_finalize(n, F):
+    """cgc_l2norm_act_bn = l2norm_act_stats + bn_finalize + num_batches_tracked += 1 behind one entry point."""
+    k = hip()
+    count = float(n + 23)
+    res = {}
+    for name, K_, dev in (('ref', REF, 'cpu'), ('hip', k, DEV)):
+        rm, rv = torch.zeros(F, device=dev), torch.ones(F, device=dev)
+        nbt = torch.zeros((), dtype=torch.int64, device=dev)
+        outs = []
+        for rep in range(3):
+            h = rnd(n, F, seed=F + rep).to(dev)
+            hn, rinv = torch.empty(n, F, device=dev), torch.empty(n, device=dev)
+            mean, istd = torch.empty(F, device=dev), torch.empty(F, device=dev)
+            K_.l2norm_act_bn(h, n, F, True, 1, hn, rinv, count, 1e-5, 0.1, rm, rv, nbt, mean, istd)
+            outs += [hn, rinv, mean, istd]
+        res[name] = outs + [rm, rv, nbt.double()]
+    torch.cuda.synchronize()
+    assert int(res['hip'][-1].item()) == 3
+    for a, b in zip(res['hip'], res['ref']):
+        close(a, b)
+
+
 def test_epilogue_without_bn_and_without_normalize():
     k = hip()
     n, F = 77, 20

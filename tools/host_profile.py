@@ -1,0 +1,42 @@
+#!/usr/bin/env python
+"""cProfile of the host side of training steps in the launch-bound regime (C3 graphs, max_num_nodes = 1800 => C1 = 180)."""
+import cProfile
+import os
+import pstats
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import cgc_net_amd  # noqa: E402,F401
+from cgc_net_amd import network  # noqa: E402
+from cgc_net_amd.data import Batch, SyntheticCellGraphs  # noqa: E402
+
+dev = 'cuda:0'
+ds = SyntheticCellGraphs(32, 1800, 16, base_seed=0)
+b = Batch.from_data_list([ds[i] for i in range(32)]).to(dev)
+kw = dict(concat=True, load_data_sparse=True)
+if '--shipped' in sys.argv:
+    kw.update(norm_adj=True, jk=True, drop_out=0.2)
+model = network.SoftPoolingGcnEncoder(1800, 16, 20, 20, True, True, 20, 3, 0.1, [50], **kw).to(dev)
+opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
+
+
+def step():
+    _, loss = model(b)
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+
+
+for _ in range(5):
+    step()
+torch.cuda.synchronize()
+pr = cProfile.Profile()
+pr.enable()
+for _ in range(20):
+    step()
+torch.cuda.synchronize()
+pr.disable()
+st = pstats.Stats(pr)
+st.sort_stats('tottime').print_stats(28)
