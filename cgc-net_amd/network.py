@@ -219,15 +219,22 @@ class GNN_Module(nn.Module):
                     z = ops.l2_act_bn(z, None, count, 'identity', True, self.training)
                 h = ops.l2_act_bn(z * row_mask, bn, count, self.activation, False, self.training)
             outs.append(h)
-        if self.lin is not None and row_mask is None:
-            # Linear over cat[x1,x2,x3] without the concatenation: the two narrow pieces are joined (cheap), the wide one
-            # ([rows, cluster count]) is the main operand of the same GEMM
-            return ops.linear_cat([torch.cat(outs[:2], dim=-1), outs[2]], self.lin.weight, self.lin.bias, softmax)
+        if row_mask is None:
+            return self._tail(outs, softmax)
         h = torch.cat(outs, dim=-1)
         if row_mask is not None:
             h = h * row_mask
         if self.lin is not None:
             h = ops.linear_bias(h, self.lin.weight, self.lin.bias, out_in_layout=True) * row_mask
+        return ops.softmax_rows(h) if softmax else h
+
+    def _tail(self, outs, softmax=False):
+        """cat[x1,x2,x3] (-> Linear (-> softmax)) of the three layer outputs, unpadded rows."""
+        if self.lin is not None:
+            # Linear over cat[x1,x2,x3] without the concatenation: the two narrow pieces are joined (cheap), the wide one
+            # ([rows, cluster count]) is the main operand of the same GEMM
+            return ops.linear_cat([torch.cat(outs[:2], dim=-1), outs[2]], self.lin.weight, self.lin.bias, softmax)
+        h = torch.cat(outs, dim=-1)
         return ops.softmax_rows(h) if softmax else h
 
     def forward_graph(self, x, g, agg0=None, softmax=False):
@@ -247,6 +254,35 @@ class GNN_Module(nn.Module):
         out = self.run_rows(x.reshape(B * N, -1), lambda h: ops.bmatmul(a, h.view(B, N, -1)).view(B * N, -1),
                             B * N, None, row_mask)
         return out.view(B, N, -1)
+
+
+def run_blocks_paired(emb, pool, x, aggregate, count, agg0):
+    """The embedding block and the assignment block of one level, layer by layer.  Layer k of both blocks aggregates over
+    the SAME adjacency (model/network.py:258-262: ``GCN_embed_k(x, adj)`` and ``GCN_pool_k(x, adj)``), so the two
+    aggregations run as ONE pass over it, ``A [h_embed | h_pool]`` (the first layer's inputs are identical: ``agg0``).  At
+    level 2 that pass reads the dense 166 MB adjacency, at level 1 it is one gather instead of two.  Returns the blocks' layer
+    outputs (lists of three)."""
+    he = hp = x
+    outs_e, outs_p = [], []
+    for k in (1, 2, 3):
+        ce, cp = getattr(emb, 'gcn%d' % k), getattr(pool, 'gcn%d' % k)
+        be = getattr(emb, 'bn%d' % k) if emb.use_bn else None
+        bp = getattr(pool, 'bn%d' % k) if pool.use_bn else None
+        if k == 1:
+            ae = ap = agg0
+        else:
+            we = he.shape[1]
+            agg = aggregate(torch.cat([he, hp], dim=-1))
+            ae, ap = agg[:, :we], agg[:, we:]
+        he = ops.sage_project(ae, ce.weight, ce.bias, be, count, emb.activation, ce.normalize, emb.training)
+        hp = ops.sage_project(ap, cp.weight, cp.bias, bp, count, pool.activation, cp.normalize, pool.training)
+        outs_e.append(he)
+        outs_p.append(hp)
+    return outs_e, outs_p
+
+
+def _pairable(emb, pool):
+    return emb.mean_aggregation and pool.mean_aggregation and not emb.add_loop and not pool.add_loop
 
 
 # ------------------------------------------------------------------------------------------------
@@ -322,11 +358,16 @@ class SoftPoolingGcnEncoder(nn.Module):
         x = data.x
         emb_blk, pool_blk = self.GCN_embed_1, self.GCN_pool_1
         agg0 = ops.aggregate(x, g, emb_blk.mean_aggregation)     # shared by both blocks' first conv
-        embed = emb_blk.forward_graph(x, g, agg0)
+        if _pairable(emb_blk, pool_blk):
+            outs_e, outs_p = run_blocks_paired(emb_blk, pool_blk, x, lambda h: ops.aggregate(h, g, True), g.padded_rows, agg0)
+            embed, s = emb_blk._tail(outs_e), pool_blk._tail(outs_p, softmax=True)
+        else:
+            embed, s = emb_blk.forward_graph(x, g, agg0), None
         if self.jk:
             embed = self.jk1(embed)
         readout = ops.segment_max(embed, g.gptr, g.B, g.nmax)
-        s = pool_blk.forward_graph(x, g, agg0, softmax=True)
+        if s is None:
+            s = pool_blk.forward_graph(x, g, agg0, softmax=True)
         if self.collect_assign:
             self.assign_matrix.append(self._pad_assign(s.detach(), g))
         xn, an = ops.diff_pool_sparse(embed, s, g)
@@ -352,13 +393,20 @@ class SoftPoolingGcnEncoder(nn.Module):
             return ops.bmatmul(a, h.view(B, C, -1), shared=shared).view(B * C, -1)
         xf = x.reshape(B * C, -1)
         agg0 = aggregate(xf)
-        embed = emb_blk.run_rows(xf, aggregate, B * C, agg0)
+        pool_blk = getattr(self, 'GCN_pool_%d' % level) if level < 3 else None
+        s = None
+        if pool_blk is not None and _pairable(emb_blk, pool_blk):
+            outs_e, outs_p = run_blocks_paired(emb_blk, pool_blk, xf, aggregate, B * C, agg0)
+            embed, s = emb_blk._tail(outs_e), pool_blk._tail(outs_p, softmax=True)
+        else:
+            embed = emb_blk.run_rows(xf, aggregate, B * C, agg0)
         if self.jk:
             embed = getattr(self, 'jk%d' % level)(embed)
         readout = ops.segment_max(embed, uniform_ptr(B, C, x.device), B, C)
         if level == 3:
             return readout, None, None
-        s = getattr(self, 'GCN_pool_%d' % level).run_rows(xf, aggregate, B * C, agg0, None, True)
+        if s is None:
+            s = pool_blk.run_rows(xf, aggregate, B * C, agg0, None, True)
         if self.collect_assign:
             self.assign_matrix.append(s.detach().view(B, C, -1))
         xn, an = ops.diff_pool_dense(embed.view(B, C, -1), adj, s.view(B, C, -1))

@@ -304,12 +304,12 @@ class _SageProject(Function):
     @staticmethod
     def forward(ctx, agg, weight, bias, gamma, beta, running_mean, running_var, count, act, normalize, bn_mode, eps, momentum,
                 nbt=None):
-        agg, weight = _f32c(agg), _f32c(weight)
+        (agg, lda), weight = _rows_ld(agg), _f32c(weight)      # agg may be a column slice of a paired aggregation
         n, fin = agg.shape
         F = weight.shape[1]
         dev = agg.device
         h = torch.empty(n, F, dtype=torch.float32, device=dev)
-        K().gemm(agg, weight, h, n, F, fin, False, False, fin, F, F, 1.0, 0.0, bias)
+        K().gemm(agg, weight, h, n, F, fin, False, False, lda, F, F, 1.0, 0.0, bias)
         rinv = torch.empty(n, dtype=torch.float32, device=dev)
         mean = istd = None
         if bn_mode == 2:
@@ -324,13 +324,13 @@ class _SageProject(Function):
         y = torch.empty(n, F, dtype=torch.float32, device=dev)
         K().bn_act_apply(h, n, F, act, mean, istd, gamma, beta, y, F)
         ctx.save_for_backward(agg, weight, h, rinv, mean, istd, gamma)
-        ctx.cfg = (act, normalize, bn_mode, float(count), bias is not None)
+        ctx.cfg = (act, normalize, bn_mode, float(count), bias is not None, lda)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         agg, weight, hn, rinv, mean, istd, gamma = ctx.saved_tensors
-        act, normalize, bn_mode, count, has_bias = ctx.cfg
+        act, normalize, bn_mode, count, has_bias, lda = ctx.cfg
         n, F = hn.shape
         fin = agg.shape[1]
         dy, ld = _rows_ld(dy)
@@ -345,11 +345,11 @@ class _SageProject(Function):
         K().bn_act_l2_bwd(dy, ld, hn, rinv, n, F, act, normalize, bn_mode, mean, istd, gamma, sums, count, dh, db)
         dagg = dw = None
         if ctx.needs_input_grad[0]:
-            dagg = torch.empty_like(agg)
+            dagg = torch.empty(n, fin, dtype=torch.float32, device=dev)
             K().gemm(dh, weight, dagg, n, fin, F, False, True, F, F, fin)
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(weight)
-            gemm_tn_rows(agg, fin, fin, dh, F, F, n, dw)
+            gemm_tn_rows(agg, lda, fin, dh, F, F, n, dw)
         return dagg, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None
 
 
