@@ -33,6 +33,8 @@ PROTOTYPES = {
     'cgc_jk_supported': [I],
     'cgc_jk_lstm_fwd': [P, I, I, I, P, P, P, P, P, P, P],
     'cgc_jk_lstm_bwd': [P, P, I, I, I, P, P, P, P, P, P, P, P, P, P],
+    'cgc_jk_bwd_ws_floats': [I],
+    'cgc_jk_lstm_bwd_params': [P, P, I, I, I, P, P, P, P, P, P, P, P, P],
     'cgc_dense_rownorm_fwd': [P, I, I, P, P, P, P],
     'cgc_dense_rownorm_bwd': [P, P, P, P, I, I, P, P],
     'cgc_dense_renorm_fwd': [P, I, I, F, P, P],
@@ -45,4 +47,4 @@ def declare(lib):
     for name, argtypes in PROTOTYPES.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
-        fn.restype = C.c_int64 if name.endswith('_ws_ints') else C.c_int
+        fn.restype = C.c_int64 if name.endswith(('_ws_ints', '_ws_floats')) else C.c_int

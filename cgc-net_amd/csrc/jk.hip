@@ -354,3 +354,17 @@ extern "C" int cgc_jk_lstm_bwd(const float* xs, const float* dout, int n, int np
     default: return CGC_EINVAL;
   }
 }
+
+extern "C" int64_t cgc_jk_bwd_ws_floats(int C) { return jk_mfma_bwd_ws_floats(C); }
+
+// Backward with the parameter gradients accumulated in-kernel (matrix-core path only; CGC_EINVAL when the buffers are not
+// 16-byte aligned or C is unsupported -- the caller then uses cgc_jk_lstm_bwd + one GEMM per direction).
+extern "C" int cgc_jk_lstm_bwd_params(const float* xs, const float* dout, int n, int npad, int C, const float* const* lstm,
+                                      const float* w_att, const float* b_att, const float* HS, const float* CS, float* dxs,
+                                      float* G, float* ws, cgc_stream_t stream) {
+  if (n <= 0) return 0;
+  if (npad < n) return CGC_EINVAL;
+  JkWeights w;
+  fill_weights(w, lstm, w_att, b_att);
+  return jk_mfma_bwd_params(xs, dout, n, npad, C, w, HS, CS, dxs, G, ws, as_stream(stream));
+}

@@ -25,3 +25,7 @@ struct JkWeights {            // PyTorch nn.LSTM layout, gate order i,f,g,o; [0]
 int jk_mfma_fwd(const float* xs, int n, int npad, int C, const JkWeights& w, float* out, float* HS, float* CS, hipStream_t st);
 int jk_mfma_bwd(const float* xs, const float* dout, int n, int npad, int C, const JkWeights& w, const float* HS, const float* CS,
                 float* dxs, float* DGT, float* INT, hipStream_t st);
+// backward with the parameter gradients accumulated in-kernel: G [2][4H+1][C+2H+1] (same layout as DGT . INT^T)
+int64_t jk_mfma_bwd_ws_floats(int C);
+int jk_mfma_bwd_params(const float* xs, const float* dout, int n, int npad, int C, const JkWeights& w, const float* HS,
+                       const float* CS, float* dxs, float* G, float* ws, hipStream_t st);

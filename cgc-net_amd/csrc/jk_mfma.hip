@@ -36,6 +36,7 @@ struct JkM {
   static constexpr int S_OFF = A_OFF + 2 * 32 + 4;             // score exchange [node half 2][d 2][t 3][32]
   static constexpr int TOTAL = S_OFF + 2 * 2 * 3 * 32;
   static constexpr size_t lds_bytes = sizeof(float) * TOTAL;
+  static constexpr int PG_FLOATS = (8 * 16 + 16 + 1) * 64;        // parameter-gradient partial of one wave
   static_assert(H <= 32 && C % 4 == 0, "one 32-row tile per gate; 16-byte x fragments");
 };
 
@@ -208,10 +209,11 @@ __global__ __launch_bounds__(256, JKM_WAVES) void k_jk_fwd_mfma(const float* __r
 // read out of the SAME LDS image the forward uses, strided: 4-way bank conflicts, irrelevant next to 128 MFMAs), whose
 // accumulator layout hands dh_{t-1} to the next step in registers and dx_t as 16-byte fragments.  Gate gradients and cell
 // inputs are written transposed (DGT / INT, see jk.hip) for the parameter-gradient GEMM.
-template <int C>
+template <int C, bool PG>
 __global__ __launch_bounds__(JKB_THREADS) void k_jk_bwd_mfma(const float* __restrict__ xs, const float* __restrict__ dout, int n, int npad,
                                                      const JkWeights w, const float* __restrict__ HS, const float* __restrict__ CS,
-                                                     float* __restrict__ dxs, float* __restrict__ DGT, float* __restrict__ INT) {
+                                                     float* __restrict__ dxs, float* __restrict__ DGT, float* __restrict__ INT,
+                                                     float* __restrict__ PART) {
   using M = JkM<C>;
   constexpr int H = M::H, XG = M::XG, HG = M::HG, NQ = M::NQ;
   constexpr int NG = 4 * H + 1, NI = C + 2 * H + 1;
@@ -233,9 +235,27 @@ __global__ __launch_bounds__(JKB_THREADS) void k_jk_bwd_mfma(const float* __rest
   float* dgt = DGT + (size_t)d * NG * ktot;
   float* inT = INT + (size_t)d * NI * ktot;
   const int ntiles = npad / 32;
+  // PG: parameter gradients accumulated here.  dW[(g,j)][kin] = sum_node q_g[node][j] * in[node][kin] contracts over the
+  // LANE dimension of the layout above, so q and the cell inputs take one trip through a per-wave LDS tile ([node][36]) to
+  // come back with lane = row / column and the node pair as the MFMA k index.  8 persistent accumulator tiles per wave:
+  // (gate g) x (inputs: h part with the bias column at 31 | x part); attention-weight gradients per lane.
+  float* Qw = lds + M::TOTAL + JKB_TILES * 192 + JKB_TILES * 2 * 3 * XG * 64 * 4 + (size_t)wave * 3 * 32 * 36;
+  float* Iw = Qw + 32 * 36;                       // two input tiles
+  floatx16 dW[PG ? 4 : 1][2];
+  floatx16 wacc;
+  float bacc = 0.f;
+  if (PG) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dW[g][0][r] = 0.f; dW[g][1][r] = 0.f; }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) wacc[r] = 0.f;
+  }
 
   for (int base = blockIdx.x * JKB_TILES; base < ntiles; base += gridDim.x * JKB_TILES) {
     const int node = (base + half) * 32 + l31;
+    if (PG && base * 32 >= n) break;            // padding tiles contribute nothing
     if (base * 32 >= n) {            // all tiles of this workgroup pass are padding columns: they must read as zero in the GEMM
       for (int t = 0; t < 3; ++t) {
         const size_t col = (size_t)t * npad + node;
@@ -362,13 +382,13 @@ __global__ __launch_bounds__(JKB_THREADS) void k_jk_bwd_mfma(const float* __rest
         }
       }
       // ---- cell backward per (node, unit); acc[g] is overwritten with d loss / d pre-activation of gate g
-      if (lhi == 0) {
+      if (!PG && lhi == 0) {
         dgt[(size_t)(4 * H) * ktot + col] = dst;
         inT[(size_t)(C + H) * ktot + col] = 1.f;
       }
 #pragma unroll
       for (int q = 0; q < XG; ++q) {
-        if (8 * q + 4 * lhi < C) {
+        if (!PG && 8 * q + 4 * lhi < C) {
           inT[(size_t)(8 * q + 4 * lhi + 0) * ktot + col] = xt[q].x;
           inT[(size_t)(8 * q + 4 * lhi + 1) * ktot + col] = xt[q].y;
           inT[(size_t)(8 * q + 4 * lhi + 2) * ktot + col] = xt[q].z;
@@ -392,13 +412,54 @@ __global__ __launch_bounds__(JKB_THREADS) void k_jk_bwd_mfma(const float* __rest
           const float qi = dc * gg * gi * (1.f - gi), qf = dc * cprev[r] * gf * (1.f - gf);
           const float qg = dc * gi * (1.f - gg * gg), qo = dh * th * go * (1.f - go);
           acc[0][r] = qi; acc[1][r] = qf; acc[2][r] = qg; acc[3][r] = qo;
-          if (8 * q + u < H && j < H) {
+          if (PG) wacc[r] = fmaf(dst, go * th, wacc[r]);          // d w_att[j] += ds_t * h_t[j]
+          if (!PG && 8 * q + u < H && j < H) {
             dgt[(size_t)(0 * H + j) * ktot + col] = qi;
             dgt[(size_t)(1 * H + j) * ktot + col] = qf;
             dgt[(size_t)(2 * H + j) * ktot + col] = qg;
             dgt[(size_t)(3 * H + j) * ktot + col] = qo;
             inT[(size_t)(C + j) * ktot + col] = hprev[r];
             inT[(size_t)(C + H + 1 + j) * ktot + col] = go * th;
+          }
+        }
+      }
+      if (PG) {
+        if (lhi == 0) bacc += dst;                                // d b_att (one lane half per node)
+        // inputs of this step, node-major: tile 0 = h_{t-1} (+ 1.0 at column 31: the bias column), tile 1 = x_t
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (q < HG) v = make_float4(hprev[4 * q + 0], hprev[4 * q + 1], hprev[4 * q + 2], hprev[4 * q + 3]);
+          if (q == 3 && lhi == 1) v.w = 1.f;
+          *reinterpret_cast<float4*>(Iw + l31 * 36 + 8 * q + 4 * lhi) = v;
+          float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (q < XG) xv = xt[q];
+          *reinterpret_cast<float4*>(Iw + 32 * 36 + l31 * 36 + 8 * q + 4 * lhi) = xv;
+        }
+        __builtin_amdgcn_wave_barrier();
+        float bf[2][16];
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+          bf[0][kk] = Iw[(2 * kk + lhi) * 36 + l31];
+          bf[1][kk] = Iw[32 * 36 + (2 * kk + lhi) * 36 + l31];
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q < HG) v = make_float4(acc[g][4 * q + 0], acc[g][4 * q + 1], acc[g][4 * q + 2], acc[g][4 * q + 3]);
+            *reinterpret_cast<float4*>(Qw + l31 * 36 + 8 * q + 4 * lhi) = v;
+          }
+          __builtin_amdgcn_wave_barrier();
+          float af[16];
+#pragma unroll
+          for (int kk = 0; kk < 16; ++kk) af[kk] = Qw[(2 * kk + lhi) * 36 + l31];
+#pragma unroll
+          for (int kk = 0; kk < 16; ++kk) {
+            dW[g][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk], bf[0][kk], dW[g][0], 0, 0, 0);
+            dW[g][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk], bf[1][kk], dW[g][1], 0, 0, 0);
           }
         }
       }
@@ -448,6 +509,65 @@ __global__ __launch_bounds__(JKB_THREADS) void k_jk_bwd_mfma(const float* __rest
     }
     __syncthreads();
   }
+  if (PG) {       // this wave's partial parameter gradients: [8 tiles x 16 registers | 16 attention registers | bias] x 64 lanes
+    float* pw = PART + ((size_t)d * gridDim.x * JKB_TILES + (size_t)blockIdx.x * JKB_TILES + half) * JkM<C>::PG_FLOATS + lane;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pw[((g * 2 + m) * 16 + r) * 64] = dW[g][m][r];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pw[(128 + r) * 64] = wacc[r];
+    pw[144 * 64] = bacc;
+  }
+}
+
+// parameter-gradient partials -> G [2][4H+1][C+2H+1] (the layout ops.py reads: rows = gate pre-activations then the
+// attention score, columns = x (C) | h_{t-1} (H) | 1 | h_t (H)), two deterministic stages
+__global__ void k_jk_pg_fold(const float* __restrict__ part, int P, int P2, int per, float* __restrict__ tmp) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x, p2 = blockIdx.y, d = blockIdx.z;
+  if (e >= per) return;
+  const float* src = part + ((size_t)d * P + (size_t)p2 * 16) * per + e;
+  const int cnt = min(16, P - p2 * 16);
+  float a = 0.f;
+  for (int k = 0; k < cnt; ++k) a += src[(size_t)k * per];
+  tmp[((size_t)d * P2 + p2) * per + e] = a;
+}
+
+template <int C>
+__global__ void k_jk_pg_finish(const float* __restrict__ tmp, int P2, float* __restrict__ G) {
+  constexpr int H = JkM<C>::H, per = JkM<C>::PG_FLOATS, NG = 4 * H + 1, NI = C + 2 * H + 1;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x, d = blockIdx.y;
+  if (e >= per) return;
+  const int slot = e >> 6, lane = e & 63, lhi = lane >> 5, kin = lane & 31;
+  const float* src = tmp + (size_t)d * P2 * per;
+  if (slot < 128) {
+    const int tile = slot >> 4, r = slot & 15, g = tile >> 1, m = tile & 1;
+    const int j = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+    int col = -1;
+    if (m == 0) col = kin < H ? C + kin : (kin == 31 ? C + H : -1);
+    else col = kin < C ? kin : -1;
+    if (j >= H || col < 0) return;
+    float a = 0.f;
+    for (int k = 0; k < P2; ++k) a += src[(size_t)k * per + e];
+    G[((size_t)d * NG + g * H + j) * NI + col] = a;
+  } else if (kin == 0) {                        // per-lane (= per-node) sums: fold the 32 lanes of this half
+    const int r = slot - 128;
+    if (slot < 144) {
+      const int j = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      if (j >= H) return;
+      float a = 0.f;
+      for (int k = 0; k < P2; ++k)
+        for (int l = 0; l < 32; ++l) a += src[(size_t)k * per + slot * 64 + lhi * 32 + l];
+      G[((size_t)d * NG + 4 * H) * NI + C + H + 1 + j] = a;
+    } else if (lhi == 0 && d == 0) {
+      float a = 0.f;
+      for (int k = 0; k < P2; ++k)
+        for (int l = 0; l < 32; ++l) a += src[(size_t)k * per + slot * 64 + l];
+      G[((size_t)4 * H) * NI + C + H] = a;
+    }
+  }
 }
 
 template <int C>
@@ -476,19 +596,29 @@ int jk_mfma_fwd(const float* xs, int n, int npad, int C, const JkWeights& w, flo
   }
 }
 
-template <int C>
+template <int C, bool PG>
 static int launch_bwd(const float* xs, const float* dout, int n, int npad, const JkWeights& w, const float* HS, const float* CS,
-                      float* dxs, float* DGT, float* INT, hipStream_t st) {
-  const size_t lds = sizeof(float) * (JkM<C>::TOTAL + JKB_TILES * 192) + sizeof(float4) * JKB_TILES * 2 * 3 * JkM<C>::XG * 64;
+                      float* dxs, float* DGT, float* INT, float* G, float* ws, hipStream_t st) {
+  size_t lds = sizeof(float) * (JkM<C>::TOTAL + JKB_TILES * 192) + sizeof(float4) * JKB_TILES * 2 * 3 * JkM<C>::XG * 64;
+  if (PG) lds += sizeof(float) * JKB_TILES * 2 * 3 * 32 * 36;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_jk_bwd_mfma<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_jk_bwd_mfma<C, PG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  int grid = ceil_div(npad / 32, JKB_TILES);
+  int grid = ceil_div(PG ? ceil_div(n, 32) : npad / 32, JKB_TILES);
   if (grid > 256) grid = 256;                 // one workgroup per CU
-  hipLaunchKernelGGL(k_jk_bwd_mfma<C>, dim3(grid), dim3(JKB_THREADS), lds, st, xs, dout, n, npad, w, HS, CS, dxs, DGT, INT);
+  hipLaunchKernelGGL((k_jk_bwd_mfma<C, PG>), dim3(grid), dim3(JKB_THREADS), lds, st, xs, dout, n, npad, w, HS, CS, dxs, DGT, INT, ws);
   CGC_RETURN_IF_LAUNCH_FAILED();
+  if (PG) {
+    constexpr int per = JkM<C>::PG_FLOATS, NG = 4 * JkM<C>::H + 1, NI = C + 2 * JkM<C>::H + 1;
+    const int P = grid * JKB_TILES, P2 = ceil_div(P, 16);
+    float* tmp = ws + (size_t)2 * P * per;
+    (void)hipMemsetAsync(G, 0, sizeof(float) * 2 * NG * NI, st);
+    hipLaunchKernelGGL(k_jk_pg_fold, dim3(ceil_div(per, 256), P2, 2), dim3(256), 0, st, ws, P, P2, per, tmp);
+    hipLaunchKernelGGL(k_jk_pg_finish<C>, dim3(ceil_div(per, 256), 2), dim3(256), 0, st, tmp, P2, G);
+    CGC_RETURN_IF_LAUNCH_FAILED();
+  }
   return 0;
 }
 
@@ -498,9 +628,28 @@ int jk_mfma_bwd(const float* xs, const float* dout, int n, int npad, int C, cons
       npad % (32 * JKB_TILES) != 0)
     return CGC_EINVAL;
   switch (C) {
-    case 8: return launch_bwd<8>(xs, dout, n, npad, w, HS, CS, dxs, DGT, INT, st);
-    case 16: return launch_bwd<16>(xs, dout, n, npad, w, HS, CS, dxs, DGT, INT, st);
-    case 20: return launch_bwd<20>(xs, dout, n, npad, w, HS, CS, dxs, DGT, INT, st);
+    case 8: return launch_bwd<8, false>(xs, dout, n, npad, w, HS, CS, dxs, DGT, INT, nullptr, nullptr, st);
+    case 16: return launch_bwd<16, false>(xs, dout, n, npad, w, HS, CS, dxs, DGT, INT, nullptr, nullptr, st);
+    case 20: return launch_bwd<20, false>(xs, dout, n, npad, w, HS, CS, dxs, DGT, INT, nullptr, nullptr, st);
+    default: return CGC_EINVAL;
+  }
+}
+
+// workspace floats of the fused-parameter-gradient backward: partials of <= 512 waves per direction + their first fold
+int64_t jk_mfma_bwd_ws_floats(int C) {
+  const int64_t per = (8 * 16 + 16 + 1) * 64;
+  (void)C;
+  return 2 * 512 * per + 2 * 32 * per;
+}
+
+int jk_mfma_bwd_params(const float* xs, const float* dout, int n, int npad, int C, const JkWeights& w, const float* HS,
+                       const float* CS, float* dxs, float* G, float* ws, hipStream_t st) {
+  if ((reinterpret_cast<uintptr_t>(xs) & 15u) || (reinterpret_cast<uintptr_t>(dout) & 15u) || (reinterpret_cast<uintptr_t>(dxs) & 15u))
+    return CGC_EINVAL;
+  switch (C) {
+    case 8: return launch_bwd<8, true>(xs, dout, n, npad, w, HS, CS, dxs, nullptr, nullptr, G, ws, st);
+    case 16: return launch_bwd<16, true>(xs, dout, n, npad, w, HS, CS, dxs, nullptr, nullptr, G, ws, st);
+    case 20: return launch_bwd<20, true>(xs, dout, n, npad, w, HS, CS, dxs, nullptr, nullptr, G, ws, st);
     default: return CGC_EINVAL;
   }
 }

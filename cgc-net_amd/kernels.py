@@ -161,6 +161,12 @@ class KernelSpec(object):
         d w_att[dH:(d+1)H] = G_d[4H, C+H+1:], d b_att = G_0[4H, C+H].  DHC [2,2,H,npad] is scratch."""
         raise NotImplementedError
 
+    def jk_bwd_params(self, xs, dout, n, npad, C, lstm, w_att, b_att, HS, CS, dxs, G_out):
+        """DenseJK backward with the parameter gradients delivered directly: dxs [n,3C] and G_out [2, 4H+1, C+2H+1] with
+        the meaning of ``DGT[d] @ INT[d]^T`` in ``jk_bwd`` (entries of the last row that are not parameter gradients are
+        unspecified)."""
+        raise NotImplementedError
+
     # ------------------------------------------------------------------ dense adjacency ops at levels 2-3 (A4, A6)
     def dense_rownorm_fwd(self, A, R, C, out, invd_out, ge1_out):
         """s = rowsum(A); d = max(s,1); out = A/d; invd = 1/d; ge1 = (s >= 1)  (clamp(min=1) of DenseSAGEConv)."""
@@ -489,6 +495,31 @@ class HipKernels(KernelSpec):
         self._chk(self.lib.cgc_jk_lstm_bwd(_ptr(xs), _ptr(dout), n, npad, C, self._ptr_array(lstm), _ptr(w_att), _ptr(b_att),
                                            _ptr(HS), _ptr(CS), _ptr(dxs), _ptr(DGT), _ptr(INT), _ptr(DHC), self._stream()),
                   'cgc_jk_lstm_bwd')
+
+    def jk_bwd_params(self, xs, dout, n, npad, C, lstm, w_att, b_att, HS, CS, dxs, G_out):
+        self._dev(xs, dout, w_att, b_att, HS, CS, dxs, G_out, *lstm)
+        H = 3 * C // 2
+        ng, ni, ktot = 4 * H + 1, C + 2 * H + 1, 3 * npad
+        ws = torch.empty(int(self.lib.cgc_jk_bwd_ws_floats(C)), dtype=torch.float32, device=xs.device)
+        rc = self.lib.cgc_jk_lstm_bwd_params(_ptr(xs), _ptr(dout), n, npad, C, self._ptr_array(lstm), _ptr(w_att), _ptr(b_att),
+                                             _ptr(HS), _ptr(CS), _ptr(dxs), _ptr(G_out), _ptr(ws), self._stream())
+        if rc == 0:
+            return
+        if rc != -1:
+            self._chk(rc, 'cgc_jk_lstm_bwd_params')
+        # unaligned buffers / other channel counts: staged path -- gate gradients and cell inputs transposed, one batched NT
+        # GEMM per direction over K slices of 768 columns, combined deterministically
+        dev = xs.device
+        DGT = torch.empty(2, ng, ktot, dtype=torch.float32, device=dev)
+        INT = torch.empty(2, ni, ktot, dtype=torch.float32, device=dev)
+        DHC = torch.empty(2, 2, H, npad, dtype=torch.float32, device=dev)
+        self.jk_bwd(xs, dout, n, npad, C, lstm, w_att, b_att, HS, CS, dxs, DGT, INT, DHC)
+        kp = 768
+        parts = ktot // kp
+        ws2 = torch.empty(parts, ng * ni, dtype=torch.float32, device=dev)
+        for d in range(2):
+            self.gemm(DGT[d], INT[d], ws2, ng, ni, kp, False, True, ktot, ktot, ni, 1.0, 0.0, None, parts, kp, kp, ng * ni)
+            self.reduce_batch_sum(ws2, G_out[d], parts, ng * ni, 0.0)
 
     # -- dense adjacency ops
     def dense_rownorm_fwd(self, A, R, C, out, invd_out, ge1_out):

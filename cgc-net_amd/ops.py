@@ -449,20 +449,10 @@ class _DenseJK(Function):
         dev = xs.device
         ng, ni, ktot = 4 * H + 1, C + 2 * H + 1, 3 * npad
         dxs = torch.empty_like(xs)
-        DGT = torch.empty(2, ng, ktot, dtype=torch.float32, device=dev)
-        INT = torch.empty(2, ni, ktot, dtype=torch.float32, device=dev)
-        DHC = torch.empty(2, 2, H, npad, dtype=torch.float32, device=dev)
-        K().jk_bwd(xs, _f32c(dout), n, npad, C, lstm, w_att, b_att, HS, CS, dxs, DGT, INT, DHC)
-        # parameter gradients: G_d = DGT[d] @ INT[d]^T, reduced over K slices of 768 columns (deterministic combine);
-        # 768 divides 3*npad and gives >= 2 x 225 workgroups at C3 sizes
-        kp = 768
-        parts = ktot // kp
-        G = torch.empty(2, ng * ni, dtype=torch.float32, device=dev)
-        ws = torch.empty(parts, ng * ni, dtype=torch.float32, device=dev)
-        for d in range(2):
-            K().gemm(DGT[d], INT[d], ws, ng, ni, kp, False, True, ktot, ktot, ni, 1.0, 0.0, None, parts, kp, kp, ng * ni)
-            K().reduce_batch_sum(ws, G[d], parts, ng * ni, 0.0)
-        G = G.view(2, ng, ni)
+        # parameter gradients: G_d = (gate gradients | score gradient) x (x_t | h_{t-1} | 1 | h_t)^T, accumulated inside the
+        # backward kernel on the matrix cores (staged through transposed buffers + a GEMM only on the unaligned fallback)
+        G = torch.empty(2, ng, ni, dtype=torch.float32, device=dev)
+        K().jk_bwd_params(xs, _f32c(dout), n, npad, C, lstm, w_att, b_att, HS, CS, dxs, G)
         grads = []
         for d in range(2):
             grads += [G[d, :4 * H, :C], G[d, :4 * H, C:C + H], G[d, :4 * H, C + H], G[d, :4 * H, C + H]]

@@ -158,6 +158,15 @@ int cgc_jk_lstm_fwd(const float* xs, int n, int npad, int C, const float* const*
 int cgc_jk_lstm_bwd(const float* xs, const float* dout, int n, int npad, int C, const float* const* lstm,
                     const float* w_att, const float* b_att, const float* HS, const float* CS, float* dxs, float* DGT,
                     float* INT, float* DHC, cgc_stream_t stream);
+/* The same backward with the parameter gradients accumulated in-kernel (no DGT / INT staging, no GEMM):
+ * G [2][4H+1][C+2H+1] = what DGT[d] . INT[d]^T would be (rows: gate pre-activations i,f,g,o then the attention score;
+ * columns: x_t (C) | h_{t-1} (H) | 1 | h_t (H); of the last row only the entries that are parameter gradients are
+ * defined, the rest is 0).  ws: cgc_jk_bwd_ws_floats(C) floats.  Returns CGC_EINVAL (nothing launched) when the buffers
+ * are not 16-byte aligned: use cgc_jk_lstm_bwd then. */
+int64_t cgc_jk_bwd_ws_floats(int C);
+int cgc_jk_lstm_bwd_params(const float* xs, const float* dout, int n, int npad, int C, const float* const* lstm,
+                           const float* w_att, const float* b_att, const float* HS, const float* CS, float* dxs, float* G,
+                           float* ws, cgc_stream_t stream);
 
 /* ---- A4/A6 at levels 2-3 (dense, real-valued adjacency that carries gradient) */
 int cgc_dense_rownorm_fwd(const float* A, int R, int C, float* out, float* invd, float* ge1, cgc_stream_t stream);

@@ -345,6 +345,16 @@ class TorchKernels(KernelSpec):
             DGT[d][:, :ni] = g.to(DGT.device)
             INT[d][:, :ni] = torch.eye(ni, device=INT.device)
 
+
+    def jk_bwd_params(self, xs, dout, n, npad, C, lstm, w_att, b_att, HS, CS, dxs, G_out):
+        H = 3 * C // 2
+        ng, ni, ktot = 4 * H + 1, C + 2 * H + 1, 3 * npad
+        DGT, INT = torch.zeros(2, ng, ktot, device=xs.device), torch.zeros(2, ni, ktot, device=xs.device)
+        DHC = torch.zeros(2, 2, H, npad, device=xs.device)
+        self.jk_bwd(xs, dout, n, npad, C, lstm, w_att, b_att, HS, CS, dxs, DGT, INT, DHC)
+        for d in range(2):
+            G_out[d].copy_(DGT[d] @ INT[d].t())
+
     # ------------------------------------------------------------------ dense adjacency ops
     def dense_rownorm_fwd(self, A, R, C, out, invd_out, ge1_out):
         a = A.reshape(R, C)

@@ -437,13 +437,19 @@ def test_dense_jk_kernels(C, n):
         DHC = torch.empty(2, 2, H, npad, device=dev)
         K_.jk_bwd(t(xs), dout, n, npad, C, [t(v) for v in lstm], t(w_att), t(b_att), HS, CS, dxs, DGT, INT, DHC)
         G = torch.stack([DGT[d].double().cpu() @ INT[d].double().cpu().t() for d in range(2)])
-        G[:, :4 * H, C + H + 1:] = 0            # unused corner blocks of the factorisation
-        G[:, 4 * H, :C + H] = 0
-        G[1, 4 * H, C + H] = 0
-        res[name] = dict(out=out, HS=HS[:, :n], CS=CS[:, :n], dxs=dxs, G=G)
+        # the same backward with the parameter gradients accumulated in-kernel
+        dxs2 = torch.empty(n, 3 * C, device=dev)
+        G2 = torch.full((2, 4 * H + 1, C + 2 * H + 1), 7.0, device=dev)
+        K_.jk_bwd_params(t(xs), dout, n, npad, C, [t(v) for v in lstm], t(w_att), t(b_att), HS, CS, dxs2, G2)
+        G2 = G2.double().cpu()
+        for g_ in (G, G2):
+            g_[:, :4 * H, C + H + 1:] = 0       # unused corner blocks of the factorisation
+            g_[:, 4 * H, :C + H] = 0
+            g_[1, 4 * H, C + H] = 0
+        res[name] = dict(out=out, HS=HS[:, :n], CS=CS[:, :n], dxs=dxs, G=G, dxs2=dxs2, G2=G2)
     close(res['ref']['out'], want_out, 1e-5, 'twin vs torch.nn.LSTM')
     for k in res['ref']:
-        close(res['hip'][k], res['ref'][k], 2e-4 if k == 'G' else 2e-5, 'jk ' + k)
+        close(res['hip'][k], res['ref'][k], 2e-4 if k in ('G', 'G2') else 2e-5, 'jk ' + k)
 
 
 # ------------------------------------------------------------------ F2: cell-graph construction (radius k-NN)

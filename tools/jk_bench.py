@@ -46,5 +46,8 @@ for n in rows:
     DHC = torch.empty(2, 2, H, npad, device=dev)
     tf = timeit(lambda: K.jk_fwd(xs, n, npad, C, lstm, w_att, b_att, out, HS, CS))
     tb = timeit(lambda: K.jk_bwd(xs, dout, n, npad, C, lstm, w_att, b_att, HS, CS, dxs, DGT, INT, DHC))
+    G = torch.empty(2, ng, ni, device=dev)
+    tp = timeit(lambda: K.jk_bwd_params(xs, dout, n, npad, C, lstm, w_att, b_att, HS, CS, dxs, G))
     fl = 2.0 * 4 * H * (C + H) * 3 * 2 * n          # gate products, forward
-    print('rows %6d: fwd %7.1f us (%5.1f TFLOP/s)   bwd %7.1f us' % (n, tf, fl / tf / 1e6, tb))
+    print('rows %6d: fwd %7.1f us (%5.1f TFLOP/s)   bwd (staged gradients, without its GEMMs) %7.1f us   bwd with parameter '
+          'gradients in-kernel %7.1f us' % (n, tf, fl / tf / 1e6, tb, tp))
