@@ -358,16 +358,17 @@ class SoftPoolingGcnEncoder(nn.Module):
         x = data.x
         emb_blk, pool_blk = self.GCN_embed_1, self.GCN_pool_1
         agg0 = ops.aggregate(x, g, emb_blk.mean_aggregation)     # shared by both blocks' first conv
+        outs_p = None
         if _pairable(emb_blk, pool_blk):
             outs_e, outs_p = run_blocks_paired(emb_blk, pool_blk, x, lambda h: ops.aggregate(h, g, True), g.padded_rows, agg0)
-            embed, s = emb_blk._tail(outs_e), pool_blk._tail(outs_p, softmax=True)
+            embed = emb_blk._tail(outs_e)
         else:
-            embed, s = emb_blk.forward_graph(x, g, agg0), None
+            embed = emb_blk.forward_graph(x, g, agg0)
         if self.jk:
             embed = self.jk1(embed)
         readout = ops.segment_max(embed, g.gptr, g.B, g.nmax)
-        if s is None:
-            s = pool_blk.forward_graph(x, g, agg0, softmax=True)
+        # the assignment matrix last: the wide aggregation A*S right behind it finds S's tail in the Infinity Cache
+        s = pool_blk._tail(outs_p, softmax=True) if outs_p is not None else pool_blk.forward_graph(x, g, agg0, softmax=True)
         if self.collect_assign:
             self.assign_matrix.append(self._pad_assign(s.detach(), g))
         xn, an = ops.diff_pool_sparse(embed, s, g)
@@ -394,10 +395,10 @@ class SoftPoolingGcnEncoder(nn.Module):
         xf = x.reshape(B * C, -1)
         agg0 = aggregate(xf)
         pool_blk = getattr(self, 'GCN_pool_%d' % level) if level < 3 else None
-        s = None
+        outs_p = None
         if pool_blk is not None and _pairable(emb_blk, pool_blk):
             outs_e, outs_p = run_blocks_paired(emb_blk, pool_blk, xf, aggregate, B * C, agg0)
-            embed, s = emb_blk._tail(outs_e), pool_blk._tail(outs_p, softmax=True)
+            embed = emb_blk._tail(outs_e)
         else:
             embed = emb_blk.run_rows(xf, aggregate, B * C, agg0)
         if self.jk:
@@ -405,8 +406,7 @@ class SoftPoolingGcnEncoder(nn.Module):
         readout = ops.segment_max(embed, uniform_ptr(B, C, x.device), B, C)
         if level == 3:
             return readout, None, None
-        if s is None:
-            s = pool_blk.run_rows(xf, aggregate, B * C, agg0, None, True)
+        s = pool_blk._tail(outs_p, softmax=True) if outs_p is not None else pool_blk.run_rows(xf, aggregate, B * C, agg0, None, True)
         if self.collect_assign:
             self.assign_matrix.append(s.detach().view(B, C, -1))
         xn, an = ops.diff_pool_dense(embed.view(B, C, -1), adj, s.view(B, C, -1))
