@@ -149,6 +149,17 @@ __device__ __forceinline__ void wide_batch(const int* __restrict__ col, const in
   for (int u = 0; u < CNT; ++u) acc += ww[u] * xv[u];
 }
 
+// row tail (wave-uniform count 0..N): dispatch to the batch of exactly that size
+template <int N, bool VAL, bool PERM, bool PRE>
+__device__ __forceinline__ void wide_tail(int cnt, const int* __restrict__ col, const int* __restrict__ perm,
+                                          const float* __restrict__ val, const float* __restrict__ pre,
+                                          const float* __restrict__ xl, int W, int k, wide_f4& acc) {
+  if constexpr (N > 0) {
+    if (cnt == N) wide_batch<N, VAL, PERM, PRE>(col, perm, val, pre, xl, W, k, acc);
+    else wide_tail<N - 1, VAL, PERM, PRE>(cnt, col, perm, val, pre, xl, W, k, acc);
+  }
+}
+
 template <int U, bool VAL, bool PERM, bool PRE>
 __global__ __launch_bounds__(256) void k_spmm_wide(const int* __restrict__ rowptr, const int* __restrict__ col,
                                                    const int* __restrict__ perm, const float* __restrict__ val,
@@ -199,19 +210,8 @@ __global__ __launch_bounds__(256) void k_spmm_wide(const int* __restrict__ rowpt
     const int e = rowptr[r + 1];
     f4v acc = {0.f, 0.f, 0.f, 0.f};
     int k = s;
-    static_assert(U == 9, "the tail switch below enumerates 1..U-1");
     for (; k + U <= e; k += U) wide_batch<U, VAL, PERM, PRE>(col, perm, val, pre, xl, W, k, acc);
-    switch (e - k) {                         // row tail (wave-uniform): exactly as many gathers as entries left
-      case 1: wide_batch<1, VAL, PERM, PRE>(col, perm, val, pre, xl, W, k, acc); break;
-      case 2: wide_batch<2, VAL, PERM, PRE>(col, perm, val, pre, xl, W, k, acc); break;
-      case 3: wide_batch<3, VAL, PERM, PRE>(col, perm, val, pre, xl, W, k, acc); break;
-      case 4: wide_batch<4, VAL, PERM, PRE>(col, perm, val, pre, xl, W, k, acc); break;
-      case 5: wide_batch<5, VAL, PERM, PRE>(col, perm, val, pre, xl, W, k, acc); break;
-      case 6: wide_batch<6, VAL, PERM, PRE>(col, perm, val, pre, xl, W, k, acc); break;
-      case 7: wide_batch<7, VAL, PERM, PRE>(col, perm, val, pre, xl, W, k, acc); break;
-      case 8: wide_batch<8, VAL, PERM, PRE>(col, perm, val, pre, xl, W, k, acc); break;
-      default: break;
-    }
+    wide_tail<U - 1, VAL, PERM, PRE>(e - k, col, perm, val, pre, xl, W, k, acc);   // exactly as many gathers as entries left
     if (post != nullptr) acc *= post[r];
     __builtin_nontemporal_store(acc, reinterpret_cast<f4v*>(out + (size_t)r * W + c0));
     s = e;
