@@ -299,6 +299,41 @@ def fuse_sample(pos, k, rng, farthest_frac=0.7):
     return np.sort(np.concatenate([chosen, extra]))
 
 
+def sample_nodes_batch(pos, counts, ratio, method='fuse', generator=None, farthest_frac=0.7, start=None):
+    """Node sub-sampling for a batch of graphs on the device (dataflow/data.py:195-225): per graph keep
+    ``int(n_g * ratio)`` nodes -- 'farthest': farthest-point sampling; 'fuse': 70 % farthest-point + 30 % uniform random
+    from the rest; 'random': uniform.  ``pos`` [n,2] float32 on the GPU (graphs concatenated), ``counts`` python list of
+    nodes per graph.  Returns (indices int64 [sum k_g] ascending within each graph, list k_g).  Farthest-point picks run
+    in csrc/fps.hip from the coordinates (the reference reads rows of an n x n int16 distance table); the first pick of a
+    graph is drawn at random as in the reference (``start`` fixes it, for tests)."""
+    from . import kernels
+    K = kernels.get()
+    dev, B = pos.device, len(counts)
+    ks = [int(c * ratio) for c in counts]
+    kf = [int(k * farthest_frac) if method == 'fuse' else (k if method == 'farthest' else 0) for k in ks]
+    gptr_h = np.concatenate([[0], np.cumsum(counts)])
+    gptr = torch.tensor(gptr_h, dtype=torch.int32, device=dev)
+    gid = torch.repeat_interleave(torch.arange(B, device=dev), torch.tensor(counts, device=dev))
+    taken = torch.zeros(int(gptr_h[-1]), dtype=torch.bool, device=dev)
+    if sum(kf) > 0:
+        if start is None:
+            start = [int(torch.randint(max(c, 1), (1,), generator=generator)) for c in counts]
+        optr = torch.tensor(np.concatenate([[0], np.cumsum(kf)]), dtype=torch.int32, device=dev)
+        far = torch.empty(sum(kf), dtype=torch.int32, device=dev)
+        K.farthest_point_sample(pos[:, :2].to(torch.float32).contiguous(), gptr, B, max(counts),
+                                torch.tensor(start, dtype=torch.int32, device=dev), optr, far)
+        taken[far.long()] = True
+    need = [k - f for k, f in zip(ks, kf)]
+    if sum(need) > 0:
+        # uniform without replacement from the rest: random keys, nodes already taken pushed to the end of their graph
+        key = torch.rand(taken.shape[0], device=dev, generator=generator) + taken.to(torch.float32) * 2.0
+        order = torch.argsort(gid.to(torch.float32) * 4.0 + key)         # graph-major, random within a graph
+        rank = torch.arange(taken.shape[0], device=dev) - gptr[:-1].long()[gid[order]]
+        pick = order[rank < torch.tensor(need, device=dev)[gid[order]]]
+        taken[pick] = True
+    return torch.nonzero(taken).squeeze(1), ks
+
+
 def partition_by_nodes(data_list, num_parts):
     """Contiguous split of a list of Data into <= num_parts chunks balanced by cumulative node count.
 

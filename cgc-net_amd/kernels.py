@@ -40,6 +40,12 @@ class KernelSpec(object):
         node offset gptr[g] of its graph, the edges of graph g being [eptr[g], eptr[g+1]) (None: skipped)."""
         raise NotImplementedError
 
+    def farthest_point_sample(self, pos, gptr, num_graphs, max_nodes, start, optr, out):
+        """Farthest-point sampling per graph (FarthestSampler, common/utils.py:187-197, on coordinates instead of the
+        distance table): pos [n,2] f32, gptr int32 [B+1], start int32 [B] first pick (local index), optr int32 [B+1]
+        offsets of the picks, out int32 [optr[B]] global node ids in pick order; ties -> lowest index."""
+        raise NotImplementedError
+
     def radius_knn(self, pos, gptr, num_graphs, r, k, loop):
         """Cell-graph construction for a batch of graphs (torch_cluster.radius_graph(pos, r, None, loop, k) per graph,
         dataflow/data.py:348): pos [n,2] f32, gptr int32 [B+1].  Per node its <= k nearest others within r (+ itself iff
@@ -308,6 +314,12 @@ class HipKernels(KernelSpec):
         self._chk(self.lib.cgc_collate(_ptr(x), x.shape[0], x.shape[1], _ptr(mean), _ptr(std), _ptr(gptr), num_graphs,
                                        _ptr(batch_out), _ptr(edge_index), ctypes.c_int64(E), _ptr(eptr), self._stream()),
                   'cgc_collate')
+
+    def farthest_point_sample(self, pos, gptr, num_graphs, max_nodes, start, optr, out):
+        self._dev(pos, gptr, start, optr, out)
+        assert pos.dtype == torch.float32 and pos.is_contiguous() and pos.shape[1] == 2
+        self._chk(self.lib.cgc_farthest_point_sample(_ptr(pos), _ptr(gptr), num_graphs, max_nodes, _ptr(start), _ptr(optr),
+                                                     _ptr(out), self._stream()), 'cgc_farthest_point_sample')
 
     def radius_knn(self, pos, gptr, num_graphs, r, k, loop):
         self._dev(pos, gptr)

@@ -48,6 +48,15 @@ int cgc_csr_build(const int64_t* edge_index, int64_t E, int n, int add_diag,
 int cgc_collate(float* x, int n, int F, const float* mean, const float* stdv, const int* gptr, int B, int64_t* batch,
                 int64_t* edge_index, int64_t E, const int* eptr, cgc_stream_t stream);
 
+/* ---- F3 (node samplers in front of graph construction): farthest-point sampling on the nucleus coordinates for a
+ * batch of graphs.  Replaces FarthestSampler (common/utils.py:187-197: k argmax / minimum passes over rows of a
+ * precomputed n x n int16 distance table) inside the 'farthest' / 'fuse' samplers (dataflow/data.py:195-225); distances
+ * are formed from pos (fp64, ties -> lowest index as numpy.argmax), no table.  pos [n,2] f32; gptr [B+1]; start [B] = first
+ * pick of each graph (local index; the reference draws it at random); optr [B+1] = offsets of each graph's picks in out
+ * (k_g = optr[g+1]-optr[g] <= n_g); out int32 GLOBAL node ids in pick order.  max_nodes = largest graph (<= 16384). */
+int cgc_farthest_point_sample(const float* pos, const int* gptr, int B, int max_nodes, const int* start, const int* optr,
+                              int* out, cgc_stream_t stream);
+
 /* ---- F2 (the step before the path): cell-graph construction.  Replaces torch_cluster.radius_graph(pos, r, None, loop,
  * max_num_neighbors) = cKDTree.query(k+1, distance_upper_bound = r+1e-8) per graph on the host (dataflow/data.py:246,255,
  * 297,348; dataflow/prepare_cv_dataset.py:102) for a whole batch of graphs: pos [n,2] f32, gptr [B+1] first node of each

@@ -88,6 +88,26 @@ class TorchKernels(KernelSpec):
             ep = eptr.long()
             edge_index += torch.repeat_interleave(gp[:-1], ep[1:] - ep[:-1]).unsqueeze(0)
 
+    def farthest_point_sample(self, pos, gptr, num_graphs, max_nodes, start, optr, out):
+        """common/utils.py:187-197 with the distance-table rows replaced by squared coordinate distances (float64)."""
+        import numpy as np
+        p = pos.detach().cpu().numpy().astype(np.float64)
+        gp, op, st = gptr.cpu().numpy(), optr.cpu().numpy(), start.cpu().numpy()
+        res = np.zeros(int(op[-1]), dtype=np.int32)
+        for g in range(num_graphs):
+            lo, hi, k = int(gp[g]), int(gp[g + 1]), int(op[g + 1] - op[g])
+            if hi <= lo or k <= 0:
+                continue
+            q = p[lo:hi]
+            cur = min(max(int(st[g]), 0), hi - lo - 1)
+            dist = np.full(hi - lo, np.inf)
+            for i in range(k):
+                res[op[g] + i] = lo + cur
+                dx, dy = q[:, 0] - q[cur, 0], q[:, 1] - q[cur, 1]
+                dist = np.minimum(dist, dx * dx + dy * dy)
+                cur = int(dist.argmax())
+        out.copy_(torch.from_numpy(res).to(out.device))
+
     def radius_knn(self, pos, gptr, num_graphs, r, k, loop):
         """cKDTree.query(k+1, distance_upper_bound=r+1e-8) per graph (torch_cluster 1.4.2's CPU radius_graph, SURVEY B.5;
         call site dataflow/data.py:348), graph by graph with global node ids; neighbours by (distance, index)."""

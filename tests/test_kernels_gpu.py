@@ -544,3 +544,43 @@ def test_model_step_from_device_front_end():
     _, l_host = model(Batch.from_data_list(items).to(DEV))
     _, l_dev = model(Batch.from_data_list([Data(x=d.x, pos=d.pos, y=d.y) for d in items], device=DEV, knn=(100.0, 8)))
     assert abs(l_host.item() - l_dev.item()) <= 1e-6 * max(1.0, abs(l_host.item()))
+
+
+# ------------------------------------------------------------------ F3: node samplers (farthest-point sampling)
+@pytest.mark.parametrize('counts,frac', [([300], 0.5), ([1800, 1500, 2100, 7], 0.5), ([11404, 9000], 0.35), ([16000], 0.5)])
+def test_farthest_point_sampling_matches_the_host_loop(counts, frac):
+    """csrc/fps.hip against the reference's FarthestSampler loop (common/utils.py:187-197) on coordinate distances."""
+    rng = np.random.RandomState(len(counts) + counts[0])
+    n, B = sum(counts), len(counts)
+    pos = torch.from_numpy(rng.uniform(0.0, 3000.0, size=(n, 2)).astype(np.float32))
+    gptr = torch.tensor(np.cumsum([0] + counts), dtype=torch.int32)
+    ks = [int(c * frac) for c in counts]
+    optr = torch.tensor(np.cumsum([0] + ks), dtype=torch.int32)
+    start = torch.tensor([int(rng.randint(c)) for c in counts], dtype=torch.int32)
+    want, got = torch.zeros(sum(ks), dtype=torch.int32), torch.zeros(sum(ks), dtype=torch.int32, device=DEV)
+    REF.farthest_point_sample(pos, gptr, B, max(counts), start, optr, want)
+    hip().farthest_point_sample(g(pos), g(gptr), B, max(counts), g(start), g(optr), got)
+    assert torch.equal(got.cpu(), want)                             # the same picks in the same order
+
+
+def test_fuse_sampler_structure():
+    """'fuse' = 70 % farthest-point + 30 % uniform from the rest (dataflow/data.py:210-219): counts, disjointness,
+    per-graph membership; the farthest part reproduces the host loop for the same first pick."""
+    from cgc_net_amd.data import sample_nodes_batch
+    rng = np.random.RandomState(5)
+    counts = [900, 1200, 64]
+    pos = torch.from_numpy(rng.uniform(0.0, 2000.0, size=(sum(counts), 2)).astype(np.float32))
+    gen = torch.Generator(device=DEV)
+    gen.manual_seed(1)
+    idx, ks = sample_nodes_batch(g(pos), counts, 0.5, 'fuse', generator=gen, start=[3, 5, 7])
+    assert ks == [450, 600, 32] and idx.numel() == sum(ks) and torch.unique(idx).numel() == idx.numel()
+    gptr = np.cumsum([0] + counts)
+    idx_c = idx.cpu().numpy()
+    for b in range(3):
+        mine = idx_c[(idx_c >= gptr[b]) & (idx_c < gptr[b + 1])]
+        assert len(mine) == ks[b]
+        kf = int(ks[b] * 0.7)
+        far = torch.zeros(kf, dtype=torch.int32)
+        REF.farthest_point_sample(pos[gptr[b]:gptr[b + 1]], torch.tensor([0, counts[b]], dtype=torch.int32), 1, counts[b],
+                                  torch.tensor([[3, 5, 7][b]], dtype=torch.int32), torch.tensor([0, kf], dtype=torch.int32), far)
+        assert set((far.numpy() + gptr[b]).tolist()) <= set(mine.tolist())
