@@ -1,0 +1,125 @@
+"""Checkpoint interchange and the evaluation protocol of the reference.
+
+* checkpoints: the dict ``train.py:202-207`` saves -- ``{'epoch', 'loss', 'state_dict', 'optimizer', 'val_acc'}`` through
+  ``common/utils.py:82-94`` (``weight.pth.tar``, copied to ``model_best.pth.tar`` when best).  ``state_dict`` keys are the
+  reference's (identical here, tests/test_abi_and_host_cpu.py); a checkpoint written from the wrapped model carries a
+  leading ``module.``.
+* image-level result: majority vote of the patch predictions of an image (``common/metric.py:20-50``).
+* ``evaluate``: ``train.py:21-91`` -- logits averaged over ``test_time`` re-samplings of the graphs
+  (``dataset.set_val_epoch(i)``), patch accuracy from the averaged logits, image / binary accuracy from the votes of every
+  pass.
+"""
+import collections
+import os
+import shutil
+
+import numpy as np
+import torch
+
+
+# ------------------------------------------------------------------ checkpoints (common/utils.py:82-94, train.py:202-207)
+def save_checkpoint(state, is_best, fpath='checkpoint.pth.tar'):
+    d = os.path.dirname(fpath)
+    if d:
+        os.makedirs(d, exist_ok=True)
+    torch.save(state, fpath)
+    if is_best:
+        shutil.copy(fpath, os.path.join(d, 'model_best.pth.tar'))
+
+
+def load_checkpoint(fpath, map_location='cpu'):
+    if not os.path.isfile(fpath):
+        raise ValueError("=> No checkpoint found at '%s'" % fpath)
+    return torch.load(fpath, map_location=map_location, weights_only=False)
+
+
+def checkpoint_state(model, optimizer, epoch, loss, val_acc):
+    """The dict of train.py:202-207 (``model`` may be the DataParallel wrapper: its ``.module`` is saved, as at :204)."""
+    net = model.module if hasattr(model, 'module') else model
+    return {'epoch': epoch + 1, 'loss': loss, 'state_dict': net.state_dict(), 'optimizer': optimizer.state_dict(),
+            'val_acc': val_acc}
+
+
+def load_reference_state(model, checkpoint, strict=True):
+    """Load a reference-trained checkpoint (the dict above, or a bare state_dict; keys optionally prefixed ``module.``)."""
+    sd = checkpoint['state_dict'] if isinstance(checkpoint, dict) and 'state_dict' in checkpoint else checkpoint
+    sd = collections.OrderedDict((k[7:] if k.startswith('module.') else k, v) for k, v in sd.items())
+    net = model.module if hasattr(model, 'module') else model
+    return net.load_state_dict(sd, strict=strict)
+
+
+# ------------------------------------------------------------------ image-level vote (common/metric.py:20-50)
+class ImageLevelVote(object):
+    """``ground_truth``: names like ``<image>_grade_<1|2|3>`` (the reference's GROUND_TRUTH lists) or a dict image -> class."""
+
+    def __init__(self, ground_truth):
+        if isinstance(ground_truth, dict):
+            self.imglist = dict(ground_truth)
+        else:
+            self.imglist = {name.split('_grade')[0]: int(name.split('_')[-1]) - 1 for name in ground_truth}
+        self.prediction = collections.defaultdict(list)
+
+    @staticmethod
+    def _image_of(patch_name):
+        return patch_name.split('/')[-1].split('_grade')[0]
+
+    def patch_result(self, name, label):
+        self.prediction[self._image_of(name)].append(int(label))
+
+    def batch_patch_result(self, names, labels):
+        for name, label in zip(names, labels):
+            self.patch_result(name, label)
+
+    def final_result(self):
+        gt, result = [], []
+        for key, value in self.prediction.items():
+            gt.append(self.imglist[key])
+            result.append(int(np.argmax([value.count(0), value.count(1), value.count(2)])))
+        gt, result = np.asarray(gt), np.asarray(result)
+        acc = float((gt == result).mean()) if len(gt) else 0.0
+        binary_acc = float(((gt > 0) == (result > 0)).mean()) if len(gt) else 0.0
+        return acc, binary_acc
+
+
+# ------------------------------------------------------------------ evaluate (train.py:21-91)
+def _forward_local(dp, chunk):
+    """Forward of a DataParallel wrapper on a list that is ALREADY this rank's chunk."""
+    keep, dp.shard_input = dp.shard_input, False
+    try:
+        return dp(chunk)
+    finally:
+        dp.shard_input = keep
+
+
+def evaluate(loader, model, vote, test_time=1, max_num_examples=None, batch_size=None):
+    """``loader`` yields lists of Data carrying ``.y`` and ``.patch_idx`` (index into ``loader.dataset.idxlist``)."""
+    was_training = model.training
+    model.eval()
+    pred_n, labels_n = [], []
+    with torch.no_grad():
+        for rep in range(test_time):
+            if hasattr(loader.dataset, 'set_val_epoch'):
+                loader.dataset.set_val_epoch(rep)
+            preds, labels = [], []
+            for batch_idx, data in enumerate(loader):
+                if hasattr(model, 'local_chunk'):            # parallel.DataParallel: this rank scores its chunk of the list
+                    data = model.local_chunk(data)
+                    ypred = _forward_local(model, data)
+                else:                                        # bare module: collate here
+                    from .data import Batch
+                    dev = next(model.parameters()).device
+                    ypred = model(Batch.from_data_list(data).to(dev))
+                names = [loader.dataset.idxlist[int(d.patch_idx)] for d in data]
+                labels.append(torch.cat([d.y.reshape(-1) for d in data]).cpu().numpy())
+                vote.batch_patch_result(names, torch.max(ypred, 1)[1].cpu().numpy())
+                preds.append(ypred.detach().cpu().numpy())
+                if max_num_examples is not None and (batch_idx + 1) * (batch_size or len(data)) > max_num_examples:
+                    break
+            pred_n.append(np.concatenate(preds, 0)[..., np.newaxis])
+            labels_n.append(np.concatenate(labels, 0)[..., np.newaxis])
+    pred = np.argmax(np.mean(np.concatenate(pred_n, -1), -1), 1)
+    lab = np.mean(np.hstack(labels_n), -1)
+    img_acc, binary_acc = vote.final_result()
+    if was_training:
+        model.train()
+    return {'patch_acc': float((lab == pred).mean()), 'img_acc': img_acc, 'binary_acc': binary_acc}

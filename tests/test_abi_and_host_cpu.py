@@ -127,3 +127,75 @@ def test_device_collate_front_end_matches_host_collate(torch_kernels):
     key = lambda e: sorted(zip(e[0].tolist(), e[1].tolist()))
     assert key(built.edge_index) == key(host.edge_index)
     assert torch.equal(built.x, torch.cat([d.x for d in items]))
+
+
+# ------------------------------------------------------------------ F4: checkpoint interchange + evaluation protocol
+def test_image_level_vote_matches_reference_fixture():
+    """evalio.ImageLevelVote against vectors produced by the reference's common/metric.py (tests/golden/make_vote_golden.py)."""
+    import json
+    from cgc_net_amd import evalio
+    cases = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'vote_cases.json')))
+    assert len(cases) >= 6
+    for c in cases:
+        v = evalio.ImageLevelVote(c['ground_truth'])
+        half = len(c['patches']) // 2
+        for nm, lb in zip(c['patches'][:half], c['labels'][:half]):
+            v.patch_result(nm, lb)
+        v.batch_patch_result(c['patches'][half:], c['labels'][half:])
+        acc, bacc = v.final_result()
+        assert abs(acc - c['acc']) < 1e-12 and abs(bacc - c['binary_acc']) < 1e-12
+
+
+def test_checkpoint_roundtrip_and_reference_key_layout(tmp_path, torch_kernels):
+    """The dict of train.py:202-207 through save/load (common/utils.py:82-94); a checkpoint saved from the wrapped model
+    (keys prefixed 'module.') loads into a bare model; a reference-generated state_dict (golden fixture) loads strictly."""
+    from cgc_net_amd import evalio
+    cfg, _, sd, _, _, _ = load_case('tiny_shipped')
+    model = build_model(network.SoftPoolingGcnEncoder, cfg)
+    evalio.load_reference_state(model, sd)                    # the fixture's state_dict was written by the reference's own model
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
+    state = evalio.checkpoint_state(model, opt, epoch=4, loss=0.5, val_acc=0.75)
+    assert set(state) == {'epoch', 'loss', 'state_dict', 'optimizer', 'val_acc'} and state['epoch'] == 5
+    f = os.path.join(str(tmp_path), 'run', 'weight.pth.tar')
+    evalio.save_checkpoint(state, True, f)
+    assert os.path.isfile(os.path.join(str(tmp_path), 'run', 'model_best.pth.tar'))
+    ck = evalio.load_checkpoint(f)
+    other = build_model(network.SoftPoolingGcnEncoder, cfg)
+    with torch.no_grad():
+        for p in other.parameters():
+            p.add_(1.0)
+    wrapped = {'state_dict': {'module.' + k: v for k, v in ck['state_dict'].items()}}
+    evalio.load_reference_state(other, wrapped)
+    for (k, a), (_, b) in zip(sorted(model.state_dict().items()), sorted(other.state_dict().items())):
+        assert torch.equal(a, b), k
+    with pytest.raises(ValueError):
+        evalio.load_checkpoint(os.path.join(str(tmp_path), 'missing.pth.tar'))
+
+
+def test_evaluate_protocol(torch_kernels):
+    """train.py:21-91: logits averaged over test_time passes, votes collected from every pass."""
+    from cgc_net_amd import evalio
+    ds = SyntheticCellGraphs(6, 40, 16, base_seed=1)
+    ds.idxlist = ['/x/img%d_grade_%d_patch0.pt' % (i // 2, 1 + i // 2) for i in range(6)]
+
+    class WithIdx(torch.utils.data.Dataset):
+        idxlist = ds.idxlist
+
+        def __len__(self):
+            return 6
+
+        def __getitem__(self, i):
+            d = ds[i]
+            d.patch_idx = torch.tensor([i])
+            return d
+
+        def set_val_epoch(self, e):
+            self.epoch = e
+    loader = DataListLoader(WithIdx(), batch_size=3)
+    torch.manual_seed(0)
+    model = network.SoftPoolingGcnEncoder(600, 16, 20, 20, True, True, 20, 3, 0.1, [50], concat=True, load_data_sparse=True)
+    vote = evalio.ImageLevelVote(['img0_grade_1', 'img1_grade_2', 'img2_grade_3'])
+    res = evalio.evaluate(loader, model, vote, test_time=2)
+    assert set(res) == {'patch_acc', 'img_acc', 'binary_acc'} and all(0.0 <= v <= 1.0 for v in res.values())
+    assert sum(len(v) for v in vote.prediction.values()) == 12 and loader.dataset.epoch == 1     # 6 patches x 2 passes
+    assert model.training                                                                     # mode restored
