@@ -12,6 +12,7 @@ PROTOTYPES = {
     'cgc_radius_knn': [P, P, I, I, F, I, I, P, P, P, P, P],
     'cgc_knn_emit_edges': [P, P, I, I, L, P, P],
     'cgc_edge_renorm': [P, P, I, F, P, P],
+    'cgc_csr_transpose_vals': [P, P, P, I, P, P],
     'cgc_csr_invdeg': [P, P, I, P, P],
     'cgc_spmm': [P, P, P, P, P, P, P, P, I, I, P],
     'cgc_spmm_graphs': [P, P, P, P, P, P, P, P, I, I, P, I, I, I, P],

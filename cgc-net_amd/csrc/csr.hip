@@ -162,6 +162,23 @@ __global__ void k_edge_renorm(const int* __restrict__ rowptr, const int* __restr
   for (int k = s; k < e; ++k) val[k] = (col[k] == r) ? p : w;
 }
 
+// weights in transposed slot order: t_val[k] = val[t_perm[k]] for the nnz live slots (the backward aggregations then read
+// their weights contiguously instead of through a dependent index load per edge)
+__global__ void k_transpose_vals(const int* __restrict__ t_rowptr, const int* __restrict__ t_perm, const float* __restrict__ val,
+                                 int n, float* __restrict__ t_val) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  for (int k = t_rowptr[r]; k < t_rowptr[r + 1]; ++k) t_val[k] = val[t_perm[k]];
+}
+
+extern "C" int cgc_csr_transpose_vals(const int* t_rowptr, const int* t_perm, const float* val, int n, float* t_val,
+                                      cgc_stream_t stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(k_transpose_vals, dim3(ceil_div(n, 256)), dim3(256), 0, as_stream(stream), t_rowptr, t_perm, val, n, t_val);
+  CGC_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}
+
 __global__ void k_csr_invdeg(const int* __restrict__ rowptr, const float* __restrict__ val, int n, float* __restrict__ out) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n) return;

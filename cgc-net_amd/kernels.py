@@ -58,6 +58,10 @@ class KernelSpec(object):
         val[k] = p if col[k]==row else (1/(c+1e-15))*(1-p), c = number of off-diagonal entries of the row."""
         raise NotImplementedError
 
+    def csr_transpose_vals(self, t_rowptr, t_perm, val, n, t_val_out):
+        """t_val[k] = val[t_perm[k]] for the live slots of the transposed CSR (entries beyond nnz stay undefined)."""
+        raise NotImplementedError
+
     def csr_invdeg(self, rowptr, val, n, out):
         """out[i] = 1 / max(sum_k val[k] (or the entry count when val is None), 1)  -- DenseSAGEConv's clamp."""
         raise NotImplementedError
@@ -343,6 +347,11 @@ class HipKernels(KernelSpec):
         self._dev(rowptr, col, val_out)
         self._chk(self.lib.cgc_edge_renorm(_ptr(rowptr), _ptr(col), n, ctypes.c_float(p), _ptr(val_out),
                                            self._stream()), 'cgc_edge_renorm')
+
+    def csr_transpose_vals(self, t_rowptr, t_perm, val, n, t_val_out):
+        self._dev(t_rowptr, t_perm, val, t_val_out)
+        self._chk(self.lib.cgc_csr_transpose_vals(_ptr(t_rowptr), _ptr(t_perm), _ptr(val), n, _ptr(t_val_out), self._stream()),
+                  'cgc_csr_transpose_vals')
 
     def csr_invdeg(self, rowptr, val, n, out):
         self._dev(rowptr, val, out)

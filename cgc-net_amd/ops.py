@@ -103,7 +103,7 @@ class _Aggregate(Function):
         dy = _f32c(dy)
         dx = torch.empty_like(dy)
         # transpose aggregation: dx[j] = sum_i w_ij * inv_d[i] * dy[i]
-        K().spmm(g.t_rowptr, g.t_col, g.t_perm if g.val is not None else None, g.val,
+        K().spmm(g.t_rowptr, g.t_col, None, g.t_val,
                  g.inv_d if ctx.mean else None, None, dy, dx, g.n, dy.shape[1], g.gptr, g.B, g.nmax)
         return dx, None, None
 
@@ -503,7 +503,7 @@ class _DiffPoolSparse(Function):
         K().gemm(s, dao, dp, 0, c, c, False, False, c, c, c, 1.0, 0.0, None, g.B, 0, c * c, 0, g.gptr, 1, g.nmax, n)
         # dS = A^T dP  (transpose SpMM) + P dA'^T + X dX'^T
         ds = torch.empty_like(s)
-        K().spmm(g.t_rowptr, g.t_col, g.t_perm if g.val is not None else None, g.val, None, None, dp, ds, n, c,
+        K().spmm(g.t_rowptr, g.t_col, None, g.t_val, None, None, dp, ds, n, c,
                  g.gptr, g.B, g.nmax, 2)                                                             # dP: fresh from the gemm
         # ... both products in one launch: [P | X] [dA' | dX']^T, the K = dx segment rides on the K = c product
         K().gemm(p, dao, ds, 0, c, c, False, True, c, c, c, 1.0, 1.0, None, g.B, 0, c * c, 0, g.gptr, 1, g.nmax, n,

@@ -74,6 +74,10 @@ int cgc_knn_emit_edges(const int* nbr, const int* rowptr, int n, int k, int64_t 
  * (1/(c+1e-15))*(1-p) elsewhere, c = off-diagonal entries of the row.  The CSR must hold its diagonal. */
 int cgc_edge_renorm(const int* rowptr, const int* col, int n, float p, float* val, cgc_stream_t stream);
 
+/* t_val[k] = val[t_perm[k]] over the live slots of the transpose: the weights the backward aggregations (A^T ...) use, in
+ * their own slot order (no per-edge indirection in the gather kernels). */
+int cgc_csr_transpose_vals(const int* t_rowptr, const int* t_perm, const float* val, int n, float* t_val, cgc_stream_t stream);
+
 /* out[i] = 1/max(rowsum_i, 1): the clamp(min=1) mean divisor of DenseSAGEConv (PyG 1.2.1; model/network.py:114). val may be NULL (=1). */
 int cgc_csr_invdeg(const int* rowptr, const float* val, int n, float* out, cgc_stream_t stream);
 

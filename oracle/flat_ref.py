@@ -139,6 +139,10 @@ class TorchKernels(KernelSpec):
         w = (1.0 / (cnt + RENORM_EPS)) * (1 - p)
         val_out[:nnz] = torch.where(c == rows, torch.full_like(off, p), w[rows])
 
+    def csr_transpose_vals(self, t_rowptr, t_perm, val, n, t_val_out):
+        nnz = int(t_rowptr[n])
+        t_val_out[:nnz] = val[t_perm[:nnz].long()]
+
     def csr_invdeg(self, rowptr, val, n, out):
         rows, nnz = self._rows(rowptr, n)
         v = val[:nnz] if val is not None else torch.ones(nnz, device=rowptr.device)

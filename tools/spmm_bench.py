@@ -26,7 +26,18 @@ for W in widths:
         K.spmm(g.rowptr, g.col, None, None, None, None, x, out, n, W, g.gptr, g.B, g.nmax)
     def run_t():
         K.spmm(g.t_rowptr, g.t_col, None, None, None, None, x, out, n, W, g.gptr, g.B, g.nmax)
-    for name, fn in (('A x', run), ('A^T x', run_t)):
+    gw = BatchGraph.from_batch(b, 0.4)                     # re-normalised adjacency: per-edge weights (shipped flags)
+    tval = gw.val[gw.t_perm.long()].contiguous()            # weights already in transposed slot order
+
+    def run_w():
+        K.spmm(gw.rowptr, gw.col, None, gw.val, None, None, x, out, n, W, gw.gptr, gw.B, gw.nmax)
+
+    def run_tw():
+        K.spmm(gw.t_rowptr, gw.t_col, gw.t_perm, gw.val, None, None, x, out, n, W, gw.gptr, gw.B, gw.nmax)
+
+    def run_tw2():
+        K.spmm(gw.t_rowptr, gw.t_col, None, tval, None, None, x, out, n, W, gw.gptr, gw.B, gw.nmax)
+    for name, fn in (('A x', run), ('A^T x', run_t), ('Aw x', run_w), ('Aw^T x (perm)', run_tw), ('Aw^T x (pre-permuted w)', run_tw2)):
         for _ in range(3):
             fn()
         torch.cuda.synchronize()
@@ -48,7 +59,7 @@ for W in widths:
             tt.append(s.elapsed_time(e))
         after = sorted(tt[2:])[len(tt[2:]) // 2]
         by = 8.0 * n * W + 4.0 * (n + 1) + 4.0 * nnz
-        print('%-6s n=%d nnz=%d W=%5d  %8.1f us  %7.1f GB/s algorithmic (%.1f%% of 8 TB/s); right after its producer '
+        print('%-24s n=%d nnz=%d W=%5d  %8.1f us  %7.1f GB/s algorithmic (%.1f%% of 8 TB/s); right after its producer '
               '%.1f us (%.1f%%)  [env %s]' % (
             name, n, nnz, W, ms * 1e3, by / ms / 1e6, by / ms / 1e6 / 80.0, after * 1e3, by / after / 1e6 / 80.0,
             {k: v for k, v in os.environ.items() if k.startswith('CGC_SPMM')}))
