@@ -172,9 +172,17 @@ class _LinearCat(Function):
         order = sorted(range(len(xs)), key=lambda i: -xs[i].shape[1])
         m = order[0]
         y = torch.empty(n, fout, dtype=torch.float32, device=weight.device)
-        extra = [(xs[i], weight[:, offs[i]:], xs[i].shape[1], ftot, xs[i].shape[1], 0, 0) for i in order[1:]]
-        K().gemm(xs[m], weight[:, offs[m]:], y, n, fout, xs[m].shape[1], False, True, xs[m].shape[1], ftot, fout,
-                 1.0, 0.0, bias, extra=extra)
+        if n >= 8 * fout:
+            # tall products: the GEMM streams an n-contiguous B operand ~8 % faster than a k-contiguous one (both tiles of
+            # the NT form arrive as 128-byte row segments), and transposing the small weight costs microseconds
+            wt = weight.t().contiguous()                                   # [sum F_k, out]
+            extra = [(xs[i], wt[offs[i]:], xs[i].shape[1], fout, xs[i].shape[1], 0, 0) for i in order[1:]]
+            K().gemm(xs[m], wt[offs[m]:], y, n, fout, xs[m].shape[1], False, False, xs[m].shape[1], fout, fout,
+                     1.0, 0.0, bias, extra=extra)
+        else:
+            extra = [(xs[i], weight[:, offs[i]:], xs[i].shape[1], ftot, xs[i].shape[1], 0, 0) for i in order[1:]]
+            K().gemm(xs[m], weight[:, offs[m]:], y, n, fout, xs[m].shape[1], False, True, xs[m].shape[1], ftot, fout,
+                     1.0, 0.0, bias, extra=extra)
         if softmax:                      # row softmax of the assignment logits, in place (model/network.py:200)
             K().softmax_fwd(y, n, fout, y)
             ctx.save_for_backward(weight, y, *xs)
