@@ -15,7 +15,7 @@ PROTOTYPES = {
     'cgc_csr_transpose_vals': [P, P, P, I, P, P],
     'cgc_csr_invdeg': [P, P, I, P, P],
     'cgc_spmm': [P, P, P, P, P, P, P, P, I, I, P],
-    'cgc_spmm_graphs': [P, P, P, P, P, P, P, P, I, I, P, I, I, I, P],
+    'cgc_spmm_graphs': [P, P, P, P, P, P, P, P, I, I, I, P, I, I, I, P],
     'cgc_gemm_f32': [I, I, I, I, I, F, P, I, P, I, F, P, I, P, I, L, L, L, P, I, I, P],
     'cgc_gemm_f32_cat': [I, I, I, I, I, F, P, I, P, I, F, P, I, P, I, L, L, L, P, I, I, I, P, P, P, P, P, P, P, P],
     'cgc_reduce_batch_sum': [P, P, I, L, F, P],
@@ -28,8 +28,8 @@ PROTOTYPES = {
     'cgc_bn_bwd_reduce': [P, I, P, I, I, I, P, P, P, P, P],
     'cgc_bn_act_l2_bwd': [P, I, P, P, I, I, I, I, I, P, P, P, P, D, P, P, P, P],
     'cgc_colsum': [P, I, I, I, P, P, P],
-    'cgc_softmax_fwd': [P, I, I, P, P],
-    'cgc_softmax_bwd': [P, P, I, I, P, P, P, P],
+    'cgc_softmax_fwd': [P, I, I, I, P, P],
+    'cgc_softmax_bwd': [P, P, I, I, I, P, P, P, P],
     'cgc_segment_max_fwd': [P, P, I, I, I, P, P, P],
     'cgc_segment_max_bwd': [P, P, I, I, P, P],
     'cgc_jk_supported': [I],

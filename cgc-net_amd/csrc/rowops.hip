@@ -557,12 +557,12 @@ extern "C" int cgc_colsum(const float* x, int ld, int n, int F, float* out, floa
 // row softmax (assignment matrix)
 // ------------------------------------------------------------------------------------------------
 template <int VEC>
-__global__ __launch_bounds__(256) void k_softmax_fwd(const float* __restrict__ x, int n, int C, int lpr, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_softmax_fwd(const float* __restrict__ x, int n, int C, int ld, int lpr, float* __restrict__ out) {
   const RowGroup rg(lpr);
   for (int base = rg.gwave * rg.rpw; base < n; base += rg.nwaves * rg.rpw) {
     const int row = base + rg.sub;
     const bool valid = row < n;
-    const float* xr = x + (size_t)row * C;
+    const float* xr = x + (size_t)row * ld;
     float m = -INFINITY;
     if (valid)
       for (int c = rg.sl * VEC; c < C; c += lpr * VEC) {
@@ -588,14 +588,14 @@ __global__ __launch_bounds__(256) void k_softmax_fwd(const float* __restrict__ x
       t.load(xr + c);
 #pragma unroll
       for (int v = 0; v < VEC; ++v) t.v[v] = expf(t.v[v] - m) * inv;
-      t.store(out + (size_t)row * C + c);
+      t.store(out + (size_t)row * ld + c);
     }
   }
 }
 
 template <int VEC, int MAXJ>
 __global__ __launch_bounds__(256) void k_softmax_bwd(const float* __restrict__ S, const float* __restrict__ dS, int n, int C,
-                                                     int lpr, float* __restrict__ dx, float* __restrict__ ws) {
+                                                     int ld, int lpr, float* __restrict__ dx, float* __restrict__ ws) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const RowGroup rg(lpr);
   float csum[1][MAXJ][VEC];
@@ -612,8 +612,8 @@ __global__ __launch_bounds__(256) void k_softmax_bwd(const float* __restrict__ S
     for (int j = 0; j < MAXJ; ++j) {
       const int c = (rg.sl + lpr * j) * VEC;
       if (valid && c < C) {
-        s[j].load(S + (size_t)row * C + c);
-        d[j].load(dS + (size_t)row * C + c);
+        s[j].load(S + (size_t)row * ld + c);
+        d[j].load(dS + (size_t)row * ld + c);
 #pragma unroll
         for (int v = 0; v < VEC; ++v) dot += s[j].v[v] * d[j].v[v];
       } else {
@@ -632,40 +632,42 @@ __global__ __launch_bounds__(256) void k_softmax_bwd(const float* __restrict__ S
           d[j].v[v] = s[j].v[v] * (d[j].v[v] - dot);
           csum[0][j][v] += d[j].v[v];
         }
-        d[j].store(dx + (size_t)row * C + c);
+        d[j].store(dx + (size_t)row * ld + c);
       }
     }
   }
   if (ws != nullptr) col_reduce_store<VEC, MAXJ, 1>(csum, C, lpr, smem, ws + (size_t)blockIdx.x * C);
 }
 
-extern "C" int cgc_softmax_fwd(const float* x, int n, int C, float* out, cgc_stream_t stream) {
+extern "C" int cgc_softmax_fwd(const float* x, int n, int C, int ld, float* out, cgc_stream_t stream) {
   if (n <= 0 || C <= 0) return 0;
-  const bool vec = (C % 4 == 0) && aligned16(x) && aligned16(out);
+  if (ld < C) return CGC_EINVAL;
+  const bool vec = (C % 4 == 0) && (ld % 4 == 0) && aligned16(x) && aligned16(out);
   const int lpr = pick_lpr(vec ? C / 4 : C);
   dim3 grid(row_blocks(n, lpr)), block(CGC_BLOCK);
   if (vec)
-    hipLaunchKernelGGL(k_softmax_fwd<4>, grid, block, 0, as_stream(stream), x, n, C, lpr, out);
+    hipLaunchKernelGGL(k_softmax_fwd<4>, grid, block, 0, as_stream(stream), x, n, C, ld, lpr, out);
   else
-    hipLaunchKernelGGL(k_softmax_fwd<1>, grid, block, 0, as_stream(stream), x, n, C, lpr, out);
+    hipLaunchKernelGGL(k_softmax_fwd<1>, grid, block, 0, as_stream(stream), x, n, C, ld, lpr, out);
   CGC_RETURN_IF_LAUNCH_FAILED();
   return 0;
 }
 
-extern "C" int cgc_softmax_bwd(const float* S, const float* dS, int n, int C, float* dx, float* dx_colsum, float* ws,
+extern "C" int cgc_softmax_bwd(const float* S, const float* dS, int n, int C, int ld, float* dx, float* dx_colsum, float* ws,
                                cgc_stream_t stream) {
   if (C <= 0) return 0;
+  if (ld < C) return CGC_EINVAL;
   if (n <= 0) {
     if (dx_colsum) (void)hipMemsetAsync(dx_colsum, 0, sizeof(float) * C, as_stream(stream));
     return 0;
   }
   if (dx_colsum != nullptr && ws == nullptr) return CGC_EINVAL;
-  const bool vec = (C % 4 == 0) && aligned16(S) && aligned16(dS) && aligned16(dx);
+  const bool vec = (C % 4 == 0) && (ld % 4 == 0) && aligned16(S) && aligned16(dS) && aligned16(dx);
   ColCfg cfg = col_cfg(n, C, vec);
   if (!cfg.ok) return CGC_EINVAL;
   if (dx_colsum == nullptr) cfg.blocks = row_blocks(n, cfg.lpr);
   const size_t smem = dx_colsum ? sizeof(float) * 3 * C : 0;
-  DISPATCH_COL(k_softmax_bwd, cfg, smem, as_stream(stream), S, dS, n, C, cfg.lpr, dx, dx_colsum ? ws : (float*)nullptr);
+  DISPATCH_COL(k_softmax_bwd, cfg, smem, as_stream(stream), S, dS, n, C, ld, cfg.lpr, dx, dx_colsum ? ws : (float*)nullptr);
   CGC_RETURN_IF_LAUNCH_FAILED();
   if (dx_colsum) {
     hipLaunchKernelGGL(k_reduce_slots<float>, REDUCE_SLOTS_GRID(C), dim3(256), 0, as_stream(stream), ws, cfg.blocks, C, dx_colsum);

@@ -164,7 +164,7 @@ template <int U, bool VAL, bool PERM, bool PRE>
 __global__ __launch_bounds__(256) void k_spmm_wide(const int* __restrict__ rowptr, const int* __restrict__ col,
                                                    const int* __restrict__ perm, const float* __restrict__ val,
                                                    const float* __restrict__ pre, const float* __restrict__ post,
-                                                   const float* __restrict__ x, float* __restrict__ out, int n, int W,
+                                                   const float* __restrict__ x, float* __restrict__ out, int n, int W, int ld,
                                                    int n_ctiles, int run, int blocks_per_ct, int n_chunks,
                                                    const int* __restrict__ gptr, int order) {
   typedef float f4v __attribute__((ext_vector_type(4)));
@@ -210,10 +210,10 @@ __global__ __launch_bounds__(256) void k_spmm_wide(const int* __restrict__ rowpt
     const int e = rowptr[r + 1];
     f4v acc = {0.f, 0.f, 0.f, 0.f};
     int k = s;
-    for (; k + U <= e; k += U) wide_batch<U, VAL, PERM, PRE>(col, perm, val, pre, xl, W, k, acc);
-    wide_tail<U - 1, VAL, PERM, PRE>(e - k, col, perm, val, pre, xl, W, k, acc);   // exactly as many gathers as entries left
+    for (; k + U <= e; k += U) wide_batch<U, VAL, PERM, PRE>(col, perm, val, pre, xl, ld, k, acc);
+    wide_tail<U - 1, VAL, PERM, PRE>(e - k, col, perm, val, pre, xl, ld, k, acc);   // exactly as many gathers as entries left
     if (post != nullptr) acc *= post[r];
-    __builtin_nontemporal_store(acc, reinterpret_cast<f4v*>(out + (size_t)r * W + c0));
+    __builtin_nontemporal_store(acc, reinterpret_cast<f4v*>(out + (size_t)r * ld + c0));
     s = e;
   }
 }
@@ -225,11 +225,11 @@ static int knob(const char* name, int dflt) {
 }
 
 static int launch_gather(const int* rowptr, const int* col, const int* perm, const float* val, const float* pre, const float* post,
-                         const float* x, float* out, int n, int width, const int* gptr, int B, int nmax, int visit,
+                         const float* x, float* out, int n, int width, int ld, const int* gptr, int B, int nmax, int visit,
                          hipStream_t stream) {
   static const int k_passes = knob("CGC_SPMM_PASSES", 2), k_chunk = knob("CGC_SPMM_CHUNK", 2048);
   static const int k_nt = knob("CGC_SPMM_NT", 1), k_lds = knob("CGC_SPMM_LDS", 0), k_lpr = knob("CGC_SPMM_LPR", 64);
-  const bool vec = (width % 4 == 0) && aligned16(x) && aligned16(out);
+  const bool vec = (width % 4 == 0) && (ld % 4 == 0) && aligned16(x) && aligned16(out);
   const int chunks = vec ? width / 4 : width;        // per-lane column chunks in a row
   int lpr = pick_lpr(chunks);
   if (lpr > k_lpr) lpr = k_lpr;     // narrower column tiles for wide rows (experiment)
@@ -261,7 +261,7 @@ static int launch_gather(const int* rowptr, const int* col, const int* perm, con
     const int nbw = ceil_div(n_chunks * blocks_per_ct * n_ctiles, 8) * 8;
 #define WIDE_LAUNCH(V, P, Q)                                                                                              \
   hipLaunchKernelGGL((k_spmm_wide<GATHER_U, V, P, Q>), dim3(nbw), dim3(CGC_BLOCK), 0, stream, rowptr, col, perm, val, pre, \
-                     post, x, out, n, width, n_ctiles, k_run, blocks_per_ct, n_chunks, gptr, order)
+                     post, x, out, n, width, ld, n_ctiles, k_run, blocks_per_ct, n_chunks, gptr, order)
     const bool hv = val != nullptr, hp = hv && perm != nullptr, hq = pre != nullptr;
     if (!hv && !hq) WIDE_LAUNCH(false, false, false);
     else if (!hv) WIDE_LAUNCH(false, false, true);
@@ -273,6 +273,7 @@ static int launch_gather(const int* rowptr, const int* col, const int* perm, con
     CGC_RETURN_IF_LAUNCH_FAILED();
     return 0;
   }
+  if (ld != width) return CGC_EINVAL;                  // padded rows: wide (wave-per-row) path only
   int nb = n_chunks * blocks_per_ct * n_ctiles;
   nb = ceil_div(nb, 8) * 8;
   dim3 grid(nb), block(CGC_BLOCK);
@@ -290,7 +291,7 @@ static int launch_gather(const int* rowptr, const int* col, const int* perm, con
 extern "C" int cgc_spmm(const int* rowptr, const int* col, const int* perm, const float* val, const float* pre, const float* post,
                         const float* x, float* out, int n, int width, cgc_stream_t stream) {
   if (n <= 0 || width <= 0) return 0;
-  return launch_gather(rowptr, col, perm, val, pre, post, x, out, n, width, nullptr, 0, 0, 0, as_stream(stream));
+  return launch_gather(rowptr, col, perm, val, pre, post, x, out, n, width, width, nullptr, 0, 0, 0, as_stream(stream));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -395,12 +396,13 @@ static int launch_slab(const int* rowptr, const int* col, const int* perm, const
 // nmax = largest graph.  Wide, 16-byte-aligned rows of graphs that fit LDS take the slab kernel; everything else the
 // gather kernel.
 extern "C" int cgc_spmm_graphs(const int* rowptr, const int* col, const int* perm, const float* val, const float* pre,
-                               const float* post, const float* x, float* out, int n, int width, const int* gptr, int B,
+                               const float* post, const float* x, float* out, int n, int width, int ld, const int* gptr, int B,
                                int nmax, int visit, cgc_stream_t stream) {
   if (n <= 0 || width <= 0) return 0;
+  if (ld < width) return CGC_EINVAL;
   static const int k_slab = knob("CGC_SPMM_SLAB", 0);
   const size_t budget = 150 * 1024;
-  if (k_slab && gptr != nullptr && B > 0 && width > 64 && width % 4 == 0 && aligned16(x) && aligned16(out) && nmax > 0) {
+  if (k_slab && ld == width && gptr != nullptr && B > 0 && width > 64 && width % 4 == 0 && aligned16(x) && aligned16(out) && nmax > 0) {
     hipStream_t st = as_stream(stream);
     static const int k_t = knob("CGC_SPMM_T", 16), k_thr = knob("CGC_SPMM_THR", 1024);
 #define SLAB_ARGS rowptr, col, perm, val, pre, post, x, out, gptr, B, nmax, width, st
@@ -409,5 +411,5 @@ extern "C" int cgc_spmm_graphs(const int* rowptr, const int* col, const int* per
     if ((size_t)nmax * 4 * 4 <= budget) return k_thr >= 1024 ? launch_slab<4, 1024>(SLAB_ARGS) : launch_slab<4, 512>(SLAB_ARGS);
 #undef SLAB_ARGS
   }
-  return launch_gather(rowptr, col, perm, val, pre, post, x, out, n, width, gptr, B, nmax, visit, as_stream(stream));
+  return launch_gather(rowptr, col, perm, val, pre, post, x, out, n, width, ld, gptr, B, nmax, visit, as_stream(stream));
 }

@@ -66,12 +66,13 @@ class KernelSpec(object):
         """out[i] = 1 / max(sum_k val[k] (or the entry count when val is None), 1)  -- DenseSAGEConv's clamp."""
         raise NotImplementedError
 
-    def spmm(self, rowptr, col, perm, val, pre, post, x, out, n, width, gptr=None, num_graphs=0, nmax=0, visit=0):
+    def spmm(self, rowptr, col, perm, val, pre, post, x, out, n, width, gptr=None, num_graphs=0, nmax=0, visit=0, ld=None):
         """out[i,:] = post[i] * sum_{k in row i} w_k * pre[col[k]] * x[col[k],:]
         with w_k = val[perm[k]] / val[k] / 1 and pre/post optional.  x, out: [n, width] contiguous.
         gptr/num_graphs/nmax (optional): the rows are a batch of graphs with block-diagonal adjacency
         (first row of each graph, count, largest graph) -- a layout hint, the result is the same.
-        visit (optional, scheduling hint): 1 = x was just written in ascending row order, 2 = by a ragged batched gemm."""
+        visit (optional, scheduling hint): 1 = x was just written in ascending row order, 2 = by a ragged batched gemm.
+        ld (optional): row stride of x and out when the rows are padded (wide rows only; needs gptr)."""
         raise NotImplementedError
 
     # ------------------------------------------------------------------ dense contractions (MFMA fp32)
@@ -137,10 +138,10 @@ class KernelSpec(object):
         raise NotImplementedError
 
     # ------------------------------------------------------------------ assignment softmax (A8), readout (A9)
-    def softmax_fwd(self, x, n, C, out):
+    def softmax_fwd(self, x, n, C, out, ld=None):
         raise NotImplementedError
 
-    def softmax_bwd(self, S, dS, n, C, dx_out, dx_colsum_out=None):
+    def softmax_bwd(self, S, dS, n, C, dx_out, dx_colsum_out=None, ld=None):
         """dx = S * (dS - <dS, S>_row);  dx_colsum_out[c] = sum_i dx[i,c] (optional)."""
         raise NotImplementedError
 
@@ -357,14 +358,14 @@ class HipKernels(KernelSpec):
         self._dev(rowptr, val, out)
         self._chk(self.lib.cgc_csr_invdeg(_ptr(rowptr), _ptr(val), n, _ptr(out), self._stream()), 'cgc_csr_invdeg')
 
-    def spmm(self, rowptr, col, perm, val, pre, post, x, out, n, width, gptr=None, num_graphs=0, nmax=0, visit=0):
+    def spmm(self, rowptr, col, perm, val, pre, post, x, out, n, width, gptr=None, num_graphs=0, nmax=0, visit=0, ld=None):
         self._dev(rowptr, col, perm, val, pre, post, x, out, gptr)
-        assert x.is_contiguous() and out.is_contiguous()
+        assert (x.is_contiguous() and out.is_contiguous()) if ld is None else (gptr is not None and x.stride(1) == 1 and out.stride(1) == 1)
         t0 = self.timer.begin() if (self.timer is not None and width > 64) else None
         if gptr is not None:
             self._chk(self.lib.cgc_spmm_graphs(_ptr(rowptr), _ptr(col), _ptr(perm), _ptr(val), _ptr(pre), _ptr(post),
-                                               _ptr(x), _ptr(out), n, width, _ptr(gptr), num_graphs, nmax,
-                                               int(visit), self._stream()), 'cgc_spmm_graphs')
+                                               _ptr(x), _ptr(out), n, width, width if ld is None else ld, _ptr(gptr),
+                                               num_graphs, nmax, int(visit), self._stream()), 'cgc_spmm_graphs')
         else:
             self._chk(self.lib.cgc_spmm(_ptr(rowptr), _ptr(col), _ptr(perm), _ptr(val), _ptr(pre), _ptr(post),
                                         _ptr(x), _ptr(out), n, width, self._stream()), 'cgc_spmm')
@@ -478,14 +479,14 @@ class HipKernels(KernelSpec):
         self._chk(self.lib.cgc_colsum(_ptr(x), ld, n, F, _ptr(out), _ptr(ws), self._stream()), 'cgc_colsum')
 
     # -- softmax / readout
-    def softmax_fwd(self, x, n, C, out):
+    def softmax_fwd(self, x, n, C, out, ld=None):
         self._dev(x, out)
-        self._chk(self.lib.cgc_softmax_fwd(_ptr(x), n, C, _ptr(out), self._stream()), 'cgc_softmax_fwd')
+        self._chk(self.lib.cgc_softmax_fwd(_ptr(x), n, C, C if ld is None else ld, _ptr(out), self._stream()), 'cgc_softmax_fwd')
 
-    def softmax_bwd(self, S, dS, n, C, dx_out, dx_colsum_out=None):
+    def softmax_bwd(self, S, dS, n, C, dx_out, dx_colsum_out=None, ld=None):
         self._dev(S, dS, dx_out, dx_colsum_out)
         ws = self._slots(n, C, S.device) if dx_colsum_out is not None else None
-        self._chk(self.lib.cgc_softmax_bwd(_ptr(S), _ptr(dS), n, C, _ptr(dx_out), _ptr(dx_colsum_out), _ptr(ws),
+        self._chk(self.lib.cgc_softmax_bwd(_ptr(S), _ptr(dS), n, C, C if ld is None else ld, _ptr(dx_out), _ptr(dx_colsum_out), _ptr(ws),
                                            self._stream()), 'cgc_softmax_bwd')
 
     def segment_max_fwd(self, x, gptr, B, D, nmax, out, arg_out):

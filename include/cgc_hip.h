@@ -95,8 +95,10 @@ int cgc_spmm(const int* rowptr, const int* col, const int* perm, const float* va
  * of x the previous kernel left in the Infinity Cache -- 0 unknown / ascending, 1 x was written in ascending row order,
  * 2 x was written by cgc_gemm_f32 as a ragged batch. */
 int cgc_spmm_graphs(const int* rowptr, const int* col, const int* perm, const float* val, const float* pre,
-                    const float* post, const float* x, float* out, int n, int width, const int* gptr, int B, int nmax,
-                    int visit, cgc_stream_t stream);
+                    const float* post, const float* x, float* out, int n, int width, int ld /* row stride of x and out
+                    (>= width): wide rows are kept at a multiple of 32 floats so that a 128-byte line never holds parts
+                    of two rows; ld != width needs width > 128 */, const int* gptr, int B, int nmax, int visit,
+                    cgc_stream_t stream);
 
 /* ---- A4/A5/A8: dense contractions on fp32 MFMA (v_mfma_f32_32x32x2_f32).  Replaces torch.matmul / nn.Linear at
  * model/network.py:122 (assignment Linear), :206-207 (S^T X, S^T A S), and the level-2/3 adj@x.
@@ -151,8 +153,8 @@ int cgc_bn_act_l2_bwd(const float* dy, int ldy, const float* hn, const float* ri
 int cgc_colsum(const float* x, int ld, int n, int F, float* out, float* ws, cgc_stream_t stream);
 
 /* ---- A8: row softmax of the assignment matrix (model/network.py:200); A9: max readout (model/network.py:264) */
-int cgc_softmax_fwd(const float* x, int n, int C, float* out, cgc_stream_t stream);
-int cgc_softmax_bwd(const float* S, const float* dS, int n, int C, float* dx,
+int cgc_softmax_fwd(const float* x, int n, int C, int ld /*row stride of x and out*/, float* out, cgc_stream_t stream);
+int cgc_softmax_bwd(const float* S, const float* dS, int n, int C, int ld /*row stride of S, dS, dx*/, float* dx,
                     float* dx_colsum /*[C] or NULL: fused column sums of dx*/, float* ws, cgc_stream_t stream);
 int cgc_segment_max_fwd(const float* x, const int* gptr, int B, int D, int nmax, float* out, int* arg, cgc_stream_t stream);
 int cgc_segment_max_bwd(const float* dout, const int* arg, int B, int D, float* dx_zeroed, cgc_stream_t stream);

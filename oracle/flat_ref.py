@@ -149,7 +149,7 @@ class TorchKernels(KernelSpec):
         s = torch.zeros(n, device=rowptr.device).index_add_(0, rows, v)
         out.copy_(1.0 / s.clamp(min=1))
 
-    def spmm(self, rowptr, col, perm, val, pre, post, x, out, n, width, gptr=None, num_graphs=0, nmax=0, visit=0):
+    def spmm(self, rowptr, col, perm, val, pre, post, x, out, n, width, gptr=None, num_graphs=0, nmax=0, visit=0, ld=None):
         rows, nnz = self._rows(rowptr, n)
         c = col[:nnz].long()
         w = torch.ones(nnz, device=x.device)
@@ -278,10 +278,10 @@ class TorchKernels(KernelSpec):
         out.copy_(_mat(x, n, F_, ld).sum(0))
 
     # ------------------------------------------------------------------ softmax / readout
-    def softmax_fwd(self, x, n, C, out):
+    def softmax_fwd(self, x, n, C, out, ld=None):      # (padded rows arrive as strided views: nothing to do with ld here)
         out.copy_(torch.softmax(x, dim=1))
 
-    def softmax_bwd(self, S, dS, n, C, dx_out, dx_colsum_out=None):
+    def softmax_bwd(self, S, dS, n, C, dx_out, dx_colsum_out=None, ld=None):
         dx_out.copy_(S * (dS - (dS * S).sum(1, keepdim=True)))
         if dx_colsum_out is not None:
             dx_colsum_out.copy_(dx_out.sum(0))

@@ -88,6 +88,35 @@ def test_variants_vs_dense_oracle(flags, torch_kernels):
         assert rel_err(p.grad, gref[k].grad) < TOL_GRAD, k
 
 
+def test_wide_assignment_rows_keep_a_padded_stride(torch_kernels):
+    """Cluster counts >= 256 that are not multiples of 32 (the reference's 1140): the assignment / aggregation tensors are
+    strided views over rows padded to 32 floats (ops._wide); results and gradients must not notice."""
+    from cgc_net_amd import ops
+    from cgc_net_amd.data import Batch, SyntheticCellGraphs
+    from oracle import dense_ref
+    assert ops._wide(5, 300, 'cpu').stride(0) == 320 and ops._wide(5, 256, 'cpu').stride(0) == 256
+    ds = SyntheticCellGraphs(3, 40, num_features=6, base_seed=3)
+    batch = Batch.from_data_list([ds[i] for i in range(3)])
+    args = (2700, 6, 8, 8, True, True, 8, 3, 0.1, [50])            # C1 = 270 (padded to 288), C2 = 27
+    kw = dict(concat=True, load_data_sparse=True, drop_out=0., norm_adj=True, jk=True, collect_assign=True)
+    torch.manual_seed(2)
+    ref = dense_ref.SoftPoolingGcnEncoder(*args, **kw)
+    model = network.SoftPoolingGcnEncoder(*args, **kw)
+    model.load_state_dict(ref.state_dict())
+    model.train()
+    ref.train()
+    logits, loss = model(batch)
+    rl, rloss = ref(batch)
+    assert rel_err(logits, rl) < TOL and rel_err(loss, rloss) < TOL
+    assert model.assign_matrix[0].shape == ref.assign_matrix[0].shape
+    assert rel_err(model.assign_matrix[0], ref.assign_matrix[0]) < TOL
+    loss.backward()
+    rloss.backward()
+    gref = dict(ref.named_parameters())
+    for k, p in model.named_parameters():      # 40-node graphs spread over 270 clusters: fp32 noise of either side ~1e-3
+        assert rel_err(p.grad, gref[k].grad) < 2e-3, k
+
+
 def test_dense_tuple_input_and_operator_contracts(torch_kernels):
     """The tuple input form (model/network.py:253-256) and the DenseSAGEConv / GNN_Module dense contracts with mask."""
     from cgc_net_amd.data import Batch, SyntheticCellGraphs
