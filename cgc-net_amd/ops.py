@@ -23,11 +23,14 @@ def _f32c(t):
     return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.contiguous().float()
 
 
+_WIDE_MIN = 256      # (128 measured on the 180-cluster configuration: no gain)
+
+
 def _wide(n, F, device):
     """[n, F] fp32 rows for kernel outputs.  Wide rows (F >= 256) get a row stride rounded up to 32 floats: every 128-byte
     line then belongs to ONE row, which the GEMM's k-contiguous tile loads (one line per 32-float segment instead of two)
     and the gather kernels reward with 5-15 % -- measured 109 -> 125 TFLOP/s on the NT contraction for 1140 vs 1152."""
-    if F < 256 or F % 32 == 0:
+    if F < _WIDE_MIN or F % 32 == 0:
         return torch.empty(n, F, dtype=torch.float32, device=device)
     ld = -(-F // 32) * 32
     return torch.empty(n, ld, dtype=torch.float32, device=device)[:, :F]
