@@ -584,3 +584,43 @@ def test_fuse_sampler_structure():
         REF.farthest_point_sample(pos[gptr[b]:gptr[b + 1]], torch.tensor([0, counts[b]], dtype=torch.int32), 1, counts[b],
                                   torch.tensor([[3, 5, 7][b]], dtype=torch.int32), torch.tensor([0, kf], dtype=torch.int32), far)
         assert set((far.numpy() + gptr[b]).tolist()) <= set(mine.tolist())
+
+
+# ------------------------------------------------------------------ padded row strides (ops._wide) at the kernel level
+@pytest.mark.parametrize('width,ld', [(1140, 1152), (300, 320), (180, 192)])
+def test_wide_spmm_and_softmax_with_padded_rows(width, ld):
+    """cgc_spmm_graphs / cgc_softmax_* on rows whose stride exceeds the width (128-byte-aligned rows): same results as on
+    packed rows, and the padding columns are never written."""
+    counts = [130, 97, 260, 3]
+    s, sg, n = _graph(counts, True, seed=width)
+    gptr = g(torch.tensor(np.cumsum([0] + counts), dtype=torch.int32))
+    val = torch.zeros(s['cap'])
+    REF.edge_renorm(s['rowptr'], s['col'], n, 0.4, val)
+    x = rnd(n, width, seed=2)
+    want = torch.zeros(n, width)
+    REF.spmm(s['rowptr'], s['col'], None, val, None, None, x, want, n, width)
+    xb = torch.full((n, ld), 7.0, device=DEV)
+    xb[:, :width] = g(x)
+    ob = torch.full((n, ld), -3.0, device=DEV)
+    hip().spmm(sg['rowptr'], sg['col'], None, g(val), None, None, xb[:, :width], ob[:, :width], n, width, gptr, len(counts),
+               max(counts), 1, ld)
+    close(ob[:, :width], want, what='padded spmm')
+    assert bool((ob[:, width:] == -3.0).all())
+    # softmax forward in place + backward with fused column sums
+    z = rnd(n, width, seed=4)
+    zb = torch.full((n, ld), 9.0, device=DEV)
+    zb[:, :width] = g(z)
+    hip().softmax_fwd(zb[:, :width], n, width, zb[:, :width], ld)
+    sm = torch.softmax(z, 1)
+    close(zb[:, :width], sm, what='padded softmax fwd')
+    assert bool((zb[:, width:] == 9.0).all())
+    dS = rnd(n, width, seed=5)
+    db_ = torch.full((n, ld), 1.0, device=DEV)
+    db_[:, :width] = g(dS)
+    dx = torch.full((n, ld), 5.0, device=DEV)
+    cs = torch.empty(width, device=DEV)
+    hip().softmax_bwd(zb[:, :width], db_[:, :width], n, width, dx[:, :width], cs, ld)
+    want_dx = sm * (dS - (dS * sm).sum(1, keepdim=True))
+    close(dx[:, :width], want_dx, what='padded softmax bwd')
+    close(cs, want_dx.sum(0), what='padded softmax bwd column sums')
+    assert bool((dx[:, width:] == 5.0).all())
