@@ -88,6 +88,19 @@ struct KContigLoader {
       reg[i] = *reinterpret_cast<const float4*>(base + (size_t)row * ld + k0 + (u % (BK / 4)) * 4);
     }
   }
+  // Partial k-tile (k_lim % 4 == 0), still branch-free: units past the end of K re-read the last valid 16 bytes of their
+  // row and are zeroed with a select -- the guarded loader above costs ~0.75 of a full tile's time on top of its own.
+  __device__ __forceinline__ void load_fast_masked(const float* __restrict__ base, int ld, int row0, int row_last, int k0, int k_lim) {
+#pragma unroll
+    for (int i = 0; i < PER_T; ++i) {
+      const int u = threadIdx.x + i * 256;
+      const int row = min(row0 + u / (BK / 4), row_last);
+      const int k = k0 + (u % (BK / 4)) * 4;
+      float4 v = *reinterpret_cast<const float4*>(base + (size_t)row * ld + min(k, k_lim - 4));
+      if (k >= k_lim) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      reg[i] = v;
+    }
+  }
   // same orientation as memory: one 16-byte write per unit.  store_part(i) writes unit i only, so that the writes of the
   // next tile can be spread between the MFMA groups of the current one.
   __device__ __forceinline__ void store_part(int i, float* __restrict__ lds) const {
@@ -138,6 +151,18 @@ struct MnContigLoader {
       const int u = threadIdx.x + i * 256;
       const int c = min(col0 + (u % (COLS / 4)) * 4, col_last4);
       reg[i] = *reinterpret_cast<const float4*>(base + (size_t)(k0 + u / (COLS / 4)) * ld + c);
+    }
+  }
+  // Partial k-tile: rows (k) past the end re-read row k_lim-1 and are zeroed.
+  __device__ __forceinline__ void load_fast_masked(const float* __restrict__ base, int ld, int col0, int col_last4, int k0, int k_lim) {
+#pragma unroll
+    for (int i = 0; i < PER_T; ++i) {
+      const int u = threadIdx.x + i * 256;
+      const int c = min(col0 + (u % (COLS / 4)) * 4, col_last4);
+      const int k = k0 + u / (COLS / 4);
+      float4 v = *reinterpret_cast<const float4*>(base + (size_t)min(k, k_lim - 1) * ld + c);
+      if (k >= k_lim) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      reg[i] = v;
     }
   }
   __device__ __forceinline__ void store_part(int i, float* __restrict__ lds) const {
@@ -243,11 +268,14 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const GemmArgs a) {   // 2 
   const bool fastA = vecA && (TA ? (M % 4 == 0 && M >= 4) : true);
   const bool fastB = vecB && (TB ? true : (N % 4 == 0 && N >= 4));
   const int a_last = TA ? M - 4 : M - 1, b_last = TB ? N - 1 : N - 4;
+  const bool k4 = (K % 4 == 0) && K >= 4;      // partial k-tiles can take the masked fast loads
   auto fetch = [&](LoaderA& la, LoaderB& lb, int kt) {
     if (kt < nk_main) {
       if (fastA && kt < nk_full) la.load_fast(A, a.lda, m0, a_last, kt * BK);
+      else if (fastA && k4) la.load_fast_masked(A, a.lda, m0, a_last, kt * BK, K);
       else la.load(A, a.lda, m0, M, kt * BK, K, vecA);
       if (fastB && kt < nk_full) lb.load_fast(B, a.ldb, n0, b_last, kt * BK);
+      else if (fastB && k4) lb.load_fast_masked(B, a.ldb, n0, b_last, kt * BK, K);
       else lb.load(B, a.ldb, n0, N, kt * BK, K, vecB);
     } else {
       int kx = kt - nk_main;
@@ -258,8 +286,12 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const GemmArgs a) {   // 2 
       const int ldax = a.xlda[second], ldbx = a.xldb[second], Kx = a.xK[second];
       const bool va = (ldax % 4 == 0) && ((reinterpret_cast<uintptr_t>(Ax) & 15u) == 0);
       const bool vb = (ldbx % 4 == 0) && ((reinterpret_cast<uintptr_t>(Bx) & 15u) == 0);
-      la.load(Ax, ldax, m0, M, kx * BK, Kx, va);
-      lb.load(Bx, ldbx, n0, N, kx * BK, Kx, vb);
+      const bool kx4 = (Kx % 4 == 0) && Kx >= 4;
+      // same M / N extents as the main pair: the clamps a_last / b_last apply; short segments are one or two k-tiles
+      if (va && kx4 && (TA ? (M % 4 == 0 && M >= 4) : true)) la.load_fast_masked(Ax, ldax, m0, a_last, kx * BK, Kx);
+      else la.load(Ax, ldax, m0, M, kx * BK, Kx, va);
+      if (vb && kx4 && (TB ? true : (N % 4 == 0 && N >= 4))) lb.load_fast_masked(Bx, ldbx, n0, b_last, kx * BK, Kx);
+      else lb.load(Bx, ldbx, n0, N, kx * BK, Kx, vb);
     }
   };
   // One k-tile: consume LDS buffer `cur` with 4 groups of TM*TN*4 MFMAs.  The fragments of group kb+1 are read from LDS
