@@ -268,14 +268,16 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const GemmArgs a) {   // 2 
   const bool fastA = vecA && (TA ? (M % 4 == 0 && M >= 4) : true);
   const bool fastB = vecB && (TB ? true : (N % 4 == 0 && N >= 4));
   const int a_last = TA ? M - 4 : M - 1, b_last = TB ? N - 1 : N - 4;
-  const bool k4 = (K % 4 == 0) && K >= 4;      // partial k-tiles can take the masked fast loads
+  // partial k-tiles can take the masked fast loads: always when k is the row index of the operand (A stored [K,M], B stored
+  // [K,N]), for k-contiguous operands when K is a multiple of the 16-byte unit
+  const bool k4 = (K % 4 == 0) && K >= 4, k4A = TA ? K >= 1 : k4, k4B = TB ? k4 : K >= 1;
   auto fetch = [&](LoaderA& la, LoaderB& lb, int kt) {
     if (kt < nk_main) {
       if (fastA && kt < nk_full) la.load_fast(A, a.lda, m0, a_last, kt * BK);
-      else if (fastA && k4) la.load_fast_masked(A, a.lda, m0, a_last, kt * BK, K);
+      else if (fastA && k4A) la.load_fast_masked(A, a.lda, m0, a_last, kt * BK, K);
       else la.load(A, a.lda, m0, M, kt * BK, K, vecA);
       if (fastB && kt < nk_full) lb.load_fast(B, a.ldb, n0, b_last, kt * BK);
-      else if (fastB && k4) lb.load_fast_masked(B, a.ldb, n0, b_last, kt * BK, K);
+      else if (fastB && k4B) lb.load_fast_masked(B, a.ldb, n0, b_last, kt * BK, K);
       else lb.load(B, a.ldb, n0, N, kt * BK, K, vecB);
     } else {
       int kx = kt - nk_main;
@@ -288,9 +290,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const GemmArgs a) {   // 2 
       const bool vb = (ldbx % 4 == 0) && ((reinterpret_cast<uintptr_t>(Bx) & 15u) == 0);
       const bool kx4 = (Kx % 4 == 0) && Kx >= 4;
       // same M / N extents as the main pair: the clamps a_last / b_last apply; short segments are one or two k-tiles
-      if (va && kx4 && (TA ? (M % 4 == 0 && M >= 4) : true)) la.load_fast_masked(Ax, ldax, m0, a_last, kx * BK, Kx);
+      if (va && (TA ? (M % 4 == 0 && M >= 4) : kx4)) la.load_fast_masked(Ax, ldax, m0, a_last, kx * BK, Kx);
       else la.load(Ax, ldax, m0, M, kx * BK, Kx, va);
-      if (vb && kx4 && (TB ? true : (N % 4 == 0 && N >= 4))) lb.load_fast_masked(Bx, ldbx, n0, b_last, kx * BK, Kx);
+      if (vb && (TB ? kx4 : (N % 4 == 0 && N >= 4))) lb.load_fast_masked(Bx, ldbx, n0, b_last, kx * BK, Kx);
       else lb.load(Bx, ldbx, n0, N, kx * BK, Kx, vb);
     }
   };
