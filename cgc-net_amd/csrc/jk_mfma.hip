@@ -321,11 +321,12 @@ __global__ __launch_bounds__(JKB_THREADS) void k_jk_bwd_mfma(const float* __rest
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dhc[r] = 0.f; dcc[r] = 0.f; }
 
-#pragma unroll
+    // (the staged variant is ~7 % faster with the recurrence rolled, the in-kernel-gradient variant ~20 % slower)
+#pragma clang loop unroll_count(PG ? 3 : 1)
     for (int s = 2; s >= 0; --s) {
       const int t = d ? 2 - s : s, tprev = d ? t + 1 : t - 1;
       const size_t col = (size_t)t * npad + node;
-      const float dst = d ? ds3[2 - s] : ds3[s];
+      const float dst = t == 0 ? ds3[0] : (t == 1 ? ds3[1] : ds3[2]);
       float4 xt[XG];
 #pragma unroll
       for (int q = 0; q < XG; ++q)
