@@ -51,7 +51,8 @@ def parse():
                         "--jk --norm_adj --drop 0.2; 'plain' = none of the three (SURVEY 8(d) parity configuration)")
     p.add_argument('--pool', type=int, default=4, help='distinct resident batches cycled through')
     p.add_argument('--no-cpu-baseline', action='store_true')
-    p.add_argument('--cpu-seconds', type=float, default=12.0, help='CPU baseline: stop after this much timed work')
+    p.add_argument('--cpu-warmup', type=int, default=3, help='CPU baseline: untimed warm-up steps')
+    p.add_argument('--cpu-steps', type=int, default=5, help='CPU baseline: timed steps')
     p.add_argument('--no-kernel-timing', action='store_true', help='do not record per-launch HIP events')
     return p.parse_args()
 
@@ -87,6 +88,16 @@ def usable_cores():
     return n
 
 
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
 def cpu_baseline(args, batches):
     """The dense oracle = the reference's algorithm on the host: densify -> dense convs -> DiffPool -> CE,
     fwd + bwd + Adam, same seeded graphs, all host cores."""
@@ -103,18 +114,21 @@ def cpu_baseline(args, batches):
         opt.zero_grad()
         loss.mean().backward()
         opt.step()
-    step(batches[0])                       # warm-up (allocator, thread pool)
-    t0, n_steps = time.perf_counter(), 0
-    while True:
-        step(batches[n_steps % len(batches)])
-        n_steps += 1
-        el = time.perf_counter() - t0
-        if el >= args.cpu_seconds or n_steps >= 8:
-            break
-    return {'value': round(args.batch * n_steps / el, 3), 'unit': 'graphs/s', 'cores': torch.get_num_threads(),
-            'kind': 'port', 'host': '%d logical CPUs online, %d usable (affinity/cgroup quota)' % (os.cpu_count() or 1, cores),
-            'sample': '%d timed fwd+bwd+Adam steps of batch %d after 1 warm-up (%.1f s), dense oracle/dense_ref.py, '
-                      'same workload' % (n_steps, args.batch, el)}
+    n_warm, n_timed = args.cpu_warmup, args.cpu_steps      # >= 3 warm-up + >= 5 timed steps at batch 32
+    tw = time.perf_counter()
+    for i in range(n_warm):                # warm-up (allocator, thread pool, page faults of the 592 MB dense adjacency)
+        step(batches[i % len(batches)])
+    tw = time.perf_counter() - tw
+    t0 = time.perf_counter()
+    for i in range(n_timed):
+        step(batches[(n_warm + i) % len(batches)])
+    el = time.perf_counter() - t0
+    return {'value': round(args.batch * n_timed / el, 3), 'unit': 'graphs/s', 'cores': torch.get_num_threads(),
+            'kind': 'port', 'cpu_model': cpu_model(),
+            'host': '%d logical CPUs online, %d usable (affinity/cgroup quota)' % (os.cpu_count() or 1, cores),
+            'sample': '%d timed fwd+bwd+Adam steps of batch %d (%.1f s) after %d warm-up steps (%.1f s), dense '
+                      'oracle/dense_ref.py (the reference algorithm incl. densification), same seeded graphs'
+                      % (n_timed, args.batch, el, n_warm, tw)}
 
 
 def main():

@@ -5,6 +5,7 @@ P, I, F, D, L = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_int64
 
 PROTOTYPES = {
     'cgc_abi_version': [],
+    'cgc_csr_bad_edges_offset': [L, I, I],
     'cgc_csr_build': [P, L, I, I, P, P, P, P, P, P, P, P],
     'cgc_collate': [P, I, I, P, P, P, I, P, P, L, P, P],
     'cgc_farthest_point_sample': [P, P, I, I, P, P, P, P],
@@ -49,4 +50,4 @@ def declare(lib):
     for name, argtypes in PROTOTYPES.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
-        fn.restype = C.c_int64 if name.endswith(('_ws_ints', '_ws_floats')) else C.c_int
+        fn.restype = C.c_int64 if name.endswith(('_ws_ints', '_ws_floats', '_offset')) else C.c_int

@@ -10,8 +10,15 @@
 __global__ void k_hist_rows(const int64_t* __restrict__ ei, int64_t E, int n, int add_diag, int* __restrict__ cnt) {
   const int64_t total = E + (add_diag ? n : 0);
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int r = i < E ? (int)ei[i] : (int)(i - E);
-    atomicAdd(&cnt[r], 1);
+    if (i < E) {
+      // ids outside [0, n) (a bad batch offset, a foreign Batch) must not reach the atomics: such edges are dropped and
+      // COUNTED in cnt[n] (reported through bad_edges) -- the reference's dense indexing raises an IndexError instead
+      const int64_t r = ei[i], c = ei[E + i];
+      if (r < 0 || r >= n || c < 0 || c >= n) { atomicAdd(&cnt[n], 1); continue; }
+      atomicAdd(&cnt[(int)r], 1);
+    } else {
+      atomicAdd(&cnt[(int)(i - E)], 1);
+    }
   }
 }
 
@@ -49,7 +56,11 @@ __global__ void k_fill_rows(const int64_t* __restrict__ ei, int64_t E, int n, in
   const int64_t total = E + (add_diag ? n : 0);
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     int r, c;
-    if (i < E) { r = (int)ei[i]; c = (int)ei[E + i]; } else { r = c = (int)(i - E); }
+    if (i < E) {
+      const int64_t r64 = ei[i], c64 = ei[E + i];
+      if (r64 < 0 || r64 >= n || c64 < 0 || c64 >= n) continue;       // dropped and counted by k_hist_rows
+      r = (int)r64; c = (int)c64;
+    } else { r = c = (int)(i - E); }
     const int pos = start[r] + atomicAdd(&cursor[r], 1);
     colraw[pos] = c;
   }
@@ -73,8 +84,9 @@ __global__ void k_sort_dedup_rows(const int* __restrict__ start, int* __restrict
 }
 
 __global__ void k_compact_rows(const int* __restrict__ start, const int* __restrict__ colraw, const int* __restrict__ rowptr, int n,
-                               int* __restrict__ col, int* __restrict__ rowidx) {
+                               int* __restrict__ col, int* __restrict__ rowidx, const int* __restrict__ bad_cnt, int* __restrict__ bad_out) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r == 0) *bad_out = *bad_cnt;      // number of out-of-range edges that were dropped (0 for a well-formed batch)
   if (r >= n) return;
   const int s = start[r], d = rowptr[r], u = rowptr[r + 1] - d;
   for (int k = 0; k < u; ++k) { col[d + k] = colraw[s + k]; rowidx[d + k] = r; }
@@ -112,6 +124,12 @@ __global__ void k_sort_pairs_rows(const int* __restrict__ start, int* __restrict
   }
 }
 
+// ws[cgc_csr_bad_edges_offset()] receives the number of edges whose ids were outside [0, n) (they are dropped)
+extern "C" int64_t cgc_csr_bad_edges_offset(int64_t E, int n, int add_diag) {
+  const int64_t cap = E + (add_diag ? n : 0);
+  return 3 * ((int64_t)n + 1) + (cap > 1 ? cap : 1);
+}
+
 extern "C" int cgc_csr_build(const int64_t* edge_index, int64_t E, int n, int add_diag, int* rowptr, int* col, int* rowidx,
                              int* t_rowptr, int* t_col, int* t_perm, int* ws, cgc_stream_t stream_) {
   hipStream_t stream = as_stream(stream_);
@@ -119,6 +137,7 @@ extern "C" int cgc_csr_build(const int64_t* edge_index, int64_t E, int n, int ad
   if (n == 0) {
     (void)hipMemsetAsync(rowptr, 0, sizeof(int), stream);
     (void)hipMemsetAsync(t_rowptr, 0, sizeof(int), stream);
+    (void)hipMemsetAsync(ws + cgc_csr_bad_edges_offset(E, n, add_diag), 0, sizeof(int), stream);
     return 0;
   }
   const int64_t cap64 = E + (add_diag ? n : 0);
@@ -138,7 +157,8 @@ extern "C" int cgc_csr_build(const int64_t* edge_index, int64_t E, int n, int ad
   hipLaunchKernelGGL(k_fill_rows, dim3(g_edges), dim3(tb), 0, stream, edge_index, E, n, add_diag, start, cursor, colraw);
   hipLaunchKernelGGL(k_sort_dedup_rows, dim3(g_rows), dim3(tb), 0, stream, start, colraw, n, cnt);   // cnt := unique count
   hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, stream, cnt, rowptr, n);
-  hipLaunchKernelGGL(k_compact_rows, dim3(g_rows), dim3(tb), 0, stream, start, colraw, rowptr, n, col, rowidx);
+  hipLaunchKernelGGL(k_compact_rows, dim3(g_rows), dim3(tb), 0, stream, start, colraw, rowptr, n, col, rowidx, cnt + n,
+                     ws + cgc_csr_bad_edges_offset(E, n, add_diag));
   CGC_RETURN_IF_LAUNCH_FAILED();
 
   (void)hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)(n + 1), stream);

@@ -102,9 +102,22 @@ def evaluate(loader, model, vote, test_time=1, max_num_examples=None, batch_size
                 loader.dataset.set_val_epoch(rep)
             preds, labels = [], []
             for batch_idx, data in enumerate(loader):
-                if hasattr(model, 'local_chunk'):            # parallel.DataParallel: this rank scores its chunk of the list
-                    data = model.local_chunk(data)
-                    ypred = _forward_local(model, data)
+                if hasattr(model, 'local_chunk'):            # parallel.DataParallel: this rank scores its chunk of the list,
+                    data = model.local_chunk(data)           # then every rank receives every rank's results (rank order =
+                    ypred = _forward_local(model, data) if len(data) else model._idle_step()       # list order)
+                    if model.world > 1:
+                        mine = ([loader.dataset.idxlist[int(d.patch_idx)] for d in data],
+                                [int(v) for d in data for v in d.y.reshape(-1)], ypred.detach().cpu().numpy())
+                        parts = [None] * model.world
+                        torch.distributed.all_gather_object(parts, mine, group=model.group)
+                        names = [n for p in parts for n in p[0]]
+                        labels.append(np.asarray([v for p in parts for v in p[1]], dtype=np.int64))
+                        allp = np.concatenate([p[2] for p in parts if len(p[0])], 0)
+                        vote.batch_patch_result(names, allp.argmax(1))
+                        preds.append(allp)
+                        if max_num_examples is not None and (batch_idx + 1) * (batch_size or len(names)) > max_num_examples:
+                            break
+                        continue
                 else:                                        # bare module: collate here
                     from .data import Batch
                     dev = next(model.parameters()).device

@@ -6,9 +6,9 @@ Layout in HBM (all int32 / fp32, contiguous):
   val[cap] or None                 per-edge weight (only after ``_re_norm_adj``; None = all ones)
   inv_d[n]                         1 / max(rowsum, 1)   (DenseSAGEConv's clamped mean divisor)
   t_rowptr[n+1], t_col, t_perm     the transpose (for backward); t_perm -> slot in ``val``; t_val = val in transposed order
-  gptr[B+1]                        first node of each graph; nmax = max nodes per graph (host int)
+  gptr[B+1]                        first node of each graph; nmax = max nodes per graph, npad = rows per graph of the dense layout (host ints)
 n = total real nodes: padding rows of the dense layout are never materialised, their effect on
-BatchNorm statistics and on the max readout is applied analytically (count = B*nmax).
+BatchNorm statistics and on the max readout is applied analytically (count = B*npad).
 """
 import torch
 
@@ -16,11 +16,15 @@ from . import kernels
 
 
 class BatchGraph(object):
-    def __init__(self, n, counts, device):
+    def __init__(self, n, counts, device, npad=None):
         self.n = int(n)
         self.counts = [int(c) for c in counts]
         self.B = len(self.counts)
         self.nmax = max(self.counts) if self.counts else 0
+        # rows per graph of the reference's dense layout: the largest graph for a sparse Batch (model/utils.py:21), the
+        # loader's fixed padding (dataflow/data.py:234,268) for the dense-tuple input form
+        self.npad = self.nmax if npad is None else int(npad)
+        assert self.npad >= self.nmax, 'dense padding smaller than the largest graph'
         ptr = [0]
         for c in self.counts:
             ptr.append(ptr[-1] + c)
@@ -34,7 +38,7 @@ class BatchGraph(object):
     @property
     def padded_rows(self):
         """B * Nmax: the row count the reference's BatchNorm sees at level 1."""
-        return self.B * self.nmax
+        return self.B * self.npad
 
     @staticmethod
     def node_counts_of(batch):
@@ -49,7 +53,7 @@ class BatchGraph(object):
     @classmethod
     def from_batch(cls, batch, renorm_p=None):
         x, edge_index = batch.x, batch.edge_index
-        g = cls(x.shape[0], cls.node_counts_of(batch), x.device)
+        g = cls(x.shape[0], cls.node_counts_of(batch), x.device, getattr(batch, '_dense_rows', None))
         g._build(edge_index.contiguous(), renorm_p)
         return g
 
@@ -59,6 +63,7 @@ class BatchGraph(object):
         self.rowptr, self.col, self.rowidx = s['rowptr'], s['col'], s['rowidx']
         self.t_rowptr, self.t_col, self.t_perm = s['t_rowptr'], s['t_col'], s['t_perm']
         self.cap = s['cap']
+        self.bad_edges = s.get('bad_edges')        # device counter of edges with ids outside [0, n) (dropped by the build)
         if renorm_p is not None:
             self.renorm_p = float(renorm_p)
             self.val = torch.empty(max(self.cap, 1), dtype=torch.float32, device=self.col.device)
@@ -69,6 +74,14 @@ class BatchGraph(object):
             K.csr_transpose_vals(self.t_rowptr, self.t_perm, self.val, self.n, self.t_val)
         self.inv_d = torch.empty(max(self.n, 1), dtype=torch.float32, device=self.col.device)
         K.csr_invdeg(self.rowptr, self.val, self.n, self.inv_d)
+
+    def validate(self):
+        """Raise if edge_index referred to nodes outside the batch (one device sync; network.py calls it when
+        CGC_VALIDATE_INPUTS=1, tests always).  The reference fails with an IndexError in to_dense_adj (model/utils.py:28-33)."""
+        bad = int(self.bad_edges) if self.bad_edges is not None else 0
+        if bad:
+            raise IndexError('%d edge(s) reference node ids outside [0, %d): edge_index does not belong to this batch' % (bad, self.n))
+        return self
 
     @property
     def nnz(self):

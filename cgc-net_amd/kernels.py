@@ -30,7 +30,8 @@ class KernelSpec(object):
         every i (needed by edge_renorm, whose result always has a diagonal).  Returns a dict of
         int32 tensors: rowptr[n+1], col[cap], rowidx[cap], t_rowptr[n+1], t_col[cap], t_perm[cap]
         with cap = E (+n); entries at or beyond nnz = rowptr[n] are undefined.  t_col[k] is the
-        source row of transposed slot k and t_perm[k] its slot in the forward arrays.
+        source row of transposed slot k and t_perm[k] its slot in the forward arrays.  Edges with an id outside [0, n) are
+        dropped and counted in ``bad_edges`` (int32 [1] on the device; the reference's dense indexing raises instead).
         """
         raise NotImplementedError
 
@@ -223,7 +224,7 @@ if _raw_stream is None or _cur_device is None:          # older / newer torch wi
         return torch.cuda.current_stream().cuda_stream
 
     def _cur_device():
-        return 0
+        return torch.cuda.current_device()
 
 
 def _ptr(t):
@@ -288,9 +289,16 @@ class HipKernels(KernelSpec):
 
     @staticmethod
     def _dev(*ts):
+        # kernels are enqueued on the CURRENT device's current stream (_stream()): tensors living on another GPU would be
+        # touched from the wrong device's stream, unordered against torch's work on them -- refuse instead of racing
+        cur = _cur_device()
         for t in ts:
-            if t is not None and not t.is_cuda:
-                raise RuntimeError('cgc_net_amd kernels take GPU tensors only (got a %s tensor)' % t.device)
+            if t is not None:
+                if not t.is_cuda:
+                    raise RuntimeError('cgc_net_amd kernels take GPU tensors only (got a %s tensor)' % t.device)
+                if t.get_device() != cur:
+                    raise RuntimeError('tensor on cuda:%d but the current device is cuda:%d: wrap the call in '
+                                       'torch.cuda.device(...) / call torch.cuda.set_device first' % (t.get_device(), cur))
 
     # -- graph structure
     def csr_build(self, edge_index, n, add_diag):
@@ -309,6 +317,8 @@ class HipKernels(KernelSpec):
                                     _ptr(ws), self._stream())
         self._chk(rc, 'cgc_csr_build')
         out['cap'] = cap
+        o = int(self.lib.cgc_csr_bad_edges_offset(ctypes.c_int64(E), n, int(add_diag)))
+        out['bad_edges'] = ws[o:o + 1]              # device-side count of dropped out-of-range edges (no sync here)
         return out
 
     def collate(self, x, mean, std, gptr, num_graphs, batch_out, edge_index, eptr):

@@ -10,6 +10,7 @@ What differs from the reference, by design:
 * no ``.cuda()`` calls inside the model: it runs on the device its parameters live on.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -19,6 +20,7 @@ from . import ops
 from .graph import BatchGraph, uniform_ptr
 
 EPS = 1e-15
+_VALIDATE_INPUTS = os.environ.get('CGC_VALIDATE_INPUTS', '0') == '1'     # one device sync per batch: off by default
 RENORM_P = 0.4      # model/network.py:260,271,280
 
 
@@ -349,11 +351,14 @@ class SoftPoolingGcnEncoder(nn.Module):
         flat.x = x[real]
         flat.edge_index = torch.stack([off[b] + r, off[b] + c])
         flat._node_counts = counts
+        flat._dense_rows = N          # the loader's padding (dataflow/data.py:234,268): BN row count B*N, readout vs zero rows
         return flat
 
     # -- stages --------------------------------------------------------------------------------
     def _level1(self, data):
         g = BatchGraph.from_batch(data, RENORM_P if self.norm_adj else None)
+        if _VALIDATE_INPUTS:
+            g.validate()
         self.last_graph = g
         x = data.x
         emb_blk, pool_blk = self.GCN_embed_1, self.GCN_pool_1
@@ -366,7 +371,7 @@ class SoftPoolingGcnEncoder(nn.Module):
             embed = emb_blk.forward_graph(x, g, agg0)
         if self.jk:
             embed = self.jk1(embed)
-        readout = ops.segment_max(embed, g.gptr, g.B, g.nmax)
+        readout = ops.segment_max(embed, g.gptr, g.B, g.npad)
         # the assignment matrix last: the wide aggregation A*S right behind it finds S's tail in the Infinity Cache
         s = pool_blk._tail(outs_p, softmax=True) if outs_p is not None else pool_blk.forward_graph(x, g, agg0, softmax=True)
         if self.collect_assign:
@@ -377,7 +382,7 @@ class SoftPoolingGcnEncoder(nn.Module):
     @staticmethod
     def _pad_assign(s, g):
         """[Ntot, C] -> the reference's [B, Nmax, C]; its padded rows hold softmax(0) = 1/C."""
-        out = s.new_full((g.B, g.nmax, s.shape[1]), 1.0 / s.shape[1])
+        out = s.new_full((g.B, g.npad, s.shape[1]), 1.0 / s.shape[1])
         for b in range(g.B):
             out[b, :g.counts[b]] = s[g.gptr_host[b]:g.gptr_host[b + 1]]
         return out

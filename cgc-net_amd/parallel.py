@@ -35,6 +35,7 @@ class DataParallel(nn.Module):
         self._params = [p for p in module.parameters() if p.requires_grad]
         self._flat = None
         self._pending = False
+        self._active = self.world        # ranks that received graphs in the current step (see local_chunk)
         if self.world > 1:
             with torch.no_grad():                      # replicas start from rank 0's weights and buffers
                 for t in list(module.parameters()) + list(module.buffers()):
@@ -67,26 +68,41 @@ class DataParallel(nn.Module):
             off += g.numel()
         torch._foreach_copy_(views, grads)
         dist.all_reduce(self._flat, op=dist.ReduceOp.SUM, group=self.group)
-        self._flat.div_(self.world)
+        self._flat.div_(self._active)      # mean over the replicas that ran (train.py:179 torch.mean(cls_loss))
         torch._foreach_copy_(grads, views)
 
     # ---- forward
     def local_chunk(self, data_list):
         if self.world == 1 or not self.shard_input:
             return data_list
+        # torch_geometric's scatter simply uses FEWER devices when the split yields fewer non-empty chunks (the last partial
+        # batch of an epoch, one huge graph dominating the node-count split): the ranks beyond them idle through the step
+        # -- they still join the gradient all-reduce, contributing zeros -- and the mean is taken over the active replicas
         chunks = partition_by_nodes(data_list, self.world)
-        if len(chunks) != self.world:
-            raise ValueError('cannot split %d graphs over %d ranks' % (len(data_list), self.world))
-        return chunks[self.rank]
+        self._active = len(chunks)
+        return chunks[self.rank] if self.rank < len(chunks) else []
+
+    def _idle_step(self):
+        """This rank got no graphs: empty logits; in training mode a zero loss that still reaches every parameter, so that
+        backward fires the hooks and the rank takes part in the all-reduce."""
+        out_dim = [m for m in self.module.modules() if isinstance(m, nn.Linear)][-1].out_features
+        logits = torch.zeros(0, out_dim, device=self.device)
+        if not self.module.training:
+            return logits
+        return logits, sum(p.sum() for p in self._params) * 0.0
 
     def forward(self, data_list):
         """data_list: python list of Data (the DataListLoader protocol).  Returns what the module returns
         for this rank's chunk: ``(logits, loss)`` in training mode, ``logits`` in eval mode."""
         if hasattr(data_list, 'edge_index'):          # an already collated (device-resident) Batch of THIS rank
+            self._active = self.world
             return self.module(data_list)
         if len(data_list) == 0:
             raise ValueError('empty batch')
+        chunk = self.local_chunk(data_list)
+        if len(chunk) == 0:
+            return self._idle_step()
         # loader front-end on the device: one packed copy + one kernel (data.py / csrc/collate.hip), optionally with the
         # k-NN graph construction and the feature z-scoring the reference does per item on the host
-        batch = Batch.from_data_list(self.local_chunk(data_list), device=self.device, **self.front_end)
+        batch = Batch.from_data_list(chunk, device=self.device, **self.front_end)
         return self.module(batch)

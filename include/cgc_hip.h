@@ -36,7 +36,11 @@ int cgc_abi_version(void);
  * edge_index: int64 [2,E] (row 0 = aggregating centre, row 1 = neighbour), any order, duplicates allowed.
  * Produces column-sorted, de-duplicated CSR (rowptr[n+1], col[cap], rowidx[cap]) and its transpose
  * (t_rowptr[n+1], t_col[cap] = source row, t_perm[cap] = slot in the forward arrays); cap = E + (add_diag? n : 0).
- * nnz = rowptr[n] stays on the device.  ws: int32 workspace of 3*(n+1) + 2*cap elements. */
+ * nnz = rowptr[n] stays on the device.  ws: int32 workspace of 3*(n+1) + 2*max(cap,1) elements.
+ * Edges with an id outside [0, n) are DROPPED (never dereferenced) and counted: after the call
+ * ws[cgc_csr_bad_edges_offset(E, n, add_diag)] holds their number (0 for a well-formed batch) -- the device-side
+ * counterpart of the IndexError the reference's dense indexing raises (model/utils.py:28-33). */
+int64_t cgc_csr_bad_edges_offset(int64_t E, int n, int add_diag);
 int cgc_csr_build(const int64_t* edge_index, int64_t E, int n, int add_diag,
                   int* rowptr, int* col, int* rowidx, int* t_rowptr, int* t_col, int* t_perm,
                   int* ws, cgc_stream_t stream);

@@ -51,6 +51,9 @@ class TorchKernels(KernelSpec):
     # ------------------------------------------------------------------ graph structure
     def csr_build(self, edge_index, n, add_diag):
         row, col = edge_index[0], edge_index[1]
+        ok = (row >= 0) & (row < n) & (col >= 0) & (col < n)
+        bad = int((~ok).sum())
+        row, col = row[ok], col[ok]
         if add_diag:
             ar = torch.arange(n, dtype=torch.int64, device=row.device)
             row, col = torch.cat([row, ar]), torch.cat([col, ar])
@@ -69,7 +72,8 @@ class TorchKernels(KernelSpec):
             return out
         tkey, tperm = torch.sort(col * n + row)      # transposed order: by col, then by row
         return {'rowptr': ptr_of(row), 'col': padded(col), 'rowidx': padded(row),
-                't_rowptr': ptr_of(col), 't_col': padded(tkey % n), 't_perm': padded(tperm), 'cap': cap}
+                't_rowptr': ptr_of(col), 't_col': padded(tkey % n), 't_perm': padded(tperm), 'cap': cap + bad,
+                'bad_edges': torch.tensor([bad], dtype=i32, device=row.device)}
 
     @staticmethod
     def _rows(rowptr, n):

@@ -9,6 +9,7 @@ import types
 
 import numpy as np
 
+sys.dont_write_bytecode = True      # /root/reference is read-only: no __pycache__ may be left behind there
 sys.path.insert(0, '/root/reference')
 from common import metric  # noqa: E402
 

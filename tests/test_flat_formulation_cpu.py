@@ -154,3 +154,76 @@ def test_dense_tuple_input_and_operator_contracts(torch_kernels):
     (got * w).sum().backward()
     (want * w).sum().backward()
     assert rel_err(xg.grad, xr.grad) < TOL_GRAD and rel_err(ag.grad, ar.grad) < TOL_GRAD
+
+
+def _padded_dense_case(pad, seed=9, all_negative=True):
+    """Dense-tuple inputs whose padding N exceeds the largest graph (the reference's dense loader pads to a FIXED
+    max_num_nodes, dataflow/data.py:234,268): the BatchNorm row count is B*N and every graph's readout competes with zero rows."""
+    from cgc_net_amd.data import Batch, SyntheticCellGraphs
+    from oracle import dense_ref
+    ds = SyntheticCellGraphs(3, 40, num_features=6, base_seed=seed)
+    b = Batch.from_data_list([ds[i] for i in range(3)])
+    adj = dense_ref.to_dense_adj(b.edge_index, b.batch)
+    x, counts = dense_ref.to_dense_batch(b.x, b.batch)
+    N = adj.shape[1] + pad
+    adj_p = torch.zeros(3, N, N)
+    adj_p[:, :adj.shape[1], :adj.shape[1]] = adj
+    x_p = torch.zeros(3, N, x.shape[2])
+    x_p[:, :x.shape[1]] = x
+    return b, x_p, adj_p, counts
+
+
+def test_dense_tuple_padded_beyond_largest_graph(torch_kernels):
+    from oracle import dense_ref
+    b, x, adj, counts = _padded_dense_case(pad=7)
+    args = (80, 6, 8, 8, True, True, 8, 3, 0.2, [50])
+    torch.manual_seed(1)
+    ref = dense_ref.SoftPoolingGcnEncoder(*args, load_data_sparse=False, collect_assign=True)
+    model = network.SoftPoolingGcnEncoder(*args, load_data_sparse=False, collect_assign=True)
+    model.load_state_dict(ref.state_dict())
+    model.train(), ref.train()
+    (rl, rloss), (gl, gloss) = ref((x, adj, counts, b.y)), model((x, adj, counts, b.y))
+    assert rel_err(gl, rl) < TOL and rel_err(gloss, rloss) < TOL
+    assert model.assign_matrix[0].shape == ref.assign_matrix[0].shape == (3, x.shape[1], 16)
+    assert rel_err(model.assign_matrix[0], ref.assign_matrix[0]) < TOL
+    rloss.backward(), gloss.backward()
+    gref = dict(ref.named_parameters())
+    for k, p in model.named_parameters():
+        assert rel_err(p.grad, gref[k].grad) < TOL_GRAD, k
+    rbuf = dict(ref.named_buffers())
+    for k, a in model.named_buffers():          # running statistics with count = B*N (padding included)
+        if a.dtype.is_floating_point:
+            assert rel_err(a, rbuf[k]) < TOL, k
+    model.eval(), ref.eval()
+    assert rel_err(model((x, adj, counts)), ref((x, adj, counts))) < TOL
+
+
+@pytest.mark.parametrize('flags,lo,hi', [(dict(), 0.0, 1e-4), (dict(norm_adj=True, jk=True), 0.0, 1e-4),
+                                         (dict(gcn_name='GIN'), 5e-4, 3e-3)], ids=['plain', 'shipped', 'GIN'])
+def test_fp32_rounding_spread_of_the_reference_algorithm(flags, lo, hi):
+    """What the gradient tolerances of the parity tests rest on: the REFERENCE's own algorithm (dense oracle) evaluated in
+    fp32 vs in fp64 on the same input and weights.  The SAGE variants (L2-normalised, mean aggregation) stay inside 1e-4 of
+    the fp64 gradients, so two correct fp32 implementations may differ by up to twice that and 5e-4 (TOL_GRAD) is a real
+    bound; the GIN variant (no normalisation, sum aggregation) is ill-conditioned: its fp32 gradients are already
+    ~1.3e-3 away from fp64, which is why tests/test_model_gpu.py holds GIN to 3e-3 and nothing tighter is meaningful."""
+    import copy
+    from cgc_net_amd.data import Batch, SyntheticCellGraphs
+    from oracle import dense_ref
+    ds = SyntheticCellGraphs(6, 300, num_features=16, base_seed=42)
+    b = Batch.from_data_list([ds[i] for i in range(6)])
+    adj = dense_ref.to_dense_adj(b.edge_index, b.batch)
+    x, counts = dense_ref.to_dense_batch(b.x, b.batch)
+    kw = dict(concat=True, load_data_sparse=False, drop_out=0.)
+    kw.update(flags)
+    torch.manual_seed(3)
+    m32 = dense_ref.SoftPoolingGcnEncoder(600, 16, 20, 20, True, True, 20, 3, 0.1, [50], **kw)
+    m64 = copy.deepcopy(m32).double()
+    m32.train(), m64.train()
+    l32, s32 = m32((x, adj.clone(), counts, b.y))
+    l64, s64 = m64((x.double(), adj.double(), counts, b.y))
+    assert l64.dtype == torch.float64
+    s32.backward(), s64.backward()
+    assert rel_err(l32, l64) < 1e-5
+    g64 = dict(m64.named_parameters())
+    spread = max(rel_err(p.grad, g64[k].grad) for k, p in m32.named_parameters())
+    assert lo <= spread < hi, spread

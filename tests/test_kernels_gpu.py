@@ -66,6 +66,28 @@ def build_both(ei, n, add_diag):
     return want, got
 
 
+def test_csr_build_drops_and_counts_out_of_range_edges():
+    """A foreign Batch / bad node offset: ids outside [0, n) never reach the atomics; they are dropped and reported."""
+    from cgc_net_amd.graph import BatchGraph
+    ei, n = random_graph([40, 33], seed=4)
+    bad = torch.tensor([[3, n, -1, 5, 7], [n + 5, 2, 4, -7, 1 << 40]], dtype=torch.int64)
+    dirty = torch.cat([ei[:, :50], bad, ei[:, 50:]], dim=1)
+    for add_diag in (False, True):
+        want, got = build_both(ei, n, add_diag)
+        _, got_dirty = build_both(dirty, n, add_diag)
+        nnz = int(want['rowptr'][n])
+        assert int(got['bad_edges']) == 0 and int(got_dirty['bad_edges']) == 5
+        assert torch.equal(got_dirty['rowptr'].cpu(), want['rowptr']) and torch.equal(got_dirty['t_rowptr'].cpu(), want['t_rowptr'])
+        for k in ('col', 'rowidx', 't_col', 't_perm'):
+            assert torch.equal(got_dirty[k].cpu()[:nnz], want[k][:nnz]), k
+    b = type('B', (), {})()
+    b.x, b.edge_index, b._node_counts = torch.zeros(n, 4, device=DEV), g(dirty), [40, 33]
+    with pytest.raises(IndexError):
+        BatchGraph.from_batch(b).validate()
+    b.edge_index = g(ei)
+    BatchGraph.from_batch(b).validate()
+
+
 @pytest.mark.parametrize('counts,add_diag', [([5, 9, 12], False), ([5, 9, 12], True), ([300, 0, 257, 64], False),
                                              ([1800, 2100, 1500], True)])
 def test_csr_build_bit_exact(counts, add_diag):

@@ -112,6 +112,36 @@ def test_dense_tuple_input_form_and_eval():
             assert rel_err(got, want) < TOL
 
 
+def test_dense_tuple_padded_beyond_largest_graph():
+    """The dense loader pads to a fixed max_num_nodes (dataflow/data.py:234,268): N > max(counts) changes the BatchNorm
+    row count (B*N), makes every readout compete with zero rows and fixes the assignment matrix's shape."""
+    from test_flat_formulation_cpu import _padded_dense_case
+    b, x, adj, counts = _padded_dense_case(pad=7)
+    args = (80, 6, 8, 8, True, True, 8, 3, 0.2, [50])
+    torch.manual_seed(1)
+    ref = dense_ref.SoftPoolingGcnEncoder(*args, load_data_sparse=False, collect_assign=True)
+    model = network.SoftPoolingGcnEncoder(*args, load_data_sparse=False, collect_assign=True)
+    model.load_state_dict(ref.state_dict())
+    model.to(DEV).train()
+    ref.train()
+    rl, rloss = ref((x, adj, counts, b.y))
+    gl, gloss = model((x.to(DEV), adj.to(DEV), counts, b.y.to(DEV)))
+    assert rel_err(gl, rl) < TOL and rel_err(gloss, rloss) < TOL
+    assert tuple(model.assign_matrix[0].shape) == tuple(ref.assign_matrix[0].shape)
+    assert rel_err(model.assign_matrix[0], ref.assign_matrix[0]) < TOL
+    rloss.backward(), gloss.backward()
+    gref = dict(ref.named_parameters())
+    for k, p in model.named_parameters():
+        assert rel_err(p.grad, gref[k].grad) < TOL_GRAD, k
+    rbuf = dict(ref.named_buffers())
+    for k, a in model.named_buffers():
+        if a.dtype.is_floating_point:
+            assert rel_err(a, rbuf[k]) < TOL, k
+    model.eval(), ref.eval()
+    with torch.no_grad():
+        assert rel_err(model((x.to(DEV), adj.to(DEV), counts)), ref((x, adj, counts))) < TOL
+
+
 def test_operator_modules_vs_oracle():
     """DenseSAGEConv / GNN_Module dense-tensor contracts incl. mask and add_loop."""
     torch.manual_seed(0)

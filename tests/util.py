@@ -43,3 +43,18 @@ def rel_err(a, b, atol=1e-7):
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
     assert a.shape == b.shape, (a.shape, b.shape)
     return float((a - b).abs().max() / (float(b.abs().max()) + atol / 1e-4))
+
+
+def elementwise_excess(a, b, rtol=1e-4, atol=None):
+    """Elementwise yardstick beside the max-norm one: the largest value of |a-b| / (rtol*|b| + atol) over all elements
+    (<= 1 means every element satisfies |a-b| <= rtol*|b| + atol).  ``atol`` defaults to rtol * rms(b) + 1e-7: the rounding
+    error of an fp32 sum of mixed-sign terms scales with the magnitude of the TERMS, not with the (possibly cancelled)
+    result, so elements near zero are held to rtol times the tensor's typical magnitude; that is still up to
+    max|b|/rms(b) times tighter for them than the max-norm bound."""
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    if b.numel() == 0:
+        return 0.0
+    if atol is None:
+        atol = rtol * float(b.pow(2).mean().sqrt()) + 1e-7
+    return float(((a - b).abs() / (rtol * b.abs() + atol)).max())
