@@ -9,6 +9,7 @@ PROTOTYPES = {
     'cgc_csr_build': [P, L, I, I, P, P, P, P, P, P, P, P],
     'cgc_collate': [P, I, I, P, P, P, I, P, P, L, P, P],
     'cgc_farthest_point_sample': [P, P, I, I, P, P, P, P],
+    'cgc_farthest_point_sample_table16': [P, P, I, I, P, P, P, P],
     'cgc_radius_knn_ws_ints': [I, I],
     'cgc_radius_knn': [P, P, I, I, F, I, I, P, P, P, P, P],
     'cgc_knn_emit_edges': [P, P, I, I, L, P, P],

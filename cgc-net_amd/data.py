@@ -299,37 +299,78 @@ def fuse_sample(pos, k, rng, farthest_frac=0.7):
     return np.sort(np.concatenate([chosen, extra]))
 
 
-def sample_nodes_batch(pos, counts, ratio, method='fuse', generator=None, farthest_frac=0.7, start=None):
+def sample_nodes_batch(pos, counts, ratio, method='fuse', generator=None, farthest_frac=0.7, start=None,
+                       distance='coords', rng='torch', order='ascending'):
     """Node sub-sampling for a batch of graphs on the device (dataflow/data.py:195-225): per graph keep
     ``int(n_g * ratio)`` nodes -- 'farthest': farthest-point sampling; 'fuse': 70 % farthest-point + 30 % uniform random
     from the rest; 'random': uniform.  ``pos`` [n,2] float32 on the GPU (graphs concatenated), ``counts`` python list of
-    nodes per graph.  Returns (indices int64 [sum k_g] ascending within each graph, list k_g).  Farthest-point picks run
-    in csrc/fps.hip from the coordinates (the reference reads rows of an n x n int16 distance table); the first pick of a
-    graph is drawn at random as in the reference (``start`` fixes it, for tests)."""
+    nodes per graph.  Returns (indices int64, list k_g).  Farthest-point picks run in csrc/fps.hip from the coordinates (the
+    reference reads rows of an n x n int16 distance table); the first pick of a graph is drawn at random as in the reference
+    (``start`` fixes it, for tests).
+
+    ``distance``: 'coords' = exact squared distances (fp64); 'int16' = the entries of the reference's distance table,
+    int16(sqrt(dx^2+dy^2)) in float32 (dataflow/construct_feature_graph.py:17-24), recomputed on the fly: the farthest-point
+    picks are then index for index those of ``FarthestSampler`` (common/utils.py:187-197) on the stored table.
+    ``rng``: 'torch' = the random part is drawn on the device (``generator``); 'python' = as the reference does,
+    ``random.sample(remaining indices in ascending order, k)`` on the host (dataflow/data.py:213-215; numpy's
+    ``np.random.choice`` for method 'random', :221) -- seed ``random`` / ``numpy.random`` to reproduce its picks.
+    ``order``: 'ascending' = indices sorted within each graph; 'reference' = the reference's order per graph, farthest
+    picks in pick order followed by the random picks in draw order (``np.concatenate((far_indice, rand_indice))``, :217)."""
     from . import kernels
     K = kernels.get()
+    assert distance in ('coords', 'int16') and rng in ('torch', 'python') and order in ('ascending', 'reference')
     dev, B = pos.device, len(counts)
     ks = [int(c * ratio) for c in counts]
     kf = [int(k * farthest_frac) if method == 'fuse' else (k if method == 'farthest' else 0) for k in ks]
     gptr_h = np.concatenate([[0], np.cumsum(counts)])
     gptr = torch.tensor(gptr_h, dtype=torch.int32, device=dev)
-    gid = torch.repeat_interleave(torch.arange(B, device=dev), torch.tensor(counts, device=dev))
-    taken = torch.zeros(int(gptr_h[-1]), dtype=torch.bool, device=dev)
+    far = None
     if sum(kf) > 0:
         if start is None:
-            start = [int(torch.randint(max(c, 1), (1,), generator=generator)) for c in counts]
-        optr = torch.tensor(np.concatenate([[0], np.cumsum(kf)]), dtype=torch.int32, device=dev)
+            if rng == 'python':          # FarthestSampler: farthest_pts[0] = np.random.randint(arr.shape[0])
+                start = [int(np.random.randint(max(c, 1))) for c in counts]
+            else:
+                start = [int(torch.randint(max(c, 1), (1,), generator=generator)) for c in counts]
+        optr_h = np.concatenate([[0], np.cumsum(kf)])
+        optr = torch.tensor(optr_h, dtype=torch.int32, device=dev)
         far = torch.empty(sum(kf), dtype=torch.int32, device=dev)
         K.farthest_point_sample(pos[:, :2].to(torch.float32).contiguous(), gptr, B, max(counts),
-                                torch.tensor(start, dtype=torch.int32, device=dev), optr, far)
-        taken[far.long()] = True
+                                torch.tensor(start, dtype=torch.int32, device=dev), optr, far, distance == 'int16')
     need = [k - f for k, f in zip(ks, kf)]
+    if rng == 'python' or order == 'reference':
+        # host-side composition, graph by graph, exactly as dataflow/data.py:205-221 composes ``indice``
+        import random as pyrandom
+        far_h = far.cpu().numpy().astype(np.int64) if far is not None else np.zeros(0, dtype=np.int64)
+        out = []
+        for g in range(B):
+            lo, n_g = int(gptr_h[g]), int(counts[g])
+            fg = far_h[optr_h[g]:optr_h[g + 1]] - lo if far is not None else np.zeros(0, dtype=np.int64)
+            if need[g] > 0:
+                if method == 'random':
+                    rg = np.random.choice(n_g, need[g], replace=False) if rng == 'python' else \
+                        torch.randperm(n_g, generator=generator)[:need[g]].numpy()
+                else:
+                    taken = set(fg.tolist())
+                    remain = [i for i in range(n_g) if i not in taken]              # filter_sampled_indice, common/utils.py:200-203
+                    if rng == 'python':
+                        rg = np.asarray(pyrandom.sample(remain, need[g]), dtype=np.int64)
+                    else:
+                        rg = np.asarray(remain, dtype=np.int64)[torch.randperm(len(remain), generator=generator)[:need[g]].numpy()]
+                ind = np.concatenate((fg, rg.astype(np.int64)), 0)
+            else:
+                ind = fg
+            out.append((np.sort(ind) if order == 'ascending' else ind) + lo)
+        return torch.from_numpy(np.concatenate(out) if out else np.zeros(0, dtype=np.int64)).to(dev), ks
+    gid = torch.repeat_interleave(torch.arange(B, device=dev), torch.tensor(counts, device=dev))
+    taken = torch.zeros(int(gptr_h[-1]), dtype=torch.bool, device=dev)
+    if far is not None:
+        taken[far.long()] = True
     if sum(need) > 0:
         # uniform without replacement from the rest: random keys, nodes already taken pushed to the end of their graph
         key = torch.rand(taken.shape[0], device=dev, generator=generator) + taken.to(torch.float32) * 2.0
-        order = torch.argsort(gid.to(torch.float32) * 4.0 + key)         # graph-major, random within a graph
-        rank = torch.arange(taken.shape[0], device=dev) - gptr[:-1].long()[gid[order]]
-        pick = order[rank < torch.tensor(need, device=dev)[gid[order]]]
+        order_ = torch.argsort(gid.to(torch.float32) * 4.0 + key)         # graph-major, random within a graph
+        rank = torch.arange(taken.shape[0], device=dev) - gptr[:-1].long()[gid[order_]]
+        pick = order_[rank < torch.tensor(need, device=dev)[gid[order_]]]
         taken[pick] = True
     return torch.nonzero(taken).squeeze(1), ks
 

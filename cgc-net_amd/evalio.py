@@ -136,3 +136,47 @@ def evaluate(loader, model, vote, test_time=1, max_num_examples=None, batch_size
     if was_training:
         model.train()
     return {'patch_acc': float((lab == pred).mean()), 'img_acc': img_acc, 'binary_acc': binary_acc}
+
+
+# ------------------------------------------------------------------ GEXF export of the assignment matrices (common/utils.py:48-79)
+def cluster_labels(assign_matrix_list):
+    """Per ORIGINAL node its cluster at every pooling level: level 1 = argmax of its row of S1, level k = the level-k cluster
+    of its level-(k-1) cluster (the mapping chain of common/utils.py:55-71).  Returns {'assign_1': [n] ints, ...}."""
+    out, prev = {}, None
+    for level, s in enumerate(assign_matrix_list, 1):
+        s = s.detach().cpu().numpy() if torch.is_tensor(s) else np.asarray(s)
+        hard = np.argmax(s, axis=1)
+        prev = hard if prev is None else hard[prev]
+        out['assign_%d' % level] = prev.astype(np.int64)
+    return out
+
+
+def output_to_gexf(coordinate, adj, assign_matrix_list, path):
+    """Write one graph with node attributes ``x``, ``y``, ``assign_1..k`` as GEXF (the reference's visualisation export;
+    same signature).  ``coordinate`` [n, 2]; ``assign_matrix_list``: per level the soft assignment of ONE graph ([n, C1],
+    [C1, C2], ...; take ``model.assign_matrix[k][b, :n_b]``); ``adj``: the dense [n, n] matrix the reference passes, or -- so
+    that no n x n tensor is needed -- an ``edge_index`` [2, E] (integer dtype)."""
+    import networkx as nx
+    coordinate = coordinate.detach().cpu().numpy() if torch.is_tensor(coordinate) else np.asarray(coordinate)
+    n = coordinate.shape[0]
+    G = nx.Graph()
+    G.add_nodes_from(range(n))
+    a = adj.detach().cpu() if torch.is_tensor(adj) else torch.as_tensor(np.asarray(adj))
+    if not a.dtype.is_floating_point and a.dim() == 2 and a.shape[0] == 2 and a.shape[1] != 2:      # edge list
+        ei = a.numpy()
+        G.add_edges_from(((int(u), int(v), {'weight': 1.0}) for u, v in zip(ei[0], ei[1])))
+    else:
+        assert a.shape[0] == a.shape[1] == n, 'the adjacent matrix should have same row and col'
+        a = a.numpy()
+        rows, cols = np.nonzero(a)
+        G.add_edges_from(((int(u), int(v), {'weight': float(a[u, v])}) for u, v in zip(rows, cols)))
+    for name, lab in cluster_labels(assign_matrix_list).items():
+        assert lab.shape[0] == n, 'assignment matrices must belong to this graph (rows = its nodes)'
+        nx.set_node_attributes(G, {i: int(v) for i, v in enumerate(lab)}, name)
+    nx.set_node_attributes(G, dict(enumerate(coordinate[:, 0].tolist())), 'x')
+    nx.set_node_attributes(G, dict(enumerate(coordinate[:, 1].tolist())), 'y')
+    d = os.path.dirname(path)
+    if d:
+        os.makedirs(d, exist_ok=True)
+    nx.write_gexf(G, path)
+    return G

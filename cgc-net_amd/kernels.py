@@ -41,10 +41,12 @@ class KernelSpec(object):
         node offset gptr[g] of its graph, the edges of graph g being [eptr[g], eptr[g+1]) (None: skipped)."""
         raise NotImplementedError
 
-    def farthest_point_sample(self, pos, gptr, num_graphs, max_nodes, start, optr, out):
+    def farthest_point_sample(self, pos, gptr, num_graphs, max_nodes, start, optr, out, table16=False):
         """Farthest-point sampling per graph (FarthestSampler, common/utils.py:187-197, on coordinates instead of the
         distance table): pos [n,2] f32, gptr int32 [B+1], start int32 [B] first pick (local index), optr int32 [B+1]
-        offsets of the picks, out int32 [optr[B]] global node ids in pick order; ties -> lowest index."""
+        offsets of the picks, out int32 [optr[B]] global node ids in pick order; ties -> lowest index.
+        table16=False: squared fp64 distances.  table16=True: the reference's table entries int16(sqrt(dx^2+dy^2)) in
+        float32 (dataflow/construct_feature_graph.py:17-24) -- the reference's picks index for index."""
         raise NotImplementedError
 
     def radius_knn(self, pos, gptr, num_graphs, r, k, loop):
@@ -330,11 +332,12 @@ class HipKernels(KernelSpec):
                                        _ptr(batch_out), _ptr(edge_index), ctypes.c_int64(E), _ptr(eptr), self._stream()),
                   'cgc_collate')
 
-    def farthest_point_sample(self, pos, gptr, num_graphs, max_nodes, start, optr, out):
+    def farthest_point_sample(self, pos, gptr, num_graphs, max_nodes, start, optr, out, table16=False):
         self._dev(pos, gptr, start, optr, out)
         assert pos.dtype == torch.float32 and pos.is_contiguous() and pos.shape[1] == 2
-        self._chk(self.lib.cgc_farthest_point_sample(_ptr(pos), _ptr(gptr), num_graphs, max_nodes, _ptr(start), _ptr(optr),
-                                                     _ptr(out), self._stream()), 'cgc_farthest_point_sample')
+        fn = self.lib.cgc_farthest_point_sample_table16 if table16 else self.lib.cgc_farthest_point_sample
+        self._chk(fn(_ptr(pos), _ptr(gptr), num_graphs, max_nodes, _ptr(start), _ptr(optr), _ptr(out), self._stream()),
+                  'cgc_farthest_point_sample')
 
     def radius_knn(self, pos, gptr, num_graphs, r, k, loop):
         self._dev(pos, gptr)

@@ -60,6 +60,12 @@ int cgc_collate(float* x, int n, int F, const float* mean, const float* stdv, co
  * (k_g = optr[g+1]-optr[g] <= n_g); out int32 GLOBAL node ids in pick order.  max_nodes = largest graph (<= 16384). */
 int cgc_farthest_point_sample(const float* pos, const int* gptr, int B, int max_nodes, const int* start, const int* optr,
                               int* out, cgc_stream_t stream);
+/* Reference-compatible variant: the distance between two nuclei is the entry the reference's table holds,
+ * int16(sqrt(dx*dx + dy*dy)) evaluated in float32 on the float32 coordinates (euc_dist,
+ * dataflow/construct_feature_graph.py:17-24), recomputed on the fly -- the picks equal FarthestSampler's on the stored table
+ * index for index (ties of the truncated distances -> lowest index).  Same arguments. */
+int cgc_farthest_point_sample_table16(const float* pos, const int* gptr, int B, int max_nodes, const int* start,
+                                      const int* optr, int* out, cgc_stream_t stream);
 
 /* ---- F2 (the step before the path): cell-graph construction.  Replaces torch_cluster.radius_graph(pos, r, None, loop,
  * max_num_neighbors) = cKDTree.query(k+1, distance_upper_bound = r+1e-8) per graph on the host (dataflow/data.py:246,255,

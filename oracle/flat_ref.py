@@ -92,10 +92,12 @@ class TorchKernels(KernelSpec):
             ep = eptr.long()
             edge_index += torch.repeat_interleave(gp[:-1], ep[1:] - ep[:-1]).unsqueeze(0)
 
-    def farthest_point_sample(self, pos, gptr, num_graphs, max_nodes, start, optr, out):
-        """common/utils.py:187-197 with the distance-table rows replaced by squared coordinate distances (float64)."""
+    def farthest_point_sample(self, pos, gptr, num_graphs, max_nodes, start, optr, out, table16=False):
+        """common/utils.py:187-197 with the distance-table rows replaced by squared coordinate distances (float64), or
+        (table16) by the table's own entries: float32 arithmetic + astype(int16) as in
+        dataflow/construct_feature_graph.py:17-24."""
         import numpy as np
-        p = pos.detach().cpu().numpy().astype(np.float64)
+        p = pos.detach().cpu().numpy().astype(np.float32 if table16 else np.float64)
         gp, op, st = gptr.cpu().numpy(), optr.cpu().numpy(), start.cpu().numpy()
         res = np.zeros(int(op[-1]), dtype=np.int32)
         for g in range(num_graphs):
@@ -108,7 +110,8 @@ class TorchKernels(KernelSpec):
             for i in range(k):
                 res[op[g] + i] = lo + cur
                 dx, dy = q[:, 0] - q[cur, 0], q[:, 1] - q[cur, 1]
-                dist = np.minimum(dist, dx * dx + dy * dy)
+                d = np.sqrt(dx ** 2 + dy ** 2).astype(np.int16) if table16 else dx * dx + dy * dy
+                dist = np.minimum(dist, d)
                 cur = int(dist.argmax())
         out.copy_(torch.from_numpy(res).to(out.device))
 

@@ -1,0 +1,143 @@
+"""GPU: F4 on the device -- the evaluation protocol (train.py:21-91) and the checkpoint interchange (train.py:202-207,
+common/utils.py:82-94) with the model, the forward passes and the optimizer state living on the MI355X; plus the
+data-parallel wrapper on a 1-rank RCCL ('nccl') process group (the engine-callback all-reduce runs once on hardware)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cgc_net_amd  # noqa: F401
+from cgc_net_amd import evalio, kernels, network
+from cgc_net_amd.data import Batch, DataListLoader, SyntheticCellGraphs
+from oracle import dense_ref
+from util import build_model, load_case, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+class _WithIdx(torch.utils.data.Dataset):
+    def __init__(self, ds, names):
+        self.ds, self.idxlist, self.epoch = ds, names, 0
+
+    def __len__(self):
+        return len(self.idxlist)
+
+    def __getitem__(self, i):
+        d = self.ds[i]
+        d.patch_idx = torch.tensor([i])
+        return d
+
+    def set_val_epoch(self, e):
+        self.epoch = e
+
+
+def test_evaluate_on_device_matches_oracle_protocol():
+    ds = SyntheticCellGraphs(8, 120, 16, base_seed=21)
+    names = ['/fold/img%d_grade_%d_patch%d.pt' % (i // 2, 1 + (i // 2) % 3, i) for i in range(8)]
+    loader = DataListLoader(_WithIdx(ds, names), batch_size=3)
+    gt = ['img%d_grade_%d' % (i, 1 + i % 3) for i in range(4)]
+    args = (240, 16, 20, 20, True, True, 20, 3, 0.1, [50])
+    kw = dict(concat=True, load_data_sparse=True, norm_adj=True, jk=True, drop_out=0.2)
+    torch.manual_seed(4)
+    ref = dense_ref.SoftPoolingGcnEncoder(*args, **kw)
+    model = network.SoftPoolingGcnEncoder(*args, **kw)
+    model.load_state_dict(ref.state_dict())
+    model.to(DEV).train()
+    vote = evalio.ImageLevelVote(gt)
+    res = evalio.evaluate(loader, model, vote, test_time=2)
+    assert kernels.is_native() and model.training and loader.dataset.epoch == 1
+    # the same protocol through the oracle on the host: identical votes and metrics
+    ref.eval()
+    vote_ref = evalio.ImageLevelVote(gt)
+    preds = []
+    with torch.no_grad():
+        for rep in range(2):
+            for lo in range(0, 8, 3):
+                items = [ds[i] for i in range(lo, min(lo + 3, 8))]
+                out = ref(Batch.from_data_list(items))
+                vote_ref.batch_patch_result(names[lo:lo + len(items)], out.argmax(1).numpy())
+                preds.append(out)
+    assert {k: sorted(v) for k, v in vote.prediction.items()} == {k: sorted(v) for k, v in vote_ref.prediction.items()}
+    img_acc, binary_acc = vote_ref.final_result()
+    assert res['img_acc'] == img_acc and res['binary_acc'] == binary_acc
+    model.eval()
+    with torch.no_grad():
+        got = torch.cat([model(Batch.from_data_list([ds[i] for i in range(lo, min(lo + 3, 8))]).to(DEV)) for lo in range(0, 8, 3)])
+    assert rel_err(got, torch.cat(preds[:3])) < 1e-4
+
+
+def test_checkpoint_roundtrip_on_device(tmp_path):
+    cfg, batch, sd, out, grad, sd3 = load_case('medium_shipped', DEV)
+    model = build_model(network.SoftPoolingGcnEncoder, cfg)
+    evalio.load_reference_state(model, {'state_dict': {'module.' + k: v for k, v in sd.items()}})   # reference-written, DataParallel-prefixed
+    model.to(DEV).train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
+    for _ in range(2):
+        _, loss = model(batch)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    f = os.path.join(str(tmp_path), 'run', 'weight.pth.tar')
+    evalio.save_checkpoint(evalio.checkpoint_state(model, opt, epoch=1, loss=float(loss), val_acc=0.5), True, f)
+    ck = evalio.load_checkpoint(os.path.join(str(tmp_path), 'run', 'model_best.pth.tar'))
+    assert ck['epoch'] == 2 and all(v.device.type == 'cpu' for v in ck['state_dict'].values())
+    # resume on the device: a fresh model + optimizer continue to EXACTLY the same third step as the uninterrupted run
+    resumed = build_model(network.SoftPoolingGcnEncoder, cfg)
+    evalio.load_reference_state(resumed, ck)
+    resumed.to(DEV).train()
+    opt2 = torch.optim.Adam(resumed.parameters(), lr=1e-3, weight_decay=1e-4)
+    opt2.load_state_dict(ck['optimizer'])
+    for m, o in ((model, opt), (resumed, opt2)):
+        _, loss = m(batch)
+        o.zero_grad()
+        loss.backward()
+        o.step()
+    for (k, a), (_, b) in zip(sorted(model.state_dict().items()), sorted(resumed.state_dict().items())):
+        assert torch.equal(a, b), k
+    # and the uninterrupted run is the reference's trajectory (fixture: state after 3 Adam steps)
+    for k, v in model.state_dict().items():
+        if v.dtype.is_floating_point:
+            assert rel_err(v, sd3[k]) < 2e-3, k
+
+
+def test_data_parallel_wrapper_on_one_rank_rccl_group():
+    """World size 1 over 'nccl' (= RCCL): process-group init on the GPU, parameter broadcast, and the flat-bucket
+    all-reduce queued by the autograd-engine callback execute on hardware; with one rank the averaged gradients must
+    equal the plain module's."""
+    import torch.distributed as dist
+    from cgc_net_amd.parallel import DataParallel
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(29600 + os.getpid() % 1000))
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        ds = SyntheticCellGraphs(5, 150, 16, base_seed=31)
+        items = [ds[i] for i in range(5)]
+        args = (300, 16, 20, 20, True, True, 20, 3, 0.1, [50])
+        kw = dict(concat=True, load_data_sparse=True, norm_adj=True, jk=True, drop_out=0.)
+        torch.manual_seed(2)
+        plain = network.SoftPoolingGcnEncoder(*args, **kw).to(DEV)
+        wrapped_net = network.SoftPoolingGcnEncoder(*args, **kw).to(DEV)
+        wrapped_net.load_state_dict(plain.state_dict())
+        dp = DataParallel(wrapped_net)
+        assert dp.world == 1 and dist.get_backend() == 'nccl'
+        dp.world = 2                       # force the multi-rank code path (hooks + all-reduce) on the single rank ...
+        dp._active = 2
+        for p in dp._params:
+            p.register_post_accumulate_grad_hook(dp._on_grad)
+        dp.train(), plain.train()
+        _, loss = dp(Batch.from_data_list(items).to(DEV))
+        torch.mean(loss).backward()
+        _, loss_p = plain(Batch.from_data_list(items).to(DEV))
+        loss_p.backward()
+        torch.cuda.synchronize()
+        gp = dict(plain.named_parameters())
+        for k, p in wrapped_net.named_parameters():          # ... where SUM over one rank / 2 = half the plain gradient
+            assert torch.allclose(p.grad * 2.0, gp[k].grad, rtol=1e-5, atol=1e-8), k
+        t = torch.ones(4, device=DEV)
+        dist.all_reduce(t)
+        assert float(t.sum()) == 4.0
+    finally:
+        dist.destroy_process_group()
