@@ -1,8 +1,11 @@
 #!/usr/bin/env python
 """Benchmark of the CGC-Net hot path on MI355X: cell-graphs/sec, forward + backward (+ Adam step), batch 32.
 
-Contract: ``python bench.py --gpus N --steps K --warmup W`` (N>1 is launched by torch.distributed.run, one rank per
-GPU over RCCL) prints ONE JSON line on rank 0.  A "step" is one pass of the hot path over one batch of synthetic
+Contract: ``python bench.py --gpus N --steps K --warmup W`` prints ONE JSON line on rank 0.  N>1 runs one rank per GPU over
+RCCL: either the driver starts the ranks (``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N``) or a plain
+``python bench.py --gpus N`` starts them itself.  ``--scaling weak`` (default): every GPU processes its own 32 graphs per step;
+``--scaling strong``: ONE global batch of 32 is split over the GPUs by cumulative node count, the reference's DataParallel
+scatter (train.py:276-287) -- 4 graphs per GPU at N=8.  A "step" is one pass of the hot path over one batch of synthetic
 cell graphs that is already resident in HBM: CSR build from ``edge_index`` (the reference densifies here), the full
 SoftPoolingGcnEncoder forward, cross-entropy, backward through every kernel, gradient all-reduce (N>1), Adam.
 
@@ -42,13 +45,20 @@ def parse():
     p.add_argument('--gpus', type=int, default=1)
     p.add_argument('--steps', type=int, default=20)
     p.add_argument('--warmup', type=int, default=5)
-    p.add_argument('--batch', type=int, default=32, help='graphs per GPU per step')
+    p.add_argument('--batch', type=int, default=32, help="graphs per GPU per step (weak scaling) / per global step (strong scaling)")
+    p.add_argument('--scaling', choices=['weak', 'strong'], default='weak',
+                   help="'weak' (default): every GPU gets its own --batch graphs per step; 'strong': ONE global batch of --batch graphs "
+                        "per step is split over the GPUs by cumulative node count, as the reference's DataParallel scatter does "
+                        "(train.py:276-287)")
     p.add_argument('--nodes', type=int, default=1800, help='mean nodes per graph')
     p.add_argument('--feat', type=int, default=16)
     p.add_argument('--maxn', type=int, default=11404, help="the reference's setting.max_num_nodes (fixes cluster counts)")
     p.add_argument('--flags', choices=['plain', 'shipped'], default='shipped',
                    help="'shipped' (default) = the reference's only shipped hyper-parameter set, parallel_train.sh:2-3: "
                         "--jk --norm_adj --drop 0.2; 'plain' = none of the three (SURVEY 8(d) parity configuration)")
+    p.add_argument('--backend', default='nccl', help="torch.distributed backend for N>1: 'nccl' (= RCCL over xGMI; default) or 'gloo' (tests)")
+    p.add_argument('--oversubscribe', action='store_true',
+                   help='tests only: ranks share the visible GPUs (rank %% device_count); needs --backend gloo (RCCL refuses duplicates)')
     p.add_argument('--pool', type=int, default=4, help='distinct resident batches cycled through')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--cpu-warmup', type=int, default=3, help='CPU baseline: untimed warm-up steps')
@@ -138,22 +148,42 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus and world > 1:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit('launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N')
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        # plain `python bench.py --gpus N`: start the ranks ourselves (one process per GPU over RCCL) and pass the line through
+        import subprocess
+        port = 29500 + os.getpid() % 2000
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+               '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
+    if args.oversubscribe:
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=dev)
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     import cgc_net_amd  # noqa: F401
     from cgc_net_amd import kernels, network
     from cgc_net_amd.data import Batch, SyntheticCellGraphs
     from cgc_net_amd.parallel import DataParallel
 
-    # ---- synthetic workload: `pool` distinct batches per rank, seeded by rank, resident in HBM
-    ds = SyntheticCellGraphs(args.pool * args.batch, args.nodes, args.feat, base_seed=100000 * rank)
-    cpu_batches = [Batch.from_data_list([ds[b * args.batch + i] for i in range(args.batch)]) for b in range(args.pool)]
+    # ---- synthetic workload: `pool` distinct batches, resident in HBM.  weak: per rank, seeded by rank; strong: the SAME
+    # global batches on every rank, each rank keeping its chunk of the cumulative-node-count split (data.partition_by_nodes)
+    from cgc_net_amd.data import partition_by_nodes
+    strong = args.scaling == 'strong' and world > 1
+    ds = SyntheticCellGraphs(args.pool * args.batch, args.nodes, args.feat, base_seed=0 if strong else 100000 * rank)
+    lists = [[ds[b * args.batch + i] for i in range(args.batch)] for b in range(args.pool)]
+    if strong:
+        chunks = [partition_by_nodes(l, world) for l in lists]
+        if any(len(c) != world for c in chunks):
+            raise SystemExit('cannot split %d graphs over %d ranks' % (args.batch, world))
+        lists = [c[rank] for c in chunks]
+    cpu_batches = [Batch.from_data_list(l) for l in lists]
     batches = [b.to(dev) for b in cpu_batches]
     nodes = sum(b.x.shape[0] for b in cpu_batches) / len(cpu_batches)
     edges = sum(b.edge_index.shape[1] for b in cpu_batches) / len(cpu_batches)
@@ -198,18 +228,18 @@ def main():
         raise SystemExit('non-finite loss')
 
     if rank == 0:
-        graphs = args.batch * world * args.steps
+        graphs = args.batch * (1 if strong else world) * args.steps
         c1 = int(args.maxn * 0.1)
         out = {
             'metric': 'cell-graphs/sec (fwd+bwd), batch=32, ~1800 nodes/16 feat',
             'value': round(graphs / elapsed, 2), 'unit': 'graphs/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 3), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'scaling': 'strong' if strong else 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'C3: full CGC-Net (3 conv blocks + 2 DiffPool) fwd+bwd+Adam, %d graphs/GPU/step, '
                                    '~%d nodes, ~%d edges/graph, %d feat, max_num_nodes=%d (C1=%d, C2=%d), flags=%s'
-                                   % (args.batch, round(nodes / args.batch), round(edges / args.batch), args.feat,
+                                   % (len(lists[0]), round(nodes / len(lists[0])), round(edges / len(lists[0])), args.feat,
                                       args.maxn, c1, int(c1 * 0.1), args.flags),
-                       'global_batch': args.batch * world, 'nodes_per_batch': round(nodes),
+                       'global_batch': args.batch * (1 if strong else world), 'nodes_per_batch': round(nodes),
                        'parallelism': 'dp%d' % world, 'includes': 'CSR build + fwd + loss + bwd + grad all-reduce + Adam'},
         }
         if timer is not None:

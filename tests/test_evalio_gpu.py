@@ -141,3 +141,21 @@ def test_data_parallel_wrapper_on_one_rank_rccl_group():
         assert float(t.sum()) == 4.0
     finally:
         dist.destroy_process_group()
+
+
+def test_bench_self_launch_strong_scaling_two_ranks():
+    """`python bench.py --gpus 2` (no torchrun) starts its own ranks; --scaling strong splits ONE global batch.  Two ranks
+    share the one GPU of the test box over gloo (RCCL refuses duplicate devices); the 8-GPU RCCL run is the driver's."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--oversubscribe', '--scaling', 'strong',
+           '--steps', '3', '--warmup', '1', '--batch', '8', '--nodes', '300', '--maxn', '600', '--no-cpu-baseline', '--pool', '2']
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith('{')][-1]
+    rec = json.loads(line)
+    assert rec['n_gpus'] == 2 and rec['scaling'] == 'strong' and rec['config']['global_batch'] == 8
+    assert rec['value'] > 0 and abs(rec['value'] - 8 * 3 / (rec['ms_per_step'] * 3e-3)) < 0.05 * rec['value']
