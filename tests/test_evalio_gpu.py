@@ -73,6 +73,8 @@ def test_checkpoint_roundtrip_on_device(tmp_path):
     model = build_model(network.SoftPoolingGcnEncoder, cfg)
     evalio.load_reference_state(model, {'state_dict': {'module.' + k: v for k, v in sd.items()}})   # reference-written, DataParallel-prefixed
     model.to(DEV).train()
+    _, loss = model(batch)                 # the fixture's protocol (tests/golden/make_golden.py): one plain forward/backward first,
+    loss.backward()                        # then three Adam steps -- the BatchNorm buffers see four training forwards
     opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
     for _ in range(2):
         _, loss = model(batch)
@@ -80,7 +82,7 @@ def test_checkpoint_roundtrip_on_device(tmp_path):
         loss.backward()
         opt.step()
     f = os.path.join(str(tmp_path), 'run', 'weight.pth.tar')
-    evalio.save_checkpoint(evalio.checkpoint_state(model, opt, epoch=1, loss=float(loss), val_acc=0.5), True, f)
+    evalio.save_checkpoint(evalio.checkpoint_state(model, opt, epoch=1, loss=float(loss.detach()), val_acc=0.5), True, f)
     ck = evalio.load_checkpoint(os.path.join(str(tmp_path), 'run', 'model_best.pth.tar'))
     assert ck['epoch'] == 2 and all(v.device.type == 'cpu' for v in ck['state_dict'].values())
     # resume on the device: a fresh model + optimizer continue to EXACTLY the same third step as the uninterrupted run
