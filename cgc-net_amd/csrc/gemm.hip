@@ -188,6 +188,89 @@ __device__ __forceinline__ void fetch_frag(const float* __restrict__ tile, int k
   }
 }
 
+// Epilogue shared by the kernels below.  The MFMAs are issued with the operands SWAPPED (B fragment first), i.e. every
+// 32x32 accumulator holds the TRANSPOSED sub-tile: lane (l31, lhi) owns output ROW l31 and its 16 registers the columns
+// (r&3) + 8*(r>>2) + 4*lhi -- four runs of four consecutive columns.  (a*b is commutative and the k order is unchanged, so
+// the values are bitwise those of the unswapped product.)  A wave first parks its 32 x (TN*32) strip in a wave-private LDS
+// region with 16-byte writes (row stride TN*32+4 words: conflict-free for the 8-lane groups of ds_write_b128), then reads it
+// back with lanes running ALONG the rows and stores 16 bytes per lane: every store instruction covers whole 128-byte lines
+// (4 rows x 256 B for TN = 2) instead of 64 four-byte pieces of two rows, and the accumulate mode (beta != 0) and the bias read
+// with the same pattern.  The former row-per-register layout needed 16 store instructions per accumulator and left the
+// output-bound short-K products at 1.6 TB/s.  LDS operations of one wave execute in order, so no barrier is needed between
+// the parking writes and the read-back; the caller guarantees that no wave still reads operand tiles from this LDS.
+template <int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, float* __restrict__ C, int M, int N, int m_base, int n_base,
+                                              floatx16 (&acc)[TM][TN], float* __restrict__ st, int lane) {
+  constexpr int COLS = TN * 32, SLD = COLS + 4, LPR = COLS / 4, RPI = 64 / LPR;   // lanes per row, rows per store instruction
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const float alpha = a.alpha, beta = a.beta;
+  const int cu = lane % LPR, rsub = lane / LPR;
+  const int gcol = n_base + cu * 4;
+  const bool vec = (a.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15u) == 0) && (gcol + 3 < N);
+  float4 bia = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (a.bias != nullptr) {
+    if (gcol < N) bia.x = a.bias[gcol];
+    if (gcol + 1 < N) bia.y = a.bias[gcol + 1];
+    if (gcol + 2 < N) bia.z = a.bias[gcol + 2];
+    if (gcol + 3 < N) bia.w = a.bias[gcol + 3];
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(&st[l31 * SLD + j * 32 + 8 * g + 4 * lhi]) =
+            make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+    __builtin_amdgcn_wave_barrier();
+    float4 v[32 / RPI];
+#pragma unroll
+    for (int it = 0; it < 32 / RPI; ++it) v[it] = *reinterpret_cast<const float4*>(&st[(it * RPI + rsub) * SLD + cu * 4]);
+    __builtin_amdgcn_wave_barrier();
+    const int row0 = m_base + i * 32 + rsub;
+    if (vec) {
+      if (beta != 0.f) {                     // accumulate mode: all reads of the strip in flight before the first write
+        float4 cold[32 / RPI];
+#pragma unroll
+        for (int it = 0; it < 32 / RPI; ++it) {
+          const int row = row0 + it * RPI;
+          cold[it] = row < M ? *reinterpret_cast<const float4*>(&C[(size_t)row * a.ldc + gcol]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int it = 0; it < 32 / RPI; ++it) {
+          const int row = row0 + it * RPI;
+          if (row < M)
+            *reinterpret_cast<float4*>(&C[(size_t)row * a.ldc + gcol]) =
+                make_float4(fmaf(beta, cold[it].x, alpha * v[it].x + bia.x), fmaf(beta, cold[it].y, alpha * v[it].y + bia.y),
+                            fmaf(beta, cold[it].z, alpha * v[it].z + bia.z), fmaf(beta, cold[it].w, alpha * v[it].w + bia.w));
+        }
+      } else {
+#pragma unroll
+        for (int it = 0; it < 32 / RPI; ++it) {
+          const int row = row0 + it * RPI;
+          if (row < M)
+            *reinterpret_cast<float4*>(&C[(size_t)row * a.ldc + gcol]) =
+                make_float4(alpha * v[it].x + bia.x, alpha * v[it].y + bia.y, alpha * v[it].z + bia.z, alpha * v[it].w + bia.w);
+        }
+      }
+    } else {                                  // unaligned C / ragged right edge: element-wise with the same arithmetic
+#pragma unroll
+      for (int it = 0; it < 32 / RPI; ++it) {
+        const int row = row0 + it * RPI;
+        if (row >= M) continue;
+        const float vv[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
+        const float bb[4] = {bia.x, bia.y, bia.z, bia.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (gcol + e >= N) break;
+          float* p = &C[(size_t)row * a.ldc + gcol + e];
+          *p = beta != 0.f ? fmaf(beta, *p, alpha * vv[e] + bb[e]) : alpha * vv[e] + bb[e];
+        }
+      }
+    }
+  }
+}
+
 template <int WGM, int WGN, int TM, int TN, bool TA, bool TB>
 __global__ __launch_bounds__(256, 2) void k_gemm_f32(const GemmArgs a) {   // 2 waves per SIMD = 2 workgroups per CU (the LDS budget)
   constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
@@ -335,7 +418,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const GemmArgs a) {   // 2 
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kb & 1][i][t], bv[kb & 1][j][t], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[kb & 1][j][t], av[kb & 1][i][t], acc[i][j], 0, 0, 0);   // C^T tile: see gemm_epilogue
       if (has_next) {
         if (kb < LoaderA::PER_T) ls_a.store_part(kb, an);
         if (kb < LoaderB::PER_T) ls_b.store_part(kb, bn);
@@ -367,35 +450,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const GemmArgs a) {   // 2 
     if (kt + 1 < nk) phase(F_(), kt + 1, B1(), la1, lb1, la0, lb0);
   }
 
-  // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  const float alpha = a.alpha, beta = a.beta;
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int col = n0 + (wn * TN + j) * 32 + l31;
-      if (col >= N) continue;
-      const float bia = a.bias != nullptr ? a.bias[col] : 0.f;
-      if (beta != 0.f) {                     // accumulate mode: all 16 reads of the sub-tile in flight before the first write
-        float cold[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-          cold[r] = row < M ? C[(size_t)row * a.ldc + col] : 0.f;
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-          if (row < M) C[(size_t)row * a.ldc + col] = fmaf(beta, cold[r], alpha * acc[i][j][r] + bia);
-        }
-      } else {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-          if (row < M) C[(size_t)row * a.ldc + col] = alpha * acc[i][j][r] + bia;
-        }
-      }
-    }
+  // epilogue (the last phase ended with a barrier: nobody reads operand tiles any more, the LDS is free for the parking strips)
+  static_assert(4 * 32 * (TN * 32 + 4) <= 2 * A_SZ + 2 * B_SZ, "epilogue parking region exceeds the operand LDS");
+  gemm_epilogue<TM, TN>(a, C, M, N, m0 + wm * TM * 32, n0 + wn * TN * 32, acc, lds + wave * 32 * (TN * 32 + 4), lane);
 }
 
 template <int WGM, int WGN, int TM, int TN, bool TA, bool TB>
@@ -404,7 +461,8 @@ __global__ __launch_bounds__(256, 3) void k_gemm_f32_shortk(const GemmArgs a) {
   constexpr int LDA_S = TA ? BM + 4 : KC_LD;   // TA: A stored [K,M] -> k-major tile; else row-major [m][k]
   constexpr int LDB_S = TB ? KC_LD : BN + 4;   // TB: B stored [N,K] -> row-major [n][k]; else k-major
   constexpr int A_SZ = TA ? BK * LDA_S : BM * KC_LD, B_SZ = TB ? BN * KC_LD : BK * LDB_S;   // multiples of 4 words
-  __shared__ __attribute__((aligned(16))) float lds[A_SZ + B_SZ];   // ONE stage: 36.9 KB; 3 workgroups per CU (register-limited)
+  constexpr int PARK = 4 * 32 * (TN * 32 + 4);                             // epilogue parking strips (gemm_epilogue)
+  __shared__ __attribute__((aligned(16))) float lds[A_SZ + B_SZ > PARK ? A_SZ + B_SZ : PARK];   // ONE stage: <= 36.9 KB; 3 workgroups per CU (register-limited)
   float* const As0 = lds;                 // As[buf] = As0 + buf*A_SZ
   float* const Bs0 = lds + A_SZ;
 
@@ -492,39 +550,12 @@ __global__ __launch_bounds__(256, 3) void k_gemm_f32_shortk(const GemmArgs a) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][t], bv[j][t], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[j][t], av[i][t], acc[i][j], 0, 0, 0);
     }
   }
 
-  // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  const float alpha = a.alpha, beta = a.beta;
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int col = n0 + (wn * TN + j) * 32 + l31;
-      if (col >= N) continue;
-      const float bia = a.bias != nullptr ? a.bias[col] : 0.f;
-      if (beta != 0.f) {                     // accumulate mode: all 16 reads of the sub-tile in flight before the first write
-        float cold[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-          cold[r] = row < M ? C[(size_t)row * a.ldc + col] : 0.f;
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-          if (row < M) C[(size_t)row * a.ldc + col] = fmaf(beta, cold[r], alpha * acc[i][j][r] + bia);
-        }
-      } else {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-          if (row < M) C[(size_t)row * a.ldc + col] = alpha * acc[i][j][r] + bia;
-        }
-      }
-    }
+  __syncthreads();                          // everybody finished reading the last operand tile: the LDS becomes the parking area
+  gemm_epilogue<TM, TN>(a, C, M, N, m0 + wm * TM * 32, n0 + wn * TN * 32, acc, lds + wave * 32 * (TN * 32 + 4), lane);
 }
 
 template <int WGM, int WGN, int TM, int TN>
