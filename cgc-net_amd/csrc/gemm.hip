@@ -35,6 +35,7 @@ struct GemmArgs {
   float alpha, beta;
   int ragged;
   int tiles_n;
+  int map_mode;   // bit 0: compact tile list for ragged M, bit 1: K-balanced dealing for ragged K (gemm_map_tile)
   // optional extra K segments: C += alpha * A_x[s] * B_x[s] (same op() orientation, M, N as the main pair), i.e. the
   // product of the column-concatenated [A | A_x0 | A_x1] with the row-concatenated [B ; B_x0 ; B_x1] without ever
   // materialising the concatenation (Linear over cat[x1,x2,x3]; dS = P dA'^T + X dX'^T)
@@ -188,6 +189,64 @@ __device__ __forceinline__ void fetch_frag(const float* __restrict__ tile, int k
   }
 }
 
+// Which (batch, tile) a workgroup computes.  Speed only -- every tile is computed exactly once whatever the hardware's dispatch
+// order is.  Workgroups are dealt round-robin to the 8 XCDs, each with a private 4 MiB L2: linear id lin -> XCD lin & 7, slot
+// lin >> 3.  Every XCD gets a CONTIGUOUS run of (batch, tile_m, tile_n) ids, tile_n fastest: the ~64 workgroups resident on an
+// XCD then form a (few tile_m) x (all tile_n) super-tile that streams each A panel and each B panel through that L2 once
+// (measured before this remap: 31-50 % L2 hit rate and ~9x the algorithmic bytes fetched from the fabric).
+//   * uniform batches: the runs are cut from the launched grid.
+//   * ragged M (per-graph row counts): the grid is sized for the LARGEST graph, so cutting it into equal runs hands an XCD
+//     whose graphs are small mostly empty tiles (C3: per-XCD work spread +-8 %).  The runs are cut from the COMPACT list of
+//     real tiles instead: each wave derives the per-graph tile counts from gptr with a wave scan (batch <= 64).
+//   * ragged K (per-graph reduction length): every graph has the same tiles but a different duration.  Graphs are ranked by
+//     K and dealt to the XCDs in serpentine order (longest first), so that the sums of K per XCD agree within ~1 %
+//     (batch a multiple of 8, <= 64; otherwise the plain cut).
+template <int BM>
+__device__ __forceinline__ bool gemm_map_tile(const GemmArgs& a, int& b, int& tile_id) {
+  const unsigned per_batch = gridDim.x, nb = gridDim.z, total = per_batch * nb;
+  const unsigned lin = blockIdx.z * per_batch + blockIdx.x;
+  const unsigned xcd = lin & 7u, slot = lin >> 3;
+  const int lane = threadIdx.x & 63;
+  if (a.ragged == 1 && nb <= 64 && (a.map_mode & 1)) {
+    const int ext = lane < (int)nb ? a.gptr[lane + 1] - a.gptr[lane] : 0;
+    const int t = (ext + BM - 1) / BM;                     // m-tile rows of graph `lane`
+    int incl = t;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int up = __shfl_up(incl, o);
+      if (lane >= o) incl += up;
+    }
+    const unsigned T = (unsigned)__shfl(incl, 63) * a.tiles_n;      // real tiles of the launch
+    const unsigned q8 = T >> 3, r8 = T & 7u;
+    if (slot >= q8 + (xcd < r8 ? 1u : 0u)) return false;
+    const unsigned cid = xcd * q8 + (xcd < r8 ? xcd : r8) + slot;
+    const int row = cid / a.tiles_n;
+    b = __popcll(__ballot(incl <= row));                    // graphs that end at or before this row
+    const int first = __shfl(incl - t, b);
+    tile_id = (row - first) * a.tiles_n + (cid - row * a.tiles_n);
+    return true;
+  }
+  if (a.ragged == 2 && nb <= 64 && (nb & 7u) == 0 && (a.map_mode & 2)) {
+    const int ext = lane < (int)nb ? a.gptr[lane + 1] - a.gptr[lane] : -1;
+    int rank = 0;
+    for (int j = 0; j < (int)nb; ++j) {
+      const int ej = __shfl(ext, j);
+      rank += (ej > ext || (ej == ext && j < lane)) ? 1 : 0;
+    }
+    const unsigned p = slot / per_batch;
+    if (p >= (nb >> 3)) return false;
+    const unsigned q = p * 8 + ((p & 1u) ? 7u - xcd : xcd);
+    b = __ffsll((unsigned long long)__ballot(lane < (int)nb && rank == (int)q)) - 1;
+    tile_id = slot - p * per_batch;
+    return true;
+  }
+  const unsigned q8 = total >> 3, r8 = total & 7u;
+  const unsigned vb = xcd * q8 + (xcd < r8 ? xcd : r8) + slot;
+  b = vb / per_batch;
+  tile_id = vb - b * per_batch;
+  return true;
+}
+
+
 // Epilogue shared by the kernels below.  The MFMAs are issued with the operands SWAPPED (B fragment first), i.e. every
 // 32x32 accumulator holds the TRANSPOSED sub-tile: lane (l31, lhi) owns output ROW l31 and its 16 registers the columns
 // (r&3) + 8*(r>>2) + 4*lhi -- four runs of four consecutive columns.  (a*b is commutative and the k order is unchanged, so
@@ -281,16 +340,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const GemmArgs a) {   // 2 
   float* const As0 = lds;                 // As[buf] = As0 + buf*A_SZ
   float* const Bs0 = lds + 2 * A_SZ;      // Bs[buf] = Bs0 + buf*B_SZ
 
-  // XCD-aware workgroup order (speed only): workgroups are dealt round-robin to the 8 XCDs, each with a private 4 MiB L2.
-  // Give every XCD a CONTIGUOUS run of (batch, tile_m, tile_n) ids, tile_n fastest: the ~64 workgroups resident on an XCD
-  // then form a (few tile_m) x (all tile_n) super-tile that streams each A panel and each B panel through that L2 once
-  // (measured before this remap: 31-50 % L2 hit rate and ~9x the algorithmic bytes fetched from the fabric).
-  const unsigned per_batch = gridDim.x, total = gridDim.x * gridDim.z;
-  const unsigned lin = blockIdx.z * per_batch + blockIdx.x;
-  const unsigned q8 = total >> 3, r8 = total & 7u, xcd = lin & 7u;
-  const unsigned vb = xcd * q8 + (xcd < r8 ? xcd : r8) + (lin >> 3);
-  const int b = vb / per_batch;
-  const int tile_id = vb - b * per_batch;
+  int b, tile_id;
+  if (!gemm_map_tile<BM>(a, b, tile_id)) return;
   int M = a.M, K = a.K;
   const float* A = a.A + (size_t)b * a.strideA;
   const float* B = a.B + (size_t)b * a.strideB;
@@ -466,16 +517,8 @@ __global__ __launch_bounds__(256, 3) void k_gemm_f32_shortk(const GemmArgs a) {
   float* const As0 = lds;                 // As[buf] = As0 + buf*A_SZ
   float* const Bs0 = lds + A_SZ;
 
-  // XCD-aware workgroup order (speed only): workgroups are dealt round-robin to the 8 XCDs, each with a private 4 MiB L2.
-  // Give every XCD a CONTIGUOUS run of (batch, tile_m, tile_n) ids, tile_n fastest: the ~64 workgroups resident on an XCD
-  // then form a (few tile_m) x (all tile_n) super-tile that streams each A panel and each B panel through that L2 once
-  // (measured before this remap: 31-50 % L2 hit rate and ~9x the algorithmic bytes fetched from the fabric).
-  const unsigned per_batch = gridDim.x, total = gridDim.x * gridDim.z;
-  const unsigned lin = blockIdx.z * per_batch + blockIdx.x;
-  const unsigned q8 = total >> 3, r8 = total & 7u, xcd = lin & 7u;
-  const unsigned vb = xcd * q8 + (xcd < r8 ? xcd : r8) + (lin >> 3);
-  const int b = vb / per_batch;
-  const int tile_id = vb - b * per_batch;
+  int b, tile_id;
+  if (!gemm_map_tile<BM>(a, b, tile_id)) return;
   int M = a.M, K = a.K;
   const float* A = a.A + (size_t)b * a.strideA;
   const float* B = a.B + (size_t)b * a.strideB;
@@ -563,6 +606,8 @@ static int launch_cfg(const GemmArgs& a0, int transA, int transB, int batch, int
   constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
   GemmArgs a = a0;
   a.tiles_n = ceil_div(a.N, BN);
+  static const int map_mode = getenv("CGC_GEMM_MAP") ? atoi(getenv("CGC_GEMM_MAP")) : 3;
+  a.map_mode = map_mode;
   const long long tiles = (long long)ceil_div(m_extent, BM) * a.tiles_n;
   if (tiles <= 0 || tiles > 0x7fffffffLL || batch > 65535) return CGC_EINVAL;
   dim3 grid((unsigned)tiles, 1, (unsigned)batch), block(256);

@@ -9,8 +9,13 @@ import sys
 
 
 def main():
-    dirs = [a for a in sys.argv[1:] if not a.startswith('--')]
-    match = sys.argv[sys.argv.index('--match') + 1] if '--match' in sys.argv else ''
+    args = sys.argv[1:]
+    match = ''
+    if '--match' in args:
+        i = args.index('--match')
+        match = args[i + 1]
+        del args[i:i + 2]
+    dirs = [a for a in args if not a.startswith('--')]
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for d in dirs:
         for r in csv.DictReader(open(d.rstrip('/') + '/p_counter_collection.csv')):

@@ -3,8 +3,8 @@
 * every contraction shape of the C3 step that ``gemm_dispatch`` (csrc/gemm.hip) sends to the dominant 128x128 kernel
   ``k_gemm_f32<2,2,2,2,*>`` -- NN / NT / TN, flat, ragged-M, ragged-K, padded row strides (ld = 1152), extra K segments,
   accumulate mode, split-K -- against an fp64 product (the kernel the bench line's ``roofline`` is quoted on);
-* the FULL model, forward + backward, at C3 shapes (B = 6 graphs of ~1800 nodes, max_num_nodes = 11404 -> C1 = 1140:
-  the per-graph contractions launch 9 x 6 x 9 = 486 >= 448 tiles, so all six dominant contractions and the W = 1140 wide
+* the FULL model, forward + backward, at C3 shapes (B = 8 graphs of ~1800 nodes, max_num_nodes = 11404 -> C1 = 1140:
+  the per-graph contractions launch 9 x 8 x 9 = 648 >= 448 tiles, so all six dominant contractions and the W = 1140 wide
   SpMM are on the path) and at C5 shapes (B = 3 graphs of ~8000 nodes kept by the 'fuse' sampler out of 16000 nuclei, 64 features, max_num_nodes = 16000 ->
   C1 = 1600) against the dense CPU oracle (oracle/dense_ref.py; model/network.py:245-291, parallel_train.sh:2-3).
 
@@ -64,7 +64,8 @@ def spy():
     K.timer = None
 
 
-COUNTS = [1790, 2150, 1475, 1803, 1999, 1644]            # B = 6 ragged graphs (C3 node counts): 9 x 6 x 9 = 486 tiles >= 448
+COUNTS = [1790, 2150, 1475, 1803, 1999, 1644, 2161, 1440]     # B = 8 ragged graphs (C3 node counts): 9 x 8 x 9 = 648 tiles >= 448;
+#                                                              a multiple of 8 also takes the K-balanced XCD dealing of gemm_map_tile
 GPTR = np.cumsum([0] + COUNTS)
 NTOT = int(GPTR[-1])
 NB = len(COUNTS)
@@ -188,14 +189,24 @@ def _compare_model(cpu_batch, maxn, feat, flags, tol_grad=5e-4):
     for i, (s, rs) in enumerate(zip(model.assign_matrix, ref.assign_matrix)):
         assert rel_err(s, rs) < 1e-4, ('assign', i, rel_err(s, rs))
     g32, g64 = dict(ref.named_parameters()), dict(ref64.named_parameters())
+
+    def strict(a, b):
+        """max|a-b| / max|b| with NO absolute slack (tests/util.rel_err adds 1e-3 to the denominator, which is most of it
+        for gradients of magnitude 1e-4..1e-3).  The rounding error of a long mixed-sign sum is absolute -- it does not
+        shrink with the element -- so the max-norm is the meaningful yardstick for gradients; outputs are also checked
+        element by element above."""
+        a, b = a.detach().double().cpu(), b.detach().double().cpu()
+        return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
     report = []
     for k, p in model.named_parameters():
-        spread = rel_err(g32[k].grad, g64[k].grad)              # the reference's own fp32 rounding on this parameter
-        e = rel_err(p.grad, g64[k].grad)
+        if float(g64[k].grad.abs().max()) < 1e-12:              # mathematically zero (softmax-invariant attention bias): absolute
+            assert float(p.grad.abs().max()) < 1e-7, k
+            continue
+        spread = strict(g32[k].grad, g64[k].grad)               # the reference's own fp32 rounding on this parameter
+        e = strict(p.grad, g64[k].grad)
         tol = max(tol_grad, 2.0 * spread)
         report.append((e, spread, k))
         assert e < tol, (k, e, spread)
-        assert elementwise_excess(p.grad, g64[k].grad, tol, tol * float(g64[k].grad.abs().max()) + 1e-7) <= 1.0, (k, e, spread)
     rbuf = dict(ref.named_buffers())
     for k, a in model.named_buffers():
         if a.dtype.is_floating_point:
@@ -207,8 +218,8 @@ def _compare_model(cpu_batch, maxn, feat, flags, tol_grad=5e-4):
 
 @pytest.mark.parametrize('flags', [dict(norm_adj=True, jk=True), dict()], ids=['shipped', 'plain'])
 def test_full_model_c3_shapes_vs_oracle(flags):
-    ds = SyntheticCellGraphs(6, 1800, 16, base_seed=11)
-    cpu_batch = Batch.from_data_list([ds[i] for i in range(6)])
+    ds = SyntheticCellGraphs(8, 1800, 16, base_seed=11)
+    cpu_batch = Batch.from_data_list([ds[i] for i in range(8)])
     records, worst = _compare_model(cpu_batch, 11404, 16, flags)
     # the benchmarked kernels were on the path: the six 128x128 contractions and both wide aggregations
     assert records.get('gemm_128x128', 0) >= 6, records

@@ -228,6 +228,28 @@ def test_gemm_ragged(C, D):
     close(got, want, 2e-5, 'ragged-M NT')
 
 
+@pytest.mark.parametrize('nb', [8, 16, 24])
+def test_gemm_ragged_balanced_dealing(nb):
+    """Batches whose size is a multiple of 8 take the XCD-balanced tile dealing (gemm_map_tile: compact tile list for ragged
+    M, serpentine by reduction length for ragged K): every tile must still be computed exactly once."""
+    rng = np.random.RandomState(nb)
+    counts = [int(c) for c in rng.randint(0, 300, size=nb)]
+    counts[3] = 0
+    n = sum(counts)
+    gptr = torch.tensor(np.cumsum([0] + counts), dtype=torch.int32)
+    C, D, nmax = 150, 140, max(counts)
+    S, X = rnd(n, C, seed=1), rnd(n, D, seed=2)
+    want, got = torch.zeros(nb, C, D), torch.full((nb, C, D), 7.0, device=DEV)
+    REF.gemm(S, X, want, C, D, 0, True, False, C, D, D, 1.0, 0.0, None, nb, 0, 0, C * D, gptr, 2, nmax)
+    hip().gemm(g(S), g(X), got, C, D, 0, True, False, C, D, D, 1.0, 0.0, None, nb, 0, 0, C * D, g(gptr), 2, nmax)
+    close(got, want, 2e-5, 'ragged-K')
+    G = rnd(nb, C, D, seed=3)
+    want, got = torch.zeros(n, D), torch.full((n, D), 7.0, device=DEV)
+    REF.gemm(S, G, want, 0, D, C, False, False, C, D, D, 1.0, 0.0, None, nb, 0, C * D, 0, gptr, 1, nmax)
+    hip().gemm(g(S), g(G), got, 0, D, C, False, False, C, D, D, 1.0, 0.0, None, nb, 0, C * D, 0, g(gptr), 1, nmax)
+    close(got, want, 2e-5, 'ragged-M NN')
+
+
 def test_gemm_extra_k_segments():
     """concatenated-K products without the concatenation: flat NT (Linear over cat) and ragged-M NT (dS += X dX'^T)."""
     n, fo = 333, 150
