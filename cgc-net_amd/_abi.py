@@ -43,6 +43,8 @@ PROTOTYPES = {
     'cgc_dense_rownorm_bwd': [P, P, P, P, I, I, P, P],
     'cgc_dense_renorm_fwd': [P, I, I, F, P, P],
     'cgc_dense_renorm_bwd': [P, P, I, I, F, P, P],
+    'cgc_adj_prep_fwd': [P, I, I, F, P, P, P, P, P],
+    'cgc_adj_prep_bwd': [P, P, P, P, P, P, I, I, F, P, P],
 }
 
 

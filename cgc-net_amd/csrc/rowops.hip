@@ -861,6 +861,114 @@ __global__ __launch_bounds__(256) void k_dense_renorm_bwd(const float* __restric
   }
 }
 
+// ---- fused adjacency preparation of a dense level (levels 2-3): optional _re_norm_adj (model/network.py:183-191) followed by
+// the clamp(min=1) row normalisation of DenseSAGEConv, in ONE pass over the [B,C,C] adjacency each way.  Unfused the forward
+// was two read+write passes and the backward three (row-norm backward, the autograd sum of the two gradient streams into the
+// re-normalised adjacency, re-norm backward): 9 x 166 MB at C3 -> 5 x 166 MB here.  The later passes over a row re-read it
+// from L2 (a row is 4.5 KB).  p < 0: no re-normalisation (At is not written; pass At = NULL).
+template <int VEC>
+__global__ __launch_bounds__(256) void k_adj_prep_fwd(const float* __restrict__ A, int R, int C, int lpr, float p, float* __restrict__ At,
+                                                      float* __restrict__ An, float* __restrict__ invd, float* __restrict__ ge1) {
+  const RowGroup rg(lpr);
+  const bool renorm = p >= 0.f;
+  const float omp = 1.f - p;
+  for (int base = rg.gwave * rg.rpw; base < R; base += rg.nwaves * rg.rpw) {
+    const int row = base + rg.sub;
+    const bool valid = row < R;
+    const int diag = (valid && renorm) ? row % C : -1;
+    float s = 0.f;
+    if (valid)
+      for (int c = rg.sl * VEC; c < C; c += lpr * VEC) {
+        Vec<VEC> t;
+        t.load(A + (size_t)row * C + c);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) s += (c + v == diag) ? 0.f : t.v[v];
+      }
+    s = group_sum(s, lpr);
+    float st = s;                                        // row sum of the (re-normalised) adjacency, from the STORED values
+    const float den = s + RENORM_EPS;
+    if (renorm) {
+      st = 0.f;
+      if (valid)
+        for (int c = rg.sl * VEC; c < C; c += lpr * VEC) {
+          Vec<VEC> t;
+          t.load(A + (size_t)row * C + c);
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) { t.v[v] = (c + v == diag) ? p : (t.v[v] / den) * omp; st += t.v[v]; }
+          t.store(At + (size_t)row * C + c);
+        }
+      st = group_sum(st, lpr);
+    }
+    if (!valid) continue;
+    const float inv = 1.f / fmaxf(st, 1.f);
+    for (int c = rg.sl * VEC; c < C; c += lpr * VEC) {
+      Vec<VEC> t;
+      t.load(A + (size_t)row * C + c);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        const float at = renorm ? ((c + v == diag) ? p : (t.v[v] / den) * omp) : t.v[v];
+        t.v[v] = at * inv;
+      }
+      t.store(An + (size_t)row * C + c);
+    }
+    if (rg.sl == 0) {
+      invd[row] = inv;
+      ge1[row] = st >= 1.f ? 1.f : 0.f;
+    }
+  }
+}
+
+// dAt = invd*(gAn - ge1*<gAn,An>) + gAt  (row-norm backward + the gradient that reaches the re-normalised adjacency directly,
+// e.g. from A~ S of _diff_pool; gAt may be NULL), then, if p >= 0, the re-norm backward dA = (1-p) q (dAt - q <A,dAt>_offdiag)
+// off the diagonal and 0 on it, q = 1/(rowsum_offdiag(A)+1e-15).  <A,dAt> is assembled from four row reductions of the inputs.
+template <int VEC>
+__global__ __launch_bounds__(256) void k_adj_prep_bwd(const float* __restrict__ A, const float* __restrict__ An, const float* __restrict__ invd,
+                                                      const float* __restrict__ ge1, const float* __restrict__ gAn,
+                                                      const float* __restrict__ gAt, int R, int C, int lpr, float p, float* __restrict__ dA) {
+  const RowGroup rg(lpr);
+  const bool renorm = p >= 0.f;
+  const float omp = 1.f - p;
+  for (int base = rg.gwave * rg.rpw; base < R; base += rg.nwaves * rg.rpw) {
+    const int row = base + rg.sub;
+    const bool valid = row < R;
+    const int diag = (valid && renorm) ? row % C : -1;
+    float t1 = 0.f, s = 0.f, u = 0.f, w = 0.f;
+    if (valid)
+      for (int c = rg.sl * VEC; c < C; c += lpr * VEC) {
+        Vec<VEC> g, an, a, h;
+        g.load(gAn + (size_t)row * C + c);
+        an.load(An + (size_t)row * C + c);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) t1 += g.v[v] * an.v[v];
+        if (renorm) {
+          a.load(A + (size_t)row * C + c);
+          if (gAt != nullptr) h.load(gAt + (size_t)row * C + c);
+#pragma unroll
+          for (int v = 0; v < VEC; ++v)
+            if (c + v != diag) { s += a.v[v]; u += a.v[v] * g.v[v]; if (gAt != nullptr) w += a.v[v] * h.v[v]; }
+        }
+      }
+    t1 = group_sum(t1, lpr);
+    if (renorm) { s = group_sum(s, lpr); u = group_sum(u, lpr); w = group_sum(w, lpr); }
+    if (!valid) continue;
+    const float inv = invd[row], sub = ge1[row] * t1;
+    const float q = 1.f / (s + RENORM_EPS);
+    const float t = inv * (u - sub * s) + w;             // <A, dAt> over the off-diagonal entries
+    for (int c = rg.sl * VEC; c < C; c += lpr * VEC) {
+      Vec<VEC> g, h;
+      g.load(gAn + (size_t)row * C + c);
+      if (gAt != nullptr) h.load(gAt + (size_t)row * C + c);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        float d = inv * (g.v[v] - sub);
+        if (gAt != nullptr) d += h.v[v];
+        g.v[v] = renorm ? ((c + v == diag) ? 0.f : omp * q * (d - q * t)) : d;
+      }
+      g.store(dA + (size_t)row * C + c);
+    }
+  }
+}
+
 #define LAUNCH_ROW(KERNEL, vec, lpr, R, stream, ...)                                                          \
   do {                                                                                                        \
     dim3 g__(row_blocks(R, lpr)), b__(CGC_BLOCK);                                                             \
@@ -898,6 +1006,25 @@ extern "C" int cgc_dense_renorm_bwd(const float* A, const float* dOut, int R, in
   const bool vec = (C % 4 == 0) && aligned16(A) && aligned16(dOut) && aligned16(dA);
   const int lpr = pick_lpr(vec ? C / 4 : C);
   LAUNCH_ROW(k_dense_renorm_bwd, vec, lpr, R, as_stream(stream), A, dOut, R, C, lpr, p, dA);
+  CGC_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}
+
+extern "C" int cgc_adj_prep_fwd(const float* A, int R, int C, float p, float* At, float* An, float* invd, float* ge1, cgc_stream_t stream) {
+  if (R <= 0 || C <= 0) return 0;
+  if (p >= 0.f && At == nullptr) return CGC_EINVAL;
+  const bool vec = (C % 4 == 0) && aligned16(A) && aligned16(An) && (At == nullptr || aligned16(At));
+  const int lpr = pick_lpr(vec ? C / 4 : C);
+  LAUNCH_ROW(k_adj_prep_fwd, vec, lpr, R, as_stream(stream), A, R, C, lpr, p, At, An, invd, ge1);
+  CGC_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}
+extern "C" int cgc_adj_prep_bwd(const float* A, const float* An, const float* invd, const float* ge1, const float* gAn, const float* gAt,
+                                int R, int C, float p, float* dA, cgc_stream_t stream) {
+  if (R <= 0 || C <= 0) return 0;
+  const bool vec = (C % 4 == 0) && aligned16(A) && aligned16(An) && aligned16(gAn) && aligned16(dA) && (gAt == nullptr || aligned16(gAt));
+  const int lpr = pick_lpr(vec ? C / 4 : C);
+  LAUNCH_ROW(k_adj_prep_bwd, vec, lpr, R, as_stream(stream), A, An, invd, ge1, gAn, gAt, R, C, lpr, p, dA);
   CGC_RETURN_IF_LAUNCH_FAILED();
   return 0;
 }

@@ -197,6 +197,14 @@ class KernelSpec(object):
     def dense_renorm_bwd(self, A, dOut, R, C, p, dA_out):
         raise NotImplementedError
 
+    def adj_prep_fwd(self, A, R, C, p, At_out, An_out, invd_out, ge1_out):
+        """dense_renorm_fwd (skipped when p is None: At_out None) followed by dense_rownorm_fwd of its result, one pass."""
+        raise NotImplementedError
+
+    def adj_prep_bwd(self, A, An, invd, ge1, gAn, gAt, R, C, p, dA_out):
+        """dAt = dense_rownorm_bwd(gAn) + gAt (gAt may be None); dA = dense_renorm_bwd(A, dAt) (dA = dAt when p is None)."""
+        raise NotImplementedError
+
 
 # ----------------------------------------------------------------------------------------------
 _LIB_NAME = 'libcgc_hip.so'
@@ -576,3 +584,13 @@ class HipKernels(KernelSpec):
         self._dev(A, dOut, dA_out)
         self._chk(self.lib.cgc_dense_renorm_bwd(_ptr(A), _ptr(dOut), R, C, ctypes.c_float(p), _ptr(dA_out),
                                                 self._stream()), 'cgc_dense_renorm_bwd')
+
+    def adj_prep_fwd(self, A, R, C, p, At_out, An_out, invd_out, ge1_out):
+        self._dev(A, At_out, An_out, invd_out, ge1_out)
+        self._chk(self.lib.cgc_adj_prep_fwd(_ptr(A), R, C, ctypes.c_float(-1.0 if p is None else p), _ptr(At_out), _ptr(An_out),
+                                            _ptr(invd_out), _ptr(ge1_out), self._stream()), 'cgc_adj_prep_fwd')
+
+    def adj_prep_bwd(self, A, An, invd, ge1, gAn, gAt, R, C, p, dA_out):
+        self._dev(A, An, invd, ge1, gAn, gAt, dA_out)
+        self._chk(self.lib.cgc_adj_prep_bwd(_ptr(A), _ptr(An), _ptr(invd), _ptr(ge1), _ptr(gAn), _ptr(gAt), R, C,
+                                            ctypes.c_float(-1.0 if p is None else p), _ptr(dA_out), self._stream()), 'cgc_adj_prep_bwd')

@@ -389,10 +389,13 @@ class SoftPoolingGcnEncoder(nn.Module):
 
     def _dense_level(self, level, x, adj):
         B, C, _ = x.shape
-        if self.norm_adj:
-            adj = ops.renorm_dense(adj, RENORM_P)
         emb_blk = getattr(self, 'GCN_embed_%d' % level)
-        a = ops.rownorm_clamp(adj) if emb_blk.mean_aggregation else adj
+        if emb_blk.mean_aggregation:       # re-normalisation + clamped row normalisation: one fused pass each way
+            adj, a = ops.adj_prep(adj, RENORM_P if self.norm_adj else None)
+        else:
+            if self.norm_adj:
+                adj = ops.renorm_dense(adj, RENORM_P)
+            a = adj
         shared = ops.SharedGrad() if (torch.is_grad_enabled() and a.requires_grad) else None   # one d(adjacency) buffer per level
 
         def aggregate(h):

@@ -233,10 +233,23 @@ class _LinearCat(Function):
         n, fout, ftot = dy.shape[0], weight.shape[0], weight.shape[1]
         dxs = [None] * len(xs)
         if any(ctx.needs_input_grad[3:]):
-            dcat = torch.empty(n, ftot, dtype=torch.float32, device=dy.device)     # d cat = dy W ; the d x_k are column slices
-            K().gemm(dy, weight, dcat, n, ftot, fout, False, False, ld, ftot, ftot)
-            dxs = [dcat[:, o:o + x.shape[1]] if need else None
-                   for o, x, need in zip(ctx.offs, xs, ctx.needs_input_grad[3:])]
+            # d x_k = dy W[:, slice_k]: one product per piece.  A single product over all sum F_k = 1180 columns would run ten
+            # 128-wide column tiles for 9.2 tiles of work (8 % of a 155 GFLOP contraction) and leave d x_3 with an unaligned
+            # 4720-byte row stride; per piece the wide one has exactly nine tiles and its rows get the padded stride, and the
+            # narrow one is a skinny product that re-reads dy once (~60 us).
+            for i, (o, x, need) in enumerate(zip(ctx.offs, xs, ctx.needs_input_grad[3:])):
+                if not need:
+                    continue
+                f = x.shape[1]
+                if (o * 4) % 16 != 0:                                    # slice start not 16-byte aligned: one joint product
+                    dcat = torch.empty(n, ftot, dtype=torch.float32, device=dy.device)
+                    K().gemm(dy, weight, dcat, n, ftot, fout, False, False, ld, ftot, ftot)
+                    dxs = [dcat[:, oo:oo + xx.shape[1]] if nn_ else None
+                           for oo, xx, nn_ in zip(ctx.offs, xs, ctx.needs_input_grad[3:])]
+                    break
+                dxk = _wide(n, f, dy.device)
+                K().gemm(dy, weight[:, o:], dxk, n, f, fout, False, False, ld, ftot, dxk.stride(0))
+                dxs[i] = dxk
         if ctx.needs_input_grad[0]:
             dw = torch.empty_like(weight)
             for o, x in zip(ctx.offs, xs):                                          # dW[:, slice_k] = dy^T x_k
@@ -731,3 +744,43 @@ class _ReNormDense(Function):
 def renorm_dense(A, p):
     """_re_norm_adj (model/network.py:183-191) on a dense [B,C,C] adjacency that requires grad."""
     return _ReNormDense.apply(A, float(p))
+
+
+class _AdjPrep(Function):
+    """(A~, A~/clamp(rowsum A~, 1)) of a dense level in one pass, A~ = _re_norm_adj(A, p) or A itself (p None).  Both results
+    are outputs of ONE node, so the two gradient streams (through the row-normalised adjacency of the convolutions, and
+    directly into A~ from ``A~ S`` of _diff_pool) meet inside the fused backward kernel instead of in an autograd add."""
+
+    @staticmethod
+    def forward(ctx, A, p):
+        A = _f32c(A)
+        b, c, _ = A.shape
+        dev = A.device
+        At = torch.empty_like(A) if p is not None else None
+        An = torch.empty_like(A)
+        invd = torch.empty(b * c, dtype=torch.float32, device=dev)
+        ge1 = torch.empty(b * c, dtype=torch.float32, device=dev)
+        K().adj_prep_fwd(A, b * c, c, p, At, An, invd, ge1)
+        ctx.save_for_backward(A, An, invd, ge1)
+        ctx.p = p
+        if At is None:
+            At = A.view_as(A)
+        return At, An
+
+    @staticmethod
+    def backward(ctx, gAt, gAn):
+        A, An, invd, ge1 = ctx.saved_tensors
+        b, c, _ = A.shape
+        if gAn is None:                                   # only the pass-through was used
+            if ctx.p is None:
+                return gAt, None
+            gAn = torch.zeros_like(A)
+        dA = torch.empty_like(A)
+        K().adj_prep_bwd(A, An, invd, ge1, _f32c(gAn), None if gAt is None else _f32c(gAt), b * c, c, ctx.p, dA)
+        return dA, None
+
+
+def adj_prep(A, p=None):
+    """Returns (A~, A_norm): A~ = _re_norm_adj(A, p) (model/network.py:183-191; A itself when p is None) and
+    A_norm = A~ / clamp(rowsum(A~), min=1) (DenseSAGEConv's mean divisor folded into the adjacency)."""
+    return _AdjPrep.apply(A, None if p is None else float(p))

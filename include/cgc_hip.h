@@ -200,6 +200,15 @@ int cgc_dense_rownorm_bwd(const float* dOut, const float* Anorm, const float* in
 int cgc_dense_renorm_fwd(const float* A, int R, int C, float p, float* out, cgc_stream_t stream);
 int cgc_dense_renorm_bwd(const float* A, const float* dOut, int R, int C, float p, float* dA, cgc_stream_t stream);
 
+/* ---- A4 + A6 fused (levels 2-3): At = _re_norm_adj(A, p) (skipped when p < 0: At may be NULL and "At" below means A), then
+ * s = rowsum(At), d = max(s,1), An = At/d, invd = 1/d, ge1 = (s >= 1) -- one pass over the [R = B*C, C] adjacency
+ * (model/network.py:183-191,259-262 + DenseSAGEConv's clamp(min=1)). */
+int cgc_adj_prep_fwd(const float* A, int R, int C, float p, float* At, float* An, float* invd, float* ge1, cgc_stream_t stream);
+/* its backward: gAn = gradient w.r.t. An, gAt = gradient that reaches At directly (NULL if none; e.g. from At*S of _diff_pool):
+ * dAt = invd*(gAn - ge1*<gAn,An>_row) + gAt, dA = backward of the re-normalisation at dAt (dA = dAt when p < 0). */
+int cgc_adj_prep_bwd(const float* A, const float* An, const float* invd, const float* ge1, const float* gAn, const float* gAt,
+                     int R, int C, float p, float* dA, cgc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -419,3 +419,20 @@ class TorchKernels(KernelSpec):
         q = 1.0 / ((a * m).sum(1, keepdim=True) + RENORM_EPS)
         t = (g * a * m).sum(1, keepdim=True)
         dA_out.view(R, C).copy_((1 - p) * q * (g - q * t) * m)
+
+    def adj_prep_fwd(self, A, R, C, p, At_out, An_out, invd_out, ge1_out):
+        src = A
+        if p is not None:
+            self.dense_renorm_fwd(A, R, C, p, At_out)
+            src = At_out
+        self.dense_rownorm_fwd(src, R, C, An_out, invd_out, ge1_out)
+
+    def adj_prep_bwd(self, A, An, invd, ge1, gAn, gAt, R, C, p, dA_out):
+        dAt = torch.empty_like(An)
+        self.dense_rownorm_bwd(gAn, An, invd, ge1, R, C, dAt)
+        if gAt is not None:
+            dAt = dAt + gAt.reshape(dAt.shape)
+        if p is None:
+            dA_out.copy_(dAt.reshape(dA_out.shape))
+        else:
+            self.dense_renorm_bwd(A, dAt, R, C, p, dA_out)

@@ -450,6 +450,29 @@ def test_dense_adjacency_transforms(B_, C):
         close(x, y, 2e-5, 'dense transform %d' % i)
 
 
+@pytest.mark.parametrize('B_,C', [(3, 4), (2, 18), (3, 60), (2, 114), (1, 1140)])
+@pytest.mark.parametrize('p', [None, 0.4])
+@pytest.mark.parametrize('second_stream', [False, True])
+def test_fused_adjacency_preparation(B_, C, p, second_stream):
+    """cgc_adj_prep_{fwd,bwd}: re-normalisation + clamped row normalisation in one pass, with the gradient that reaches the
+    re-normalised adjacency directly (second_stream) folded into the backward -- against the composition of the unfused ops."""
+    R = B_ * C
+    A = rnd(B_, C, C, seed=C).abs()
+    A[0, 1] *= 0.001
+    gAn, gAt = rnd(B_, C, C, seed=1), (rnd(B_, C, C, seed=2) if second_stream else None)
+    res = {}
+    for name, K_, dev in (('ref', REF, 'cpu'), ('hip', hip(), DEV)):
+        a = A.to(dev)
+        At = torch.empty_like(a) if p is not None else None
+        An, invd, ge1 = torch.empty_like(a), torch.empty(R, device=dev), torch.empty(R, device=dev)
+        K_.adj_prep_fwd(a, R, C, p, At, An, invd, ge1)
+        dA = torch.empty_like(a)
+        K_.adj_prep_bwd(a, An, invd, ge1, gAn.to(dev), None if gAt is None else gAt.to(dev), R, C, p, dA)
+        res[name] = ([At] if At is not None else []) + [An, invd, dA]
+    for i, (x, y) in enumerate(zip(res['hip'], res['ref'])):
+        close(x, y, 2e-5, 'adj_prep %d' % i)
+
+
 @pytest.mark.parametrize('C,n', [(8, 37), (20, 300), (16, 1500), (20, 2500)])
 def test_dense_jk_kernels(C, n):
     """Fused bi-LSTM + attention (csrc/jk.hip) against the torch restatement, and that restatement against torch.nn.LSTM."""
