@@ -64,6 +64,10 @@ def parse():
     p.add_argument('--cpu-warmup', type=int, default=3, help='CPU baseline: untimed warm-up steps')
     p.add_argument('--cpu-steps', type=int, default=5, help='CPU baseline: timed steps')
     p.add_argument('--no-kernel-timing', action='store_true', help='do not record per-launch HIP events')
+    p.add_argument('--graph', action='store_true',
+                   help='replay the fixed-shape dense levels (2-3) from two hipGraphs (network.enable_graph_capture); bitwise the same '
+                        'results, measured 4-5 %% SLOWER than eager launches on ROCm 7.2 (DESIGN.md), hence off by default')
+    p.add_argument('--plain-adam', action='store_true', help='torch.optim.Adam without fused=True (one kernel per parameter group)')
     return p.parse_args()
 
 
@@ -191,8 +195,13 @@ def main():
     torch.manual_seed(0)
     model = make_model(args, network).to(dev)
     model.train()
+    if args.graph:
+        model.enable_graph_capture()           # levels 2-3 (fixed shapes per batch size): forward + backward as two hipGraphs
     dp = DataParallel(model) if world > 1 else model
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
+    # the reference's optimiser (common/utils.py:119-121: Adam, lr 1e-3, weight decay 1e-4); fused=True is the same update as
+    # ONE kernel over all parameters instead of ~16 multi-tensor launches (host-side cost matters at small per-GPU batches)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4, fused=not args.plain_adam)
+    torch.autograd.set_multithreading_enabled(False)     # backward on the calling thread: no engine-thread hand-off per node
 
     def step(b):
         _, loss = dp(b)
@@ -240,7 +249,8 @@ def main():
                                    % (len(lists[0]), round(nodes / len(lists[0])), round(edges / len(lists[0])), args.feat,
                                       args.maxn, c1, int(c1 * 0.1), args.flags),
                        'global_batch': args.batch * (1 if strong else world), 'nodes_per_batch': round(nodes),
-                       'parallelism': 'dp%d' % world, 'includes': 'CSR build + fwd + loss + bwd + grad all-reduce + Adam'},
+                       'parallelism': 'dp%d' % world, 'includes': 'CSR build + fwd + loss + bwd + grad all-reduce + Adam',
+                       'hipgraph_dense_levels': bool(args.graph), 'fused_adam': not args.plain_adam},
         }
         if timer is not None:
             s = timer.summary()

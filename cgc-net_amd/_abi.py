@@ -39,6 +39,8 @@ PROTOTYPES = {
     'cgc_jk_lstm_bwd': [P, P, I, I, I, P, P, P, P, P, P, P, P, P, P],
     'cgc_jk_bwd_ws_floats': [I],
     'cgc_jk_lstm_bwd_params': [P, P, I, I, I, P, P, P, P, P, P, P, P, P],
+    'cgc_jk_param_grad_floats': [I],
+    'cgc_jk_unpack_param_grads': [P, I, P, P],
     'cgc_dense_rownorm_fwd': [P, I, I, P, P, P, P],
     'cgc_dense_rownorm_bwd': [P, P, P, P, I, I, P, P],
     'cgc_dense_renorm_fwd': [P, I, I, F, P, P],
@@ -53,4 +55,4 @@ def declare(lib):
     for name, argtypes in PROTOTYPES.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
-        fn.restype = C.c_int64 if name.endswith(('_ws_ints', '_ws_floats', '_offset')) else C.c_int
+        fn.restype = C.c_int64 if name.endswith(('_ws_ints', '_ws_floats', '_offset', '_grad_floats')) else C.c_int

@@ -368,3 +368,42 @@ extern "C" int cgc_jk_lstm_bwd_params(const float* xs, const float* dout, int n,
   fill_weights(w, lstm, w_att, b_att);
   return jk_mfma_bwd_params(xs, dout, n, npad, C, w, HS, CS, dxs, G, ws, as_stream(stream));
 }
+
+// G [2][4H+1][C+2H+1] -> the parameter gradients of DenseJK in ONE contiguous buffer, in torch.nn.LSTM / nn.Linear order:
+// per direction d: dW_ih [4H,C] | dW_hh [4H,H] | db_ih [4H] | db_hh [4H] (= db_ih), then d att.weight [2H] and d att.bias [1].
+// Every gradient is then a contiguous slice that autograd can hand to the parameter as it is -- returned as strided windows of
+// G they were each cloned by AccumulateGrad (24 extra copy kernels per step for the three DenseJK modules).
+__global__ void k_jk_unpack(const float* __restrict__ G, int C, int H, float* __restrict__ flat) {
+  const int NI = C + 2 * H + 1, NG = 4 * H + 1;
+  const int per_dir = 4 * H * C + 4 * H * H + 8 * H, total = 2 * per_dir + 2 * H + 1;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    float v;
+    if (i < 2 * per_dir) {
+      const int d = i / per_dir;
+      int e = i - d * per_dir;
+      const float* Gd = G + (size_t)d * NG * NI;
+      if (e < 4 * H * C) v = Gd[(e / C) * NI + (e % C)];
+      else if ((e -= 4 * H * C) < 4 * H * H) v = Gd[(e / H) * NI + C + (e % H)];
+      else { e -= 4 * H * H; v = Gd[(e % (4 * H)) * NI + C + H]; }
+    } else {
+      const int e = i - 2 * per_dir;
+      if (e < 2 * H) v = G[((size_t)(e / H) * NG + 4 * H) * NI + C + H + 1 + (e % H)];
+      else v = G[(size_t)(4 * H) * NI + C + H];
+    }
+    flat[i] = v;
+  }
+}
+
+extern "C" int64_t cgc_jk_param_grad_floats(int C) {
+  const int64_t H = 3 * (int64_t)C / 2;
+  return 2 * (4 * H * C + 4 * H * H + 8 * H) + 2 * H + 1;
+}
+
+extern "C" int cgc_jk_unpack_param_grads(const float* G, int C, float* flat, cgc_stream_t stream) {
+  if (C <= 0) return CGC_EINVAL;
+  const int H = 3 * C / 2;
+  const int total = (int)cgc_jk_param_grad_floats(C);
+  hipLaunchKernelGGL(k_jk_unpack, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), G, C, H, flat);
+  CGC_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}

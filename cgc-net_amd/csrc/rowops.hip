@@ -242,19 +242,78 @@ extern "C" int cgc_bn_finalize(const double* stats, int F, double count, float e
   return 0;
 }
 
-// The training forward's statistics as ONE call: l2norm + activation sums, second stage, finalize, running statistics and
-// num_batches_tracked += 1 (three launches; one host call instead of three plus torch's counter increment).
-// ws: cgc_stats_blocks(n,F)*2F floats for the slots + 4F + 2 floats for the fp64 sums.
+// second stage of the statistics + finalize in one kernel: the column sums of the slots (same grouping and order as
+// k_reduce_slots<double>, so the same bits) and mean / istd / running statistics / num_batches_tracked of k_bn_finalize
+__global__ __launch_bounds__(256) void k_stats_finalize(const float* __restrict__ ws, int slots, int F, double count, float eps,
+                                                        float momentum, float* running_mean, float* running_var,
+                                                        float* __restrict__ mean, float* __restrict__ istd, long long* nbt) {
+  __shared__ double part[2][8][32];
+  const int cl = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int f = blockIdx.x * 32 + cl;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && nbt != nullptr) *nbt += 1;       // nn.BatchNorm1d's num_batches_tracked
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    double s = 0.0;
+    if (f < F) {
+      const float* col = ws + (size_t)q * F + f;
+      const size_t width = 2 * (size_t)F;
+      double a[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] = 0.0;
+      int k = grp;
+      for (; k + 56 < slots; k += 64) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] += (double)col[(size_t)(k + 8 * u) * width];
+      }
+      for (; k < slots; k += 8) a[0] += (double)col[(size_t)k * width];
+      s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    }
+    part[q][grp][cl] = s;
+  }
+  __syncthreads();
+  if (grp != 0 || f >= F) return;
+  double s0 = part[0][0][cl], s1 = part[1][0][cl];
+#pragma unroll
+  for (int g = 1; g < 8; ++g) { s0 += part[0][g][cl]; s1 += part[1][g][cl]; }
+  const double m = s0 / count;
+  double var = s1 / count - m * m;             // biased; the padded zero rows are part of `count`
+  if (var < 0.0) var = 0.0;
+  mean[f] = (float)m;
+  istd[f] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean != nullptr) {
+    const double unbiased = var * count / (count > 1.0 ? count - 1.0 : 1.0);
+    running_mean[f] = (1.f - momentum) * running_mean[f] + momentum * (float)m;
+    running_var[f] = (1.f - momentum) * running_var[f] + momentum * (float)unbiased;
+  }
+}
+
+int launch_stats_finalize(const float* ws, int slots, int F, double count, float eps, float momentum, float* running_mean,
+                          float* running_var, float* mean, float* istd, int64_t* nbt, hipStream_t stream) {
+  hipLaunchKernelGGL(k_stats_finalize, dim3(ceil_div(F, 32)), dim3(256), 0, stream, ws, slots, F, count, eps, momentum,
+                     running_mean, running_var, mean, istd, reinterpret_cast<long long*>(nbt));
+  CGC_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}
+
+// The training forward's statistics as ONE call: l2norm + activation sums, then second stage + finalize + running statistics +
+// num_batches_tracked += 1 in one kernel (two launches; one host call instead of three plus torch's counter increment).
+// ws: cgc_stats_blocks(n,F)*2F floats for the slots (+ 4F + 2 spare floats kept for ABI compatibility).
 extern "C" int cgc_l2norm_act_bn(const float* h, int n, int F, int normalize, int act, float* hn, float* rinv, float* ws,
                                  double count, float eps, float momentum, float* running_mean, float* running_var,
                                  int64_t* num_batches_tracked, float* mean, float* istd, cgc_stream_t stream) {
   if (F <= 0) return 0;
   if (ws == nullptr || mean == nullptr || istd == nullptr) return CGC_EINVAL;
-  const size_t slot_floats = (size_t)(cgc_stats_blocks(n, F) > 0 ? cgc_stats_blocks(n, F) : 1) * 2 * F;
-  double* stats = reinterpret_cast<double*>(ws + slot_floats + (slot_floats & 1));        // 8-byte aligned
-  const int rc = cgc_l2norm_act_stats(h, n, F, normalize, act, hn, rinv, stats, ws, stream);
-  if (rc != 0) return rc;
-  hipLaunchKernelGGL(k_bn_finalize, dim3(ceil_div(F, 256)), dim3(256), 0, as_stream(stream), stats, F, count, eps, momentum,
+  int slots = 0;
+  if (n > 0) {
+    const bool vec_ok = (F % 4 == 0) && aligned16(h) && aligned16(hn);
+    ColCfg cfg = col_cfg(n, F, vec_ok);
+    if (!cfg.ok) return CGC_EINVAL;
+    const size_t smem = sizeof(float) * 3 * 2 * F;
+    DISPATCH_COL(k_l2norm_act_stats, cfg, smem, as_stream(stream), h, n, F, cfg.lpr, normalize, act, hn, rinv, ws);
+    CGC_RETURN_IF_LAUNCH_FAILED();
+    slots = cfg.blocks;
+  }
+  hipLaunchKernelGGL(k_stats_finalize, dim3(ceil_div(F, 32)), dim3(256), 0, as_stream(stream), ws, slots, F, count, eps, momentum,
                      running_mean, running_var, mean, istd, reinterpret_cast<long long*>(num_batches_tracked));
   CGC_RETURN_IF_LAUNCH_FAILED();
   return 0;

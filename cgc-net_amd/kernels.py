@@ -181,6 +181,11 @@ class KernelSpec(object):
         unspecified)."""
         raise NotImplementedError
 
+    def jk_unpack_param_grads(self, G, C):
+        """G [2, 4H+1, C+2H+1] -> list of CONTIGUOUS gradients in parameter order: (w_ih, w_hh, b_ih, b_hh) forward, the same
+        four reverse, att.weight [1, 2H], att.bias [1] -- all slices of one flat buffer."""
+        raise NotImplementedError
+
     # ------------------------------------------------------------------ dense adjacency ops at levels 2-3 (A4, A6)
     def dense_rownorm_fwd(self, A, R, C, out, invd_out, ge1_out):
         """s = rowsum(A); d = max(s,1); out = A/d; invd = 1/d; ge1 = (s >= 1)  (clamp(min=1) of DenseSAGEConv)."""
@@ -235,6 +240,22 @@ if _raw_stream is None or _cur_device is None:          # older / newer torch wi
 
     def _cur_device():
         return torch.cuda.current_device()
+
+
+def split_jk_param_grads(flat, C):
+    """Views of the flat DenseJK parameter-gradient buffer (layout: cgc_jk_unpack_param_grads, include/cgc_hip.h)."""
+    H = 3 * C // 2
+    out, o = [], 0
+    for _ in range(2):
+        for shape in ((4 * H, C), (4 * H, H), (4 * H,), (4 * H,)):
+            k = 1
+            for d in shape:
+                k *= d
+            out.append(flat[o:o + k].view(shape))
+            o += k
+    out.append(flat[o:o + 2 * H].view(1, 2 * H))
+    out.append(flat[o + 2 * H:o + 2 * H + 1])
+    return out
 
 
 def _ptr(t):
@@ -563,6 +584,12 @@ class HipKernels(KernelSpec):
         for d in range(2):
             self.gemm(DGT[d], INT[d], ws2, ng, ni, kp, False, True, ktot, ktot, ni, 1.0, 0.0, None, parts, kp, kp, ng * ni)
             self.reduce_batch_sum(ws2, G_out[d], parts, ng * ni, 0.0)
+
+    def jk_unpack_param_grads(self, G, C):
+        self._dev(G)
+        flat = torch.empty(int(self.lib.cgc_jk_param_grad_floats(int(C))), dtype=torch.float32, device=G.device)
+        self._chk(self.lib.cgc_jk_unpack_param_grads(_ptr(G), int(C), _ptr(flat), self._stream()), 'cgc_jk_unpack_param_grads')
+        return split_jk_param_grads(flat, C)
 
     # -- dense adjacency ops
     def dense_rownorm_fwd(self, A, R, C, out, invd_out, ge1_out):

@@ -498,12 +498,10 @@ class _DenseJK(Function):
         # backward kernel on the matrix cores (staged through transposed buffers + a GEMM only on the unaligned fallback)
         G = torch.empty(2, ng, ni, dtype=torch.float32, device=dev)
         K().jk_bwd_params(xs, _f32c(dout), n, npad, C, lstm, w_att, b_att, HS, CS, dxs, G)
-        grads = []
-        for d in range(2):
-            grads += [G[d, :4 * H, :C], G[d, :4 * H, C:C + H], G[d, :4 * H, C + H], G[d, :4 * H, C + H]]
-        dw_att = torch.cat([G[0, 4 * H, C + H + 1:], G[1, 4 * H, C + H + 1:]]).reshape(w_att.shape)
-        db_att = G[0, 4 * H, C + H].reshape(b_att.shape)
-        return (dxs, dw_att, db_att) + tuple(grads)
+        # one unpack kernel -> contiguous gradients (strided windows of G would each be cloned by AccumulateGrad)
+        g = K().jk_unpack_param_grads(G, C)
+        dw_att, db_att = g[8].reshape(w_att.shape), g[9].reshape(b_att.shape)
+        return (dxs, dw_att, db_att) + tuple(g[:8])
 
 
 def dense_jk(xs, lstm_module, att_module):

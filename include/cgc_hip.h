@@ -192,6 +192,11 @@ int64_t cgc_jk_bwd_ws_floats(int C);
 int cgc_jk_lstm_bwd_params(const float* xs, const float* dout, int n, int npad, int C, const float* const* lstm,
                            const float* w_att, const float* b_att, const float* HS, const float* CS, float* dxs, float* G,
                            float* ws, cgc_stream_t stream);
+/* G -> the DenseJK parameter gradients as ONE contiguous buffer of cgc_jk_param_grad_floats(C) floats, in parameter order:
+ * per direction dW_ih [4H,C] | dW_hh [4H,H] | db_ih [4H] | db_hh [4H], then d att.weight [2H], d att.bias [1]
+ * (model/network.py:27-33: nn.LSTM(C, 3C/2, bidirectional) + nn.Linear(3C, 1)). */
+int64_t cgc_jk_param_grad_floats(int C);
+int cgc_jk_unpack_param_grads(const float* G, int C, float* flat, cgc_stream_t stream);
 
 /* ---- A4/A6 at levels 2-3 (dense, real-valued adjacency that carries gradient) */
 int cgc_dense_rownorm_fwd(const float* A, int R, int C, float* out, float* invd, float* ge1, cgc_stream_t stream);

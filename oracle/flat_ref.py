@@ -436,3 +436,12 @@ class TorchKernels(KernelSpec):
             dA_out.copy_(dAt.reshape(dA_out.shape))
         else:
             self.dense_renorm_bwd(A, dAt, R, C, p, dA_out)
+
+    def jk_unpack_param_grads(self, G, C):
+        from cgc_net_amd.kernels import split_jk_param_grads
+        H = 3 * C // 2
+        parts = []
+        for d in range(2):
+            parts += [G[d, :4 * H, :C].reshape(-1), G[d, :4 * H, C:C + H].reshape(-1), G[d, :4 * H, C + H], G[d, :4 * H, C + H]]
+        parts += [G[0, 4 * H, C + H + 1:], G[1, 4 * H, C + H + 1:], G[0, 4 * H, C + H].reshape(1)]
+        return split_jk_param_grads(torch.cat([p.reshape(-1) for p in parts]), C)

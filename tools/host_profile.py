@@ -13,12 +13,14 @@ from cgc_net_amd import network  # noqa: E402
 from cgc_net_amd.data import Batch, SyntheticCellGraphs  # noqa: E402
 
 dev = 'cuda:0'
-ds = SyntheticCellGraphs(32, 1800, 16, base_seed=0)
-b = Batch.from_data_list([ds[i] for i in range(32)]).to(dev)
+B = int(sys.argv[sys.argv.index('--batch') + 1]) if '--batch' in sys.argv else 32
+MAXN = int(sys.argv[sys.argv.index('--maxn') + 1]) if '--maxn' in sys.argv else 1800
+ds = SyntheticCellGraphs(B, 1800, 16, base_seed=0)
+b = Batch.from_data_list([ds[i] for i in range(B)]).to(dev)
 kw = dict(concat=True, load_data_sparse=True)
 if '--shipped' in sys.argv:
     kw.update(norm_adj=True, jk=True, drop_out=0.2)
-model = network.SoftPoolingGcnEncoder(1800, 16, 20, 20, True, True, 20, 3, 0.1, [50], **kw).to(dev)
+model = network.SoftPoolingGcnEncoder(MAXN, 16, 20, 20, True, True, 20, 3, 0.1, [50], **kw).to(dev)
 opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
 
 
@@ -39,4 +41,10 @@ for _ in range(20):
 torch.cuda.synchronize()
 pr.disable()
 st = pstats.Stats(pr)
-st.sort_stats('tottime').print_stats(28)
+st.sort_stats('tottime').print_stats(40)
+import time
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(20):
+    step()
+t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+print('host issue time per step %.3f ms, wall per step %.3f ms' % ((t1 - t0) * 50, (t2 - t0) * 50))
