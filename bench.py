@@ -59,6 +59,8 @@ def parse():
     p.add_argument('--backend', default='nccl', help="torch.distributed backend for N>1: 'nccl' (= RCCL over xGMI; default) or 'gloo' (tests)")
     p.add_argument('--oversubscribe', action='store_true',
                    help='tests only: ranks share the visible GPUs (rank %% device_count); needs --backend gloo (RCCL refuses duplicates)')
+    p.add_argument('--spatial', action='store_true',
+                   help='list the nuclei of every graph grid cell by grid cell (data.spatial_order) instead of in draw order')
     p.add_argument('--pool', type=int, default=4, help='distinct resident batches cycled through')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--cpu-warmup', type=int, default=3, help='CPU baseline: untimed warm-up steps')
@@ -180,7 +182,8 @@ def main():
     # global batches on every rank, each rank keeping its chunk of the cumulative-node-count split (data.partition_by_nodes)
     from cgc_net_amd.data import partition_by_nodes
     strong = args.scaling == 'strong' and world > 1
-    ds = SyntheticCellGraphs(args.pool * args.batch, args.nodes, args.feat, base_seed=0 if strong else 100000 * rank)
+    ds = SyntheticCellGraphs(args.pool * args.batch, args.nodes, args.feat, base_seed=0 if strong else 100000 * rank,
+                             spatial=args.spatial)
     lists = [[ds[b * args.batch + i] for i in range(args.batch)] for b in range(args.pool)]
     if strong:
         chunks = [partition_by_nodes(l, world) for l in lists]
@@ -250,7 +253,7 @@ def main():
                                       args.maxn, c1, int(c1 * 0.1), args.flags),
                        'global_batch': args.batch * (1 if strong else world), 'nodes_per_batch': round(nodes),
                        'parallelism': 'dp%d' % world, 'includes': 'CSR build + fwd + loss + bwd + grad all-reduce + Adam',
-                       'hipgraph_dense_levels': bool(args.graph), 'fused_adam': not args.plain_adam},
+                       'hipgraph_dense_levels': bool(args.graph), 'node_order': 'grid cells' if args.spatial else 'draw order', 'fused_adam': not args.plain_adam},
         }
         if timer is not None:
             s = timer.summary()

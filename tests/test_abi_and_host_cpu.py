@@ -127,6 +127,20 @@ def test_device_collate_front_end_matches_host_collate(torch_kernels):
     key = lambda e: sorted(zip(e[0].tolist(), e[1].tolist()))
     assert key(built.edge_index) == key(host.edge_index)
     assert torch.equal(built.x, torch.cat([d.x for d in items]))
+    # spatial=True: the same graphs with their nodes re-listed grid cell by grid cell (a permutation inside every graph)
+    sp = Batch.from_data_list(bare, device='cpu', knn=(100.0, 8), spatial=True)
+    perm = sp.node_perm
+    assert torch.equal(torch.sort(perm)[0], torch.arange(perm.numel())) and torch.equal(sp.batch, host.batch)
+    assert torch.equal(sp.x, built.x[perm]) and torch.equal(sp.pos, built.pos[perm])
+    relabelled = perm[sp.edge_index]                                    # back to the items' node numbering
+    assert key(relabelled) == key(host.edge_index)
+    cell = torch.floor(sp.pos / 100.0).long()
+    for g in range(5):                                                   # grid rows ascend inside every graph
+        cy = cell[sp.batch == g, 1]
+        assert bool((cy[1:] >= cy[:-1]).all())
+    from cgc_net_amd.data import reorder_nodes, spatial_order
+    d0 = reorder_nodes(items[0], spatial_order(items[0].pos))
+    assert key(spatial_order(items[0].pos)[d0.edge_index]) == key(items[0].edge_index) and bool((d0.edge_index[0][1:] >= d0.edge_index[0][:-1]).all())
 
 
 # ------------------------------------------------------------------ F4: checkpoint interchange + evaluation protocol
