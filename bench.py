@@ -278,17 +278,28 @@ def main():
                                                'launches_per_step': g['launches'] / args.steps,
                                                'avg_launch_ms': round(g['avg_ms'], 4),
                                                'mb_per_launch': round(bytes_per_launch / 1e6, 2)}
-        # HBM traffic per launch from the committed PMC passes of this same command (profiles/make_traffic_json.py); null if absent
-        try:
-            tr = json.load(open(os.path.join(ROOT, 'profiles', 'r01_traffic.json')))
-            if 'roofline' in out and 'gemm_128x128' in tr and args.flags == 'shipped' and args.maxn == 11404:
-                out['roofline']['traffic'] = round(tr['gemm_128x128']['hbm_bytes_per_launch'])
-                out['roofline']['traffic_source'] = 'profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes/launch)'
-            if 'roofline_aggregation' in out and 'spmm_wide' in tr and args.flags == 'shipped' and args.maxn == 11404:
-                out['roofline_aggregation']['traffic'] = round(tr['spmm_wide']['hbm_bytes_per_launch'])
-                out['roofline_aggregation']['traffic_source'] = 'profiles/r01_traffic.json'
-        except (OSError, ValueError, KeyError):
-            pass
+        # HBM traffic per launch and counter-derived matrix-core utilisation from the committed PMC passes of this same command
+        # (profiles/make_traffic_json.py, profiles/make_counters_json.py); null if absent or another configuration is run
+        if args.flags == 'shipped' and args.maxn == 11404 and args.batch == 32 and args.nodes == 1800:
+            try:
+                tr = json.load(open(os.path.join(ROOT, 'profiles', 'r02_traffic.json')))
+                if 'roofline' in out and 'gemm_128x128' in tr:
+                    out['roofline']['traffic'] = round(tr['gemm_128x128']['hbm_bytes_per_launch'])
+                    out['roofline']['traffic_source'] = 'profiles/r02_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes/launch)'
+                if 'roofline_aggregation' in out and 'spmm_wide' in tr:
+                    out['roofline_aggregation']['traffic'] = round(tr['spmm_wide']['hbm_bytes_per_launch'])
+                    out['roofline_aggregation']['traffic_source'] = 'profiles/r02_traffic.json'
+            except (OSError, ValueError, KeyError):
+                pass
+            try:
+                cn = json.load(open(os.path.join(ROOT, 'profiles', 'r02_counters.json')))
+                if 'roofline' in out and cn.get('gemm_128x128', {}).get('mfma_busy') is not None:
+                    out['roofline']['mfma_busy_counter'] = cn['gemm_128x128']['mfma_busy']
+                    out['roofline']['mfma_busy_source'] = ('profiles/r02_counters.json: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x '
+                                                           'GRBM_GUI_ACTIVE/8) of this command under rocprofv3 --pmc (clock-independent; '
+                                                           'frac = mfma_busy x sustained clock / 2.4 GHz)')
+            except (OSError, ValueError, KeyError):
+                pass
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args, cpu_batches)
         print(json.dumps(out), flush=True)

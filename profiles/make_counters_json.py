@@ -1,0 +1,42 @@
+#!/usr/bin/env python
+"""Counter-derived matrix-core utilisation of the dominant GEMM from a rocprofv3 --pmc SQ pass (profiles/rNN_bench_c3_pmc_sq.txt,
+written by tools/pmc_run.sh around `bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing`).
+
+  mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles),  kernel cycles = GRBM_GUI_ACTIVE / 8 XCDs
+
+SQ_VALU_MFMA_BUSY_CYCLES counts cycles in which a SIMD's matrix pipe is executing (64 per v_mfma_f32_32x32x2_f32, summed over
+the chip); GRBM_GUI_ACTIVE counts busy clocks per XCD, summed over the 8 XCDs.  The ratio is clock-independent: it says what
+fraction of the matrix pipes' cycles did MFMA work, whatever frequency the chip sustained (MI355X_MICROARCH.md, DVFS give-back).
+The flops-derived `frac` of bench.py divides by the 2.4 GHz peak instead, so frac = mfma_busy x (sustained clock / 2.4 GHz).
+usage: make_counters_json.py profiles/r02_bench_c3_pmc_sq.txt > profiles/r02_counters.json"""
+import collections
+import json
+import sys
+
+vals = collections.defaultdict(dict)
+for line in open(sys.argv[1]):
+    parts = line.split()
+    if len(parts) < 5 or parts[0] == 'kernel':
+        continue
+    median = float(parts[-2])
+    calls = int(parts[-3])
+    counter = parts[-4]
+    kernel = ' '.join(parts[:-4])
+    vals[kernel].setdefault(counter, (calls, median))
+out = {}
+tot_busy = tot_cyc = 0.0
+for k, c in vals.items():
+    if not k.startswith('k_gemm_f32<2, 2, 2, 2') or 'SQ_VALU_MFMA_BUSY_CYCLES' not in c or 'GRBM_GUI_ACTIVE' not in c:
+        continue
+    calls, busy = c['SQ_VALU_MFMA_BUSY_CYCLES']
+    cyc = c['GRBM_GUI_ACTIVE'][1] / 8.0
+    wave = c.get('SQ_WAVE_CYCLES', (0, 0.0))[1]
+    out[k] = {'launches_profiled': calls, 'mfma_busy': round(busy / (1024.0 * cyc), 4), 'kernel_cycles': round(cyc),
+              'wave_wait_any_frac': round(c.get('SQ_WAIT_ANY', (0, 0.0))[1] / wave, 4) if wave else None,
+              'wave_wait_inst_frac': round(c.get('SQ_WAIT_INST_ANY', (0, 0.0))[1] / wave, 4) if wave else None,
+              'lds_bank_conflict_cycles': c.get('SQ_LDS_BANK_CONFLICT', (0, 0.0))[1]}
+    tot_busy += busy * calls
+    tot_cyc += 1024.0 * cyc * calls
+out['gemm_128x128'] = {'mfma_busy': round(tot_busy / tot_cyc, 4) if tot_cyc else None,
+                       'definition': 'SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE / 8), launch-weighted over the three instantiations'}
+print(json.dumps(out, indent=1))

@@ -6,10 +6,12 @@ export TMPDIR=/tmp
 R=$(pwd)
 rm -f gpurun_out/${tag}_pmc.txt
 i=0
-passes=${PMC_PASSES:-3}
+passes=${PMC_PASSES:-5}
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE" \
            "SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_VALU SQ_INSTS_VMEM SQ_WAVES" \
-           "GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM_RD SQ_INSTS_SALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VALU"; do
+           "GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM_RD SQ_INSTS_SALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VALU" \
+           "FETCH_SIZE TCC_HIT_sum TCC_MISS_sum" \
+           "WRITE_SIZE"; do
   i=$((i+1))
   if [ $i -gt $passes ]; then break; fi
   d=$R/gpurun_out/${tag}_pmc$i
