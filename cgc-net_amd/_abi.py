@@ -20,6 +20,7 @@ PROTOTYPES = {
     'cgc_spmm_graphs': [P, P, P, P, P, P, P, P, I, I, I, P, I, I, I, P],
     'cgc_gemm_f32': [I, I, I, I, I, F, P, I, P, I, F, P, I, P, I, L, L, L, P, I, I, P],
     'cgc_gemm_f32_cat': [I, I, I, I, I, F, P, I, P, I, F, P, I, P, I, L, L, L, P, I, I, I, P, P, P, P, P, P, P, P],
+    'cgc_gemm_tuning': [I],
     'cgc_reduce_batch_sum': [P, P, I, L, F, P],
     'cgc_reduce_batched': [P, P, I, I, I, F, P],
     'cgc_stats_blocks': [I, I],

@@ -625,6 +625,14 @@ static int launch_cfg(const GemmArgs& a0, int transA, int transB, int batch, int
   return 0;
 }
 
+// tuning hook (tools/gemm_cfg_sweep.py): 0 = automatic tile selection (default)
+static int g_force_cfg = getenv("CGC_GEMM_CFG") ? atoi(getenv("CGC_GEMM_CFG")) : 0;
+extern "C" int cgc_gemm_tuning(int cfg) {
+  const int old = g_force_cfg;
+  g_force_cfg = cfg;
+  return old;
+}
+
 static int gemm_dispatch(GemmArgs& a, int transA, int transB, int batch, int max_ragged, hipStream_t stream) {
   const int M = a.M, N = a.N, K = a.K, ragged = a.ragged;
   if (batch <= 0 || N <= 0) return 0;
@@ -640,6 +648,21 @@ static int gemm_dispatch(GemmArgs& a, int transA, int transB, int batch, int max
   static const int fill_min = getenv("CGC_GEMM_FILL") ? atoi(getenv("CGC_GEMM_FILL")) : 448;
   const bool sk = k_extent <= shortk_max && a.nx == 0;
   const long long fill = (long long)ceil_div(m_extent, 128) * batch;
+  // experiment hook: CGC_GEMM_CFG = 1..6 forces a tile shape (128x128, 128x64, 64x128, 64x64, 128x32, 32x128), +10 forces the
+  // pipelined kernel, +20 the short-K kernel
+  const int force = g_force_cfg;
+  if (force > 0) {
+    const bool fsk = force >= 20 ? true : force >= 10 ? false : sk;
+    switch (force % 10) {
+      case 1: return launch_cfg<2, 2, 2, 2>(a, transA, transB, batch, m_extent, fsk, stream);
+      case 2: return launch_cfg<4, 1, 1, 2>(a, transA, transB, batch, m_extent, fsk, stream);
+      case 3: return launch_cfg<1, 4, 2, 1>(a, transA, transB, batch, m_extent, fsk, stream);
+      case 4: return launch_cfg<2, 2, 1, 1>(a, transA, transB, batch, m_extent, fsk, stream);
+      case 5: return launch_cfg<4, 1, 1, 1>(a, transA, transB, batch, m_extent, fsk, stream);
+      case 6: return launch_cfg<1, 4, 1, 1>(a, transA, transB, batch, m_extent, fsk, stream);
+      default: break;
+    }
+  }
   if (N <= 32) return launch_cfg<4, 1, 1, 1>(a, transA, transB, batch, m_extent, sk, stream);          // 128 x 32
   if (N <= 64) {
     if (m_extent > 64 && fill < fill_min) return launch_cfg<2, 2, 1, 1>(a, transA, transB, batch, m_extent, sk, stream);   // 64 x 64
@@ -647,7 +670,12 @@ static int gemm_dispatch(GemmArgs& a, int transA, int transB, int batch, int max
   }
   if (m_extent <= 32) return launch_cfg<1, 4, 1, 1>(a, transA, transB, batch, m_extent, sk, stream);   // 32 x 128
   if (m_extent <= 64) return launch_cfg<1, 4, 2, 1>(a, transA, transB, batch, m_extent, sk, stream);   // 64 x 128
-  if (fill * ceil_div(N, 128) < fill_min) {   // measured on [32 x 1140 x 1140] x [1140 x 114]: NN/NT prefer 64x128, TN prefers 128x64
+  if (fill * ceil_div(N, 128) < fill_min) {   // too few 128x128 tiles to fill the chip (tools/gemm_cfg_sweep.py over the step's shapes)
+    if (N <= 128) {                           // one column tile: long reductions stream A through 128x32 tiles (4 column tiles share the
+      if (k_extent > 256 && m_extent > 128)   // A panel in L2; [32 x 1140 x 1140] x [1140 x 114]: 200 -> 155 us), short ones take 64x64
+        return launch_cfg<4, 1, 1, 1>(a, transA, transB, batch, m_extent, sk, stream);
+      return launch_cfg<2, 2, 1, 1>(a, transA, transB, batch, m_extent, sk, stream);
+    }
     if (transA) return launch_cfg<4, 1, 1, 2>(a, transA, transB, batch, m_extent, sk, stream);
     return launch_cfg<1, 4, 2, 1>(a, transA, transB, batch, m_extent, sk, stream);
   }

@@ -131,6 +131,10 @@ int cgc_gemm_f32_cat(int transA, int transB, int M, int N, int K, float alpha, c
                      int64_t strideA, int64_t strideB, int64_t strideC, const int* gptr, int ragged, int max_ragged,
                      int nx, const float* const* xA, const int* xlda, const int64_t* xstrideA,
                      const float* const* xB, const int* xldb, const int64_t* xstrideB, const int* xK, cgc_stream_t stream);
+/* Tuning hook for experiments (tools/gemm_cfg_sweep.py): cfg 1..6 forces the tile shape 128x128, 128x64, 64x128, 64x64, 128x32,
+ * 32x128 for every following product of this process, +10 the pipelined kernel, +20 the short-K kernel; 0 restores the automatic
+ * selection.  Returns the previous value.  Results do not depend on it (same arithmetic per output element up to tile-edge order). */
+int cgc_gemm_tuning(int cfg);
 
 /* out[j] = beta*out[j] + sum_{s<parts} ws[s*numel + j]  (deterministic split-K combine) */
 int cgc_reduce_batch_sum(const float* ws, float* out, int parts, int64_t numel, float beta, cgc_stream_t stream);
