@@ -27,6 +27,7 @@ PROTOTYPES = {
     'cgc_l2norm_act_stats': [P, I, I, I, I, P, P, P, P, P],
     'cgc_bn_finalize': [P, I, D, F, F, P, P, P, P, P],
     'cgc_l2norm_act_bn': [P, I, I, I, I, P, P, P, D, F, F, P, P, P, P, P, P],
+    'cgc_sage_wide_fwd': [P, I, P, P, I, I, I, I, I, P, I, P, I, P, D, F, F, P, P, P, P, P, P],
     'cgc_bn_act_apply': [P, I, I, I, P, P, P, P, P, I, P],
     'cgc_bn_bwd_reduce': [P, I, P, I, I, I, P, P, P, P, P],
     'cgc_bn_act_l2_bwd': [P, I, P, P, I, I, I, I, I, P, P, P, P, D, P, P, P, P],

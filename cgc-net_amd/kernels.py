@@ -114,6 +114,12 @@ class KernelSpec(object):
         (int64 scalar tensor or None), as nn.BatchNorm1d.forward does."""
         raise NotImplementedError
 
+    def sage_wide_fwd(self, agg, lda, weight, bias, n, Kin, F, normalize, act, hn_out, rinv_out, stats, count, eps, momentum,
+                      running_mean, running_var, num_batches_tracked, mean_out, istd_out):
+        """hn = l2norm(agg[:, :Kin] @ weight + bias) and (stats) the statistics part of l2norm_act_bn, as one kernel for the
+        wide layer of the assignment block.  Returns False (nothing done) when the shape is outside the kernel's envelope."""
+        raise NotImplementedError
+
     def bn_finalize(self, stats, count, eps, momentum, running_mean, running_var, mean_out, istd_out):
         """mean = s0/count, var = s1/count - mean^2 (biased), istd = rsqrt(var+eps); running stats get
         momentum updates with the unbiased var*count/(count-1).  ``count`` = B*Nmax INCLUDING the
@@ -470,6 +476,22 @@ class HipKernels(KernelSpec):
         ws = torch.empty(max(nblk, 1) * 2 * F, dtype=torch.float32, device=h.device) if stats_out is not None else None
         self._chk(self.lib.cgc_l2norm_act_stats(_ptr(h), n, F, int(normalize), act, _ptr(hn_out), _ptr(rinv_out),
                                                 _ptr(stats_out), _ptr(ws), self._stream()), 'cgc_l2norm_act_stats')
+
+    def sage_wide_fwd(self, agg, lda, weight, bias, n, Kin, F, normalize, act, hn_out, rinv_out, stats, count, eps, momentum,
+                      running_mean, running_var, num_batches_tracked, mean_out, istd_out):
+        self._dev(agg, weight, bias, hn_out, rinv_out, running_mean, running_var, num_batches_tracked, mean_out, istd_out)
+        ws = None
+        if stats:
+            nblk = self.lib.cgc_stats_blocks(n, F)
+            ws = torch.empty(max(nblk, 1) * 2 * F + 4 * F + 2, dtype=torch.float32, device=agg.device)
+        rc = self.lib.cgc_sage_wide_fwd(_ptr(agg), lda, _ptr(weight), _ptr(bias), n, Kin, F, int(normalize), act, _ptr(hn_out),
+                                        hn_out.stride(0), _ptr(rinv_out), int(bool(stats)), _ptr(ws), ctypes.c_double(count),
+                                        ctypes.c_float(eps), ctypes.c_float(momentum), _ptr(running_mean), _ptr(running_var),
+                                        _ptr(num_batches_tracked), _ptr(mean_out), _ptr(istd_out), self._stream())
+        if rc == -1:
+            return False
+        self._chk(rc, 'cgc_sage_wide_fwd')
+        return True
 
     def bn_finalize(self, stats, count, eps, momentum, running_mean, running_var, mean_out, istd_out):
         self._dev(stats, running_mean, running_var, mean_out, istd_out)

@@ -354,18 +354,25 @@ class _SageProject(Function):
         F = weight.shape[1]
         dev = agg.device
         h = torch.empty(n, F, dtype=torch.float32, device=dev)
-        K().gemm(agg, weight, h, n, F, fin, False, False, lda, F, F, 1.0, 0.0, bias)
         rinv = torch.empty(n, dtype=torch.float32, device=dev)
         mean = istd = None
         if bn_mode == 2:
             mean = torch.empty(F, dtype=torch.float32, device=dev)
             istd = torch.empty(F, dtype=torch.float32, device=dev)
-            K().l2norm_act_bn(h, n, F, normalize, act, h, rinv, float(count), eps, momentum, running_mean, running_var, nbt,
-                              mean, istd)                                          # in place: h becomes hn
-        else:
-            K().l2norm_act_stats(h, n, F, normalize, act, h, rinv, None)
-            if bn_mode == 1:
-                mean, istd = running_mean, torch.rsqrt(running_var + eps)
+        # wide output from a narrow input (the assignment block's last convolution, [Ntot, 20] -> [Ntot, 1140]): projection,
+        # L2 normalisation and BatchNorm statistics in ONE kernel that writes only hn; everything else: MFMA GEMM + row kernel
+        fused = F >= _WIDE_MIN and fin <= 32 and K().sage_wide_fwd(
+            agg, lda, weight, bias, n, fin, F, normalize, act, h, rinv, bn_mode == 2, float(count), eps, momentum,
+            running_mean, running_var, nbt, mean, istd)
+        if not fused:
+            K().gemm(agg, weight, h, n, F, fin, False, False, lda, F, F, 1.0, 0.0, bias)
+            if bn_mode == 2:
+                K().l2norm_act_bn(h, n, F, normalize, act, h, rinv, float(count), eps, momentum, running_mean, running_var, nbt,
+                                  mean, istd)                                      # in place: h becomes hn
+            else:
+                K().l2norm_act_stats(h, n, F, normalize, act, h, rinv, None)
+        if bn_mode == 1:
+            mean, istd = running_mean, torch.rsqrt(running_var + eps)
         y = _wide(n, F, dev)                              # the 1140-wide layer output is the A operand of the assignment Linear
         K().bn_act_apply(h, n, F, act, mean, istd, gamma, beta, y, y.stride(0))
         ctx.save_for_backward(agg, weight, h, rinv, mean, istd, gamma)

@@ -202,6 +202,17 @@ int cgc_jk_lstm_bwd_params(const float* xs, const float* dout, int n, int npad, 
 int64_t cgc_jk_param_grad_floats(int C);
 int cgc_jk_unpack_param_grads(const float* G, int C, float* flat, cgc_stream_t stream);
 
+/* ---- A4 + A5 for the WIDE layer of the assignment block (DenseSAGEConv(hidden, assign_dim) -> act -> BatchNorm,
+ * model/network.py:114-116 with out_channels = the cluster count): hn [n,F] (row stride ldh) = agg [n,K] (row stride lda) @
+ * W [K,F] + bias, rows L2-normalised (normalize != 0), rinv [n] as cgc_l2norm_act_stats; with stats != 0 also the BatchNorm
+ * statistics of act(hn) over `count` rows exactly as cgc_l2norm_act_bn (same ws size).  One matrix-core kernel in which a
+ * workgroup owns whole rows, so only hn is written (a third of the HBM traffic of cgc_gemm_f32 + cgc_l2norm_act_bn).
+ * Envelope: K <= 32, F <= 1664 -- otherwise CGC_EINVAL and nothing is launched. */
+int cgc_sage_wide_fwd(const float* agg, int lda, const float* W, const float* bias, int n, int K, int F, int normalize, int act,
+                      float* hn, int ldh, float* rinv, int stats, float* ws, double count, float eps, float momentum,
+                      float* running_mean, float* running_var, int64_t* num_batches_tracked, float* mean, float* istd,
+                      cgc_stream_t stream);
+
 /* ---- A4/A6 at levels 2-3 (dense, real-valued adjacency that carries gradient) */
 int cgc_dense_rownorm_fwd(const float* A, int R, int C, float* out, float* invd, float* ge1, cgc_stream_t stream);
 int cgc_dense_rownorm_bwd(const float* dOut, const float* Anorm, const float* invd, const float* ge1, int R, int C,

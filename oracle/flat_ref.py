@@ -445,3 +445,18 @@ class TorchKernels(KernelSpec):
             parts += [G[d, :4 * H, :C].reshape(-1), G[d, :4 * H, C:C + H].reshape(-1), G[d, :4 * H, C + H], G[d, :4 * H, C + H]]
         parts += [G[0, 4 * H, C + H + 1:], G[1, 4 * H, C + H + 1:], G[0, 4 * H, C + H].reshape(1)]
         return split_jk_param_grads(torch.cat([p.reshape(-1) for p in parts]), C)
+
+    def sage_wide_fwd(self, agg, lda, weight, bias, n, Kin, F, normalize, act, hn_out, rinv_out, stats, count, eps, momentum,
+                      running_mean, running_var, num_batches_tracked, mean_out, istd_out):
+        if Kin > 32 or F > 1664:
+            return False
+        h = agg[:, :Kin] @ weight
+        if bias is not None:
+            h = h + bias
+        h = h.contiguous()
+        if stats:
+            self.l2norm_act_bn(h, n, F, normalize, act, hn_out, rinv_out, count, eps, momentum, running_mean, running_var,
+                               num_batches_tracked, mean_out, istd_out)
+        else:
+            self.l2norm_act_stats(h, n, F, normalize, act, hn_out, rinv_out, None)
+        return True

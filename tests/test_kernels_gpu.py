@@ -368,6 +368,36 @@ def test_fused_statistics_and_finalize(n, F):
         close(a, b)
 
 
+@pytest.mark.parametrize('n,K_,F,lda', [(1, 20, 256, 20), (37, 20, 1140, 40), (1000, 16, 1600, 16), (4100, 20, 1140, 40), (300, 7, 257, 12),
+                                         (50, 32, 200, 32), (50, 20, 1700, 20), (50, 33, 512, 36)])
+@pytest.mark.parametrize('stats', [True, False])
+def test_fused_wide_sage_forward(n, K_, F, lda, stats):
+    """cgc_sage_wide_fwd: rank-K projection + bias + L2 normalisation (+ BatchNorm statistics, running stats, batch counter) in one
+    matrix-core kernel, against GEMM + l2norm_act_bn of the contract; shapes outside its envelope report False and touch nothing."""
+    k = hip()
+    big = rnd(n, lda + 4, seed=n)
+    W, bias = rnd(K_, F, seed=1), rnd(F, seed=2)
+    count = float(n + 11)
+    res = {}
+    for name, K__, dev in (('ref', REF, 'cpu'), ('hip', k, DEV)):
+        agg = big.to(dev)[:, 4:4 + lda]                          # a column window of a wider buffer (row stride lda + 4)
+        hn, rinv = torch.full((n, F), 7.0, device=dev), torch.empty(n, device=dev)
+        rm, rv = torch.zeros(F, device=dev), torch.ones(F, device=dev)
+        nbt = torch.zeros((), dtype=torch.int64, device=dev)
+        mean, istd = torch.zeros(F, device=dev), torch.zeros(F, device=dev)
+        ok = K__.sage_wide_fwd(agg, lda + 4, W.to(dev), bias.to(dev), n, K_, F, True, 1, hn, rinv, stats, count, 1e-5, 0.1,
+                               rm if stats else None, rv if stats else None, nbt if stats else None,
+                               mean if stats else None, istd if stats else None)
+        res[name] = (ok, hn, rinv, rm, rv, mean, istd, nbt.double())
+    torch.cuda.synchronize()
+    assert res['hip'][0] == res['ref'][0] == (K_ <= 32 and F <= 1664)
+    if not res['hip'][0]:
+        assert float(res['hip'][1].min()) == 7.0                 # untouched
+        return
+    for i in range(1, 8):
+        close(res['hip'][i], res['ref'][i], TOL, 'sage_wide %d' % i)
+
+
 def test_epilogue_without_bn_and_without_normalize():
     k = hip()
     n, F = 77, 20
