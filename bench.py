@@ -247,7 +247,7 @@ def main():
             'value': round(graphs / elapsed, 2), 'unit': 'graphs/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 3), 'higher_is_better': True,
             'scaling': 'strong' if strong else 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'C3: full CGC-Net (3 conv blocks + 2 DiffPool) fwd+bwd+Adam, %d graphs/GPU/step, '
+            'config': {'workload': ('C3' if args.nodes < 4000 else 'C5 (stress)') + ': full CGC-Net (3 conv blocks + 2 DiffPool) fwd+bwd+Adam, %d graphs/GPU/step, '
                                    '~%d nodes, ~%d edges/graph, %d feat, max_num_nodes=%d (C1=%d, C2=%d), flags=%s'
                                    % (len(lists[0]), round(nodes / len(lists[0])), round(edges / len(lists[0])), args.feat,
                                       args.maxn, c1, int(c1 * 0.1), args.flags),
