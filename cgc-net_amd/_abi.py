@@ -18,6 +18,7 @@ PROTOTYPES = {
     'cgc_csr_invdeg': [P, P, I, P, P],
     'cgc_spmm': [P, P, P, P, P, P, P, P, I, I, P],
     'cgc_spmm_graphs': [P, P, P, P, P, P, P, P, I, I, I, P, I, I, I, P],
+    'cgc_spmm_graphs_ordered': [P, P, P, P, P, P, P, P, I, I, I, P, I, I, I, P, P],
     'cgc_gemm_f32': [I, I, I, I, I, F, P, I, P, I, F, P, I, P, I, L, L, L, P, I, I, P],
     'cgc_gemm_f32_cat': [I, I, I, I, I, F, P, I, P, I, F, P, I, P, I, L, L, L, P, I, I, I, P, P, P, P, P, P, P, P],
     'cgc_gemm_tuning': [I],

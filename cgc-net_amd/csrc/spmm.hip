@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void k_spmm_wide(const int* __restrict__ rowpt
                                                    const float* __restrict__ pre, const float* __restrict__ post,
                                                    const float* __restrict__ x, float* __restrict__ out, int n, int W, int ld,
                                                    int n_ctiles, int run, int blocks_per_ct, int n_chunks,
-                                                   const int* __restrict__ gptr, int order) {
+                                                   const int* __restrict__ gptr, int order, const int* __restrict__ gorder) {
   typedef float f4v __attribute__((ext_vector_type(4)));
   const int nb = gridDim.x, b = blockIdx.x;
   const int vb = (nb % 8 == 0) ? (b % 8) * (nb / 8) + b / 8 : b;
@@ -183,7 +183,9 @@ __global__ __launch_bounds__(256) void k_spmm_wide(const int* __restrict__ rowpt
     // on the last 8 graphs and walk down.  2: x was written by a batched GEMM whose XCD-contiguous tile order left the tail
     // of every eighth of the batch in cache -- every XCD walks its own eighth backwards.  0: ascending.
     int gi = chunk;
-    if (order == 1) {
+    if (gorder != nullptr) {              // caller-supplied visiting sequence (size-balanced over the XCDs: large graphs)
+      gi = gorder[chunk];
+    } else if (order == 1) {
       const int per_x = n_chunks >> 3;
       gi = ((n_chunks & 7) == 0 && (nb & 7) == 0) ? (per_x - 1 - chunk % per_x) * 8 + chunk / per_x : n_chunks - 1 - chunk;
     } else if (order == 2) {
@@ -226,7 +228,7 @@ static int knob(const char* name, int dflt) {
 
 static int launch_gather(const int* rowptr, const int* col, const int* perm, const float* val, const float* pre, const float* post,
                          const float* x, float* out, int n, int width, int ld, const int* gptr, int B, int nmax, int visit,
-                         hipStream_t stream) {
+                         hipStream_t stream, const int* gorder = nullptr) {
   static const int k_passes = knob("CGC_SPMM_PASSES", 2), k_chunk = knob("CGC_SPMM_CHUNK", 2048);
   static const int k_nt = knob("CGC_SPMM_NT", 1), k_lds = knob("CGC_SPMM_LDS", 0), k_lpr = knob("CGC_SPMM_LPR", 64);
   const bool vec = (width % 4 == 0) && (ld % 4 == 0) && aligned16(x) && aligned16(out);
@@ -261,7 +263,7 @@ static int launch_gather(const int* rowptr, const int* col, const int* perm, con
     const int nbw = ceil_div(n_chunks * blocks_per_ct * n_ctiles, 8) * 8;
 #define WIDE_LAUNCH(V, P, Q)                                                                                              \
   hipLaunchKernelGGL((k_spmm_wide<GATHER_U, V, P, Q>), dim3(nbw), dim3(CGC_BLOCK), 0, stream, rowptr, col, perm, val, pre, \
-                     post, x, out, n, width, ld, n_ctiles, k_run, blocks_per_ct, n_chunks, gptr, order)
+                     post, x, out, n, width, ld, n_ctiles, k_run, blocks_per_ct, n_chunks, gptr, order, gorder)
     const bool hv = val != nullptr, hp = hv && perm != nullptr, hq = pre != nullptr;
     if (!hv && !hq) WIDE_LAUNCH(false, false, false);
     else if (!hv) WIDE_LAUNCH(false, false, true);
@@ -395,9 +397,21 @@ static int launch_slab(const int* rowptr, const int* col, const int* perm, const
 // Graph-aware entry point: gptr[B+1] = first row of each graph (every row's neighbours lie inside its own graph),
 // nmax = largest graph.  Wide, 16-byte-aligned rows of graphs that fit LDS take the slab kernel; everything else the
 // gather kernel.
+extern "C" int cgc_spmm_graphs_ordered(const int* rowptr, const int* col, const int* perm, const float* val, const float* pre,
+                                       const float* post, const float* x, float* out, int n, int width, int ld, const int* gptr, int B,
+                                       int nmax, int visit, const int* gorder, cgc_stream_t stream);
+
 extern "C" int cgc_spmm_graphs(const int* rowptr, const int* col, const int* perm, const float* val, const float* pre,
                                const float* post, const float* x, float* out, int n, int width, int ld, const int* gptr, int B,
                                int nmax, int visit, cgc_stream_t stream) {
+  return cgc_spmm_graphs_ordered(rowptr, col, perm, val, pre, post, x, out, n, width, ld, gptr, B, nmax, visit, nullptr, stream);
+}
+
+// gorder (optional, B ints, a permutation of the graphs): the sequence in which the graphs are visited; the eight XCDs take
+// consecutive eighths of it.  Scheduling only -- the result does not depend on it.
+extern "C" int cgc_spmm_graphs_ordered(const int* rowptr, const int* col, const int* perm, const float* val, const float* pre,
+                                       const float* post, const float* x, float* out, int n, int width, int ld, const int* gptr, int B,
+                                       int nmax, int visit, const int* gorder, cgc_stream_t stream) {
   if (n <= 0 || width <= 0) return 0;
   if (ld < width) return CGC_EINVAL;
   static const int k_slab = knob("CGC_SPMM_SLAB", 0);
@@ -411,5 +425,5 @@ extern "C" int cgc_spmm_graphs(const int* rowptr, const int* col, const int* per
     if ((size_t)nmax * 4 * 4 <= budget) return k_thr >= 1024 ? launch_slab<4, 1024>(SLAB_ARGS) : launch_slab<4, 512>(SLAB_ARGS);
 #undef SLAB_ARGS
   }
-  return launch_gather(rowptr, col, perm, val, pre, post, x, out, n, width, ld, gptr, B, nmax, visit, as_stream(stream));
+  return launch_gather(rowptr, col, perm, val, pre, post, x, out, n, width, ld, gptr, B, nmax, visit, as_stream(stream), gorder);
 }

@@ -31,6 +31,17 @@ class BatchGraph(object):
         assert ptr[-1] == self.n, 'batch vector and x disagree on the node count'
         self.gptr_host = ptr
         self.gptr = torch.tensor(ptr, dtype=torch.int32, device=device)
+        # visiting sequence for the wide aggregation when the graphs are LARGE (thousands of nodes: the tensors no longer fit the
+        # Infinity Cache, so the recency hints are worthless, and four graphs of unequal size per XCD leave up to 20 % imbalance):
+        # graphs sorted by size and dealt to the 8 XCDs in serpentine order, each XCD's graphs listed consecutively
+        self.gorder = None
+        if self.B >= 8 and self.B % 8 == 0 and self.nmax >= 4000:
+            by_size = sorted(range(self.B), key=lambda b: -self.counts[b])
+            lanes = [[] for _ in range(8)]
+            for q, b in enumerate(by_size):
+                r, x = divmod(q, 8)
+                lanes[x if r % 2 == 0 else 7 - x].append(b)
+            self.gorder = torch.tensor([b for lane in lanes for b in lane], dtype=torch.int32, device=device)
         self.val = None
         self.t_val = None
         self.renorm_p = None

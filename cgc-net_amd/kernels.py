@@ -69,13 +69,14 @@ class KernelSpec(object):
         """out[i] = 1 / max(sum_k val[k] (or the entry count when val is None), 1)  -- DenseSAGEConv's clamp."""
         raise NotImplementedError
 
-    def spmm(self, rowptr, col, perm, val, pre, post, x, out, n, width, gptr=None, num_graphs=0, nmax=0, visit=0, ld=None):
+    def spmm(self, rowptr, col, perm, val, pre, post, x, out, n, width, gptr=None, num_graphs=0, nmax=0, visit=0, ld=None, gorder=None):
         """out[i,:] = post[i] * sum_{k in row i} w_k * pre[col[k]] * x[col[k],:]
         with w_k = val[perm[k]] / val[k] / 1 and pre/post optional.  x, out: [n, width] contiguous.
         gptr/num_graphs/nmax (optional): the rows are a batch of graphs with block-diagonal adjacency
         (first row of each graph, count, largest graph) -- a layout hint, the result is the same.
         visit (optional, scheduling hint): 1 = x was just written in ascending row order, 2 = by a ragged batched gemm.
-        ld (optional): row stride of x and out when the rows are padded (wide rows only; needs gptr)."""
+        ld (optional): row stride of x and out when the rows are padded (wide rows only; needs gptr).
+        gorder (optional, scheduling only): int32 [num_graphs] visiting sequence of the graphs (wide rows)."""
         raise NotImplementedError
 
     # ------------------------------------------------------------------ dense contractions (MFMA fp32)
@@ -406,14 +407,14 @@ class HipKernels(KernelSpec):
         self._dev(rowptr, val, out)
         self._chk(self.lib.cgc_csr_invdeg(_ptr(rowptr), _ptr(val), n, _ptr(out), self._stream()), 'cgc_csr_invdeg')
 
-    def spmm(self, rowptr, col, perm, val, pre, post, x, out, n, width, gptr=None, num_graphs=0, nmax=0, visit=0, ld=None):
+    def spmm(self, rowptr, col, perm, val, pre, post, x, out, n, width, gptr=None, num_graphs=0, nmax=0, visit=0, ld=None, gorder=None):
         self._dev(rowptr, col, perm, val, pre, post, x, out, gptr)
         assert (x.is_contiguous() and out.is_contiguous()) if ld is None else (gptr is not None and x.stride(1) == 1 and out.stride(1) == 1)
         t0 = self.timer.begin() if (self.timer is not None and width > 64) else None
         if gptr is not None:
-            self._chk(self.lib.cgc_spmm_graphs(_ptr(rowptr), _ptr(col), _ptr(perm), _ptr(val), _ptr(pre), _ptr(post),
-                                               _ptr(x), _ptr(out), n, width, width if ld is None else ld, _ptr(gptr),
-                                               num_graphs, nmax, int(visit), self._stream()), 'cgc_spmm_graphs')
+            self._chk(self.lib.cgc_spmm_graphs_ordered(_ptr(rowptr), _ptr(col), _ptr(perm), _ptr(val), _ptr(pre), _ptr(post),
+                                                       _ptr(x), _ptr(out), n, width, width if ld is None else ld, _ptr(gptr),
+                                                       num_graphs, nmax, int(visit), _ptr(gorder), self._stream()), 'cgc_spmm_graphs')
         else:
             self._chk(self.lib.cgc_spmm(_ptr(rowptr), _ptr(col), _ptr(perm), _ptr(val), _ptr(pre), _ptr(post),
                                         _ptr(x), _ptr(out), n, width, self._stream()), 'cgc_spmm')

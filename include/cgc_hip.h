@@ -109,6 +109,13 @@ int cgc_spmm_graphs(const int* rowptr, const int* col, const int* perm, const fl
                     (>= width): wide rows are kept at a multiple of 32 floats so that a 128-byte line never holds parts
                     of two rows; ld != width needs width > 128 */, const int* gptr, int B, int nmax, int visit,
                     cgc_stream_t stream);
+/* The same with a caller-supplied visiting sequence: gorder[B] (NULL = as above) lists the graphs in the order in which they are
+ * swept, the eight XCDs taking consecutive eighths.  For a few LARGE graphs of unequal size (the stress configuration: 32 graphs of
+ * 6400..9600 nodes, 4 per XCD) the host deals the graphs to the XCDs by size (graph.BatchGraph.gorder) so that every XCD gets
+ * the same number of rows.  The result does not depend on the sequence. */
+int cgc_spmm_graphs_ordered(const int* rowptr, const int* col, const int* perm, const float* val, const float* pre,
+                            const float* post, const float* x, float* out, int n, int width, int ld, const int* gptr, int B,
+                            int nmax, int visit, const int* gorder, cgc_stream_t stream);
 
 /* ---- A4/A5/A8: dense contractions on fp32 MFMA (v_mfma_f32_32x32x2_f32).  Replaces torch.matmul / nn.Linear at
  * model/network.py:122 (assignment Linear), :206-207 (S^T X, S^T A S), and the level-2/3 adj@x.

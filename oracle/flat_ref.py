@@ -156,7 +156,7 @@ class TorchKernels(KernelSpec):
         s = torch.zeros(n, device=rowptr.device).index_add_(0, rows, v)
         out.copy_(1.0 / s.clamp(min=1))
 
-    def spmm(self, rowptr, col, perm, val, pre, post, x, out, n, width, gptr=None, num_graphs=0, nmax=0, visit=0, ld=None):
+    def spmm(self, rowptr, col, perm, val, pre, post, x, out, n, width, gptr=None, num_graphs=0, nmax=0, visit=0, ld=None, gorder=None):
         rows, nnz = self._rows(rowptr, n)
         c = col[:nnz].long()
         w = torch.ones(nnz, device=x.device)

@@ -169,6 +169,29 @@ def test_spmm_forward_and_transpose(width, weighted):
     close(got4, want2, what='spmm graphs transpose')
 
 
+@pytest.mark.parametrize('visit', [0, 1, 2])
+def test_wide_spmm_visiting_sequences(visit):
+    """Order hints and a caller-supplied visiting sequence (cgc_spmm_graphs_ordered) are scheduling only: the same bits."""
+    from cgc_net_amd.graph import BatchGraph
+    rng = np.random.RandomState(visit)
+    counts = [int(c) for c in rng.randint(20, 140, size=16)]
+    s, sg, n = _graph(counts, True, seed=7)
+    gptr = g(torch.tensor(np.cumsum([0] + counts), dtype=torch.int32))
+    x, W = rnd(n, 320, seed=1), 300
+    xg = g(x)[:, :W]
+    want = torch.zeros(n, W)
+    REF.spmm(s['rowptr'], s['col'], None, None, None, None, x[:, :W].contiguous(), want, n, W)
+    outs = []
+    for gorder in (None, torch.tensor(rng.permutation(16), dtype=torch.int32, device=DEV)):
+        out = torch.zeros(n, 320, device=DEV)[:, :W]
+        hip().spmm(sg['rowptr'], sg['col'], None, None, None, None, xg, out, n, W, gptr, 16, max(counts), visit, 320, gorder)
+        close(out, want, what='wide spmm visit %d' % visit)
+        outs.append(out.clone())
+    assert torch.equal(outs[0], outs[1])
+    big = BatchGraph(sum([5000, 4100, 6000, 4500, 4800, 5200, 4000, 5900]), [5000, 4100, 6000, 4500, 4800, 5200, 4000, 5900], DEV)
+    assert sorted(big.gorder.tolist()) == list(range(8)) and BatchGraph(n, counts, DEV).gorder is None
+
+
 GEMM_CASES = [
     # (M, N, K, tA, tB)
     (300, 200, 150, False, False), (129, 257, 33, False, True), (260, 140, 1000, True, False),
