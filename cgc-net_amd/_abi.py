@@ -37,6 +37,7 @@ PROTOTYPES = {
     'cgc_softmax_bwd': [P, P, I, I, I, P, P, P, P],
     'cgc_segment_max_fwd': [P, P, I, I, I, P, P, P],
     'cgc_segment_max_bwd': [P, P, I, I, P, P],
+    'cgc_segment_max_bwd_full': [P, P, P, I, I, I, P, P],
     'cgc_jk_supported': [I],
     'cgc_jk_lstm_fwd': [P, I, I, I, P, P, P, P, P, P, P],
     'cgc_jk_lstm_bwd': [P, P, I, I, I, P, P, P, P, P, P, P, P, P, P],

@@ -785,6 +785,28 @@ extern "C" int cgc_segment_max_fwd(const float* x, const int* gptr, int B, int D
   return 0;
 }
 
+// the same scatter writing EVERY element of dx (zeros included): one kernel instead of a fill + a scatter
+__global__ void k_segment_max_bwd_full(const float* __restrict__ dout, const int* __restrict__ arg, const int* __restrict__ gptr, int D,
+                                       float* __restrict__ dx) {
+  const int b = blockIdx.y;
+  const int g0 = gptr[b], cnt = (gptr[b + 1] - g0) * D;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += gridDim.x * blockDim.x) {
+    const int r = i / D, d = i - r * D;
+    dx[(size_t)g0 * D + i] = (arg[b * D + d] == g0 + r) ? dout[b * D + d] : 0.f;
+  }
+}
+
+extern "C" int cgc_segment_max_bwd_full(const float* dout, const int* arg, const int* gptr, int B, int D, int nmax, float* dx,
+                                        cgc_stream_t stream) {
+  if (B <= 0 || D <= 0 || nmax <= 0) return 0;
+  if (B > 65535) return CGC_EINVAL;
+  int bx = ceil_div(nmax * D, 256 * 4);
+  if (bx < 1) bx = 1;
+  hipLaunchKernelGGL(k_segment_max_bwd_full, dim3(bx, B), dim3(256), 0, as_stream(stream), dout, arg, gptr, D, dx);
+  CGC_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}
+
 extern "C" int cgc_segment_max_bwd(const float* dout, const int* arg, int B, int D, float* dx_zeroed, cgc_stream_t stream) {
   if (B <= 0 || D <= 0) return 0;
   const int total = B * D;

@@ -165,6 +165,10 @@ class KernelSpec(object):
         """dx[arg[b,d], d] = dout[b,d] where arg >= 0 (dx arrives zero-filled)."""
         raise NotImplementedError
 
+    def segment_max_bwd_full(self, dout, arg, gptr, B, D, nmax, dx_out):
+        """segment_max_bwd that writes every element of dx (no pre-zeroed buffer needed)."""
+        raise NotImplementedError
+
     # ------------------------------------------------------------------ jumping-knowledge attention (A7)
     def jk_supported(self, C):
         """Whether the fused DenseJK kernels exist for this channel count."""
@@ -563,6 +567,11 @@ class HipKernels(KernelSpec):
         self._dev(dout, arg, dx_zeroed)
         self._chk(self.lib.cgc_segment_max_bwd(_ptr(dout), _ptr(arg), B, D, _ptr(dx_zeroed), self._stream()),
                   'cgc_segment_max_bwd')
+
+    def segment_max_bwd_full(self, dout, arg, gptr, B, D, nmax, dx_out):
+        self._dev(dout, arg, gptr, dx_out)
+        self._chk(self.lib.cgc_segment_max_bwd_full(_ptr(dout), _ptr(arg), _ptr(gptr), B, D, nmax, _ptr(dx_out), self._stream()),
+                  'cgc_segment_max_bwd_full')
 
     # -- jumping knowledge
     def jk_supported(self, C):

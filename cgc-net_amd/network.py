@@ -265,6 +265,7 @@ def run_blocks_paired(emb, pool, x, aggregate, count, agg0):
     level 2 that pass reads the dense 166 MB adjacency, at level 1 it is one gather instead of two.  Returns the blocks' layer
     outputs (lists of three)."""
     he = hp = x
+    pair = None
     outs_e, outs_p = [], []
     for k in (1, 2, 3):
         ce, cp = getattr(emb, 'gcn%d' % k), getattr(pool, 'gcn%d' % k)
@@ -274,10 +275,16 @@ def run_blocks_paired(emb, pool, x, aggregate, count, agg0):
             ae = ap = agg0
         else:
             we = he.shape[1]
-            agg = aggregate(torch.cat([he, hp], dim=-1))
-            ae, ap = agg[:, :we], agg[:, we:]
-        he = ops.sage_project(ae, ce.weight, ce.bias, be, count, emb.activation, ce.normalize, emb.training)
-        hp = ops.sage_project(ap, cp.weight, cp.bias, bp, count, pool.activation, cp.normalize, pool.training)
+            agg = aggregate(ops.join_cols(he, hp, pair) if pair is not None else torch.cat([he, hp], dim=-1))
+            ae, ap = ops.split_cols(agg, we)
+        pair = None
+        if k < 3 and ce.out_channels + cp.out_channels <= 256:
+            # layers whose outputs are aggregated together next: both blocks write into ONE [rows, we + wp] buffer
+            pair = torch.empty(x.shape[0], ce.out_channels + cp.out_channels, dtype=torch.float32, device=x.device)
+        he = ops.sage_project(ae, ce.weight, ce.bias, be, count, emb.activation, ce.normalize, emb.training,
+                              out=None if pair is None else (pair, 0))
+        hp = ops.sage_project(ap, cp.weight, cp.bias, bp, count, pool.activation, cp.normalize, pool.training,
+                              out=None if pair is None else (pair, ce.out_channels))
         outs_e.append(he)
         outs_p.append(hp)
     return outs_e, outs_p

@@ -36,6 +36,13 @@ def _wide(n, F, device):
     return torch.empty(n, ld, dtype=torch.float32, device=device)[:, :F]
 
 
+def _window(buf, off, width):
+    """Columns [off, off + width) of the 2-D buffer as an INDEPENDENT tensor on the same storage (not an autograd view of
+    ``buf``): several custom Functions may each return a window of one buffer without tripping the view + in-place checks."""
+    return torch.empty(0, dtype=buf.dtype, device=buf.device).set_(
+        buf.untyped_storage(), buf.storage_offset() + off, (buf.shape[0], width), (buf.stride(0), 1))
+
+
 def _rows_ld(t):
     """(tensor, ld) for a 2-D fp32 tensor whose rows are contiguous (e.g. a column slice of a wider one)."""
     if t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= t.shape[1] and t.dtype == torch.float32:
@@ -124,6 +131,33 @@ class _Aggregate(Function):
 def aggregate(x, g, mean=True):
     """(A x) / clamp(rowsum A, 1)  (mean=True, DenseSAGEConv) or plain A x (mean=False: A S of _diff_pool, GIN)."""
     return _Aggregate.apply(x, g, mean)
+
+
+class _SplitCols(Function):
+    """(x[:, :w], x[:, w:]) as column windows of x.  Plain slicing would do the same forward; its autograd backward, however,
+    builds each window's gradient as zeros + copy into a full-size tensor and then adds the two (5 kernels); here the two
+    gradients are joined by one concatenation."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.w, ctx.shape = w, x.shape
+        return x[:, :w], x[:, w:]
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        n, tot = ctx.shape
+        if ga is None and gb is None:
+            return None, None
+        ref = ga if ga is not None else gb
+        if ga is None:
+            ga = ref.new_zeros(n, ctx.w)
+        if gb is None:
+            gb = ref.new_zeros(n, tot - ctx.w)
+        return torch.cat([ga, gb], dim=1), None
+
+
+def split_cols(x, w):
+    return _SplitCols.apply(x, w)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -348,7 +382,7 @@ class _SageProject(Function):
 
     @staticmethod
     def forward(ctx, agg, weight, bias, gamma, beta, running_mean, running_var, count, act, normalize, bn_mode, eps, momentum,
-                nbt=None):
+                nbt=None, out=None):
         (agg, lda), weight = _rows_ld(agg), _f32c(weight)      # agg may be a column slice of a paired aggregation
         n, fin = agg.shape
         F = weight.shape[1]
@@ -373,7 +407,10 @@ class _SageProject(Function):
                 K().l2norm_act_stats(h, n, F, normalize, act, h, rinv, None)
         if bn_mode == 1:
             mean, istd = running_mean, torch.rsqrt(running_var + eps)
-        y = _wide(n, F, dev)                              # the 1140-wide layer output is the A operand of the assignment Linear
+        if out is not None:                               # (buffer, column offset): the result lands in a window of a shared buffer
+            y = _window(out[0], out[1], F)                # (the two blocks of a level write side by side: no concatenation later)
+        else:
+            y = _wide(n, F, dev)                          # the 1140-wide layer output is the A operand of the assignment Linear
         K().bn_act_apply(h, n, F, act, mean, istd, gamma, beta, y, y.stride(0))
         ctx.save_for_backward(agg, weight, h, rinv, mean, istd, gamma)
         ctx.cfg = (act, normalize, bn_mode, float(count), bias is not None, lda)
@@ -402,22 +439,43 @@ class _SageProject(Function):
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(weight)
             gemm_tn_rows(agg, lda, fin, dh, F, F, n, dw)
-        return dagg, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None
+        return dagg, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
 
 
-def sage_project(agg, weight, bias, bn, count, act='relu', normalize=True, training=True):
-    """One node for ``l2_act_bn(linear_bias(agg, weight, bias), bn, ...)`` (weight in PyG layout [in, out])."""
+def sage_project(agg, weight, bias, bn, count, act='relu', normalize=True, training=True, out=None):
+    """One node for ``l2_act_bn(linear_bias(agg, weight, bias), bn, ...)`` (weight in PyG layout [in, out]).
+    ``out = (buffer [rows, >= off + F], off)``: write the result into that column window instead of a fresh tensor."""
     code = ACT_CODES[act]
     if bn is None:
-        return _SageProject.apply(agg, weight, bias, None, None, None, None, count, code, normalize, 0, 0.0, 0.0)
+        return _SageProject.apply(agg, weight, bias, None, None, None, None, count, code, normalize, 0, 0.0, 0.0, None, out)
     use_batch = training or bn.running_mean is None
     momentum, nbt = _bn_momentum(bn, use_batch and training)
     rm, rv = (bn.running_mean, bn.running_var) if (training and bn.track_running_stats) else (None, None)
     if use_batch:
         return _SageProject.apply(agg, weight, bias, bn.weight, bn.bias, rm, rv, count, code, normalize, 2, bn.eps, momentum,
-                                  nbt)
+                                  nbt, out)
     return _SageProject.apply(agg, weight, bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, count, code,
-                              normalize, 1, bn.eps, 0.0)
+                              normalize, 1, bn.eps, 0.0, None, out)
+
+
+class _JoinCols(Function):
+    """The [rows, wa + wb] buffer whose two column windows ARE a and b (both were written there by sage_project(out=...)): the
+    concatenation without a copy.  Backward hands each producer its window of the gradient."""
+
+    @staticmethod
+    def forward(ctx, a, b, holder):
+        buf = holder[0]
+        assert a.data_ptr() == buf.data_ptr() and b.data_ptr() == buf[:, a.shape[1]:].data_ptr() and a.stride(0) == buf.stride(0)
+        ctx.wa = a.shape[1]
+        return _window(buf, 0, buf.shape[1])
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[:, :ctx.wa], g[:, ctx.wa:], None
+
+
+def join_cols(a, b, buf):
+    return _JoinCols.apply(a, b, (buf,))
 
 
 # ----------------------------------------------------------------------------------------------
@@ -453,16 +511,16 @@ class _SegmentMax(Function):
         out = torch.empty(B, D, dtype=torch.float32, device=x.device)
         arg = torch.empty(B, D, dtype=torch.int32, device=x.device)
         K().segment_max_fwd(x, gptr, B, D, nmax, out, arg)
-        ctx.save_for_backward(arg)
-        ctx.n = x.shape[0]
+        ctx.save_for_backward(arg, gptr)
+        ctx.n, ctx.nmax = x.shape[0], nmax
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        arg, = ctx.saved_tensors
+        arg, gptr = ctx.saved_tensors
         B, D = arg.shape
-        dx = torch.zeros(ctx.n, D, dtype=torch.float32, device=dout.device)
-        K().segment_max_bwd(_f32c(dout), arg, B, D, dx)
+        dx = torch.empty(ctx.n, D, dtype=torch.float32, device=dout.device)
+        K().segment_max_bwd_full(_f32c(dout), arg, gptr, B, D, ctx.nmax, dx)       # writes every element: no zero fill
         return dx, None, None, None
 
 

@@ -179,6 +179,10 @@ int cgc_softmax_bwd(const float* S, const float* dS, int n, int C, int ld /*row 
                     float* dx_colsum /*[C] or NULL: fused column sums of dx*/, float* ws, cgc_stream_t stream);
 int cgc_segment_max_fwd(const float* x, const int* gptr, int B, int D, int nmax, float* out, int* arg, cgc_stream_t stream);
 int cgc_segment_max_bwd(const float* dout, const int* arg, int B, int D, float* dx_zeroed, cgc_stream_t stream);
+/* The same gradient written in full: dx [n,D] need not be zeroed -- every element of every graph's rows is written (dout where
+ * the row is the argmax, 0 elsewhere); rows outside [gptr[0], gptr[B]) are not touched.  nmax = largest graph (grid sizing). */
+int cgc_segment_max_bwd_full(const float* dout, const int* arg, const int* gptr, int B, int D, int nmax, float* dx,
+                             cgc_stream_t stream);
 
 /* ---- A7: DenseJK (model/network.py:11-55): bi-LSTM(C -> H = 3C/2) over a node's 3 layer embeddings + Linear(2H -> 1)
  * attention + softmax-weighted sum, one thread per node.  xs [n, 3C], out [n, C].  lstm = HOST array of 8 device pointers

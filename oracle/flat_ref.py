@@ -460,3 +460,8 @@ class TorchKernels(KernelSpec):
         else:
             self.l2norm_act_stats(h, n, F, normalize, act, hn_out, rinv_out, None)
         return True
+
+    def segment_max_bwd_full(self, dout, arg, gptr, B, D, nmax, dx_out):
+        gp = gptr.long()
+        dx_out[int(gp[0]):int(gp[B])] = 0
+        self.segment_max_bwd(dout, arg, B, D, dx_out)

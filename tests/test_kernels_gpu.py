@@ -480,6 +480,9 @@ def test_segment_max(D):
         REF.segment_max_bwd(dout, warg, B_, D, wdx)
         hip().segment_max_bwd(g(dout), garg, B_, D, gdx)
         assert torch.equal(gdx.cpu(), wdx)
+        full = torch.full((n, D), float('nan'), device=DEV)          # the variant that needs no zero-filled buffer
+        hip().segment_max_bwd_full(g(dout), garg, g(gptr), B_, D, nmax, full)
+        assert torch.equal(full.cpu(), wdx)
 
 
 @pytest.mark.parametrize('B_,C', [(3, 4), (2, 16), (3, 60), (2, 114), (2, 180), (1, 1140)])
