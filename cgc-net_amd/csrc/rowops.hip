@@ -84,6 +84,12 @@ __global__ __launch_bounds__(256) void k_reduce_slots(const float* __restrict__ 
 }
 #define REDUCE_SLOTS_GRID(width) dim3(ceil_div((width), 32))
 
+int launch_reduce_slots_f32(const float* ws, int slots, int width, float* out, hipStream_t stream) {
+  hipLaunchKernelGGL(k_reduce_slots<float>, REDUCE_SLOTS_GRID(width), dim3(256), 0, stream, ws, slots, width, out);
+  CGC_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}
+
 struct ColCfg {
   int vec, maxj, lpr, blocks;
   bool ok;

@@ -1,0 +1,166 @@
+// Backward of a NARROW SAGE projection (hidden width 20 -> 20) as one kernel:  given d y of  y = BN(act(l2norm(agg W + b)))
+// it forms  d h  (BatchNorm, activation and L2-norm backward, as cgc_bn_act_l2_bwd)  and, without writing it,
+//   d agg [n, fin] = d h W^T,     d W [fin, F] = agg^T d h,     d b [F] = colsum(d h).
+//
+// Reference: the backward of DenseSAGEConv + relu + BatchNorm inside GNN_Module (model/network.py:109-125) for the thirteen
+// narrow layers of a step.  Unfused, each of them cost cgc_bn_act_l2_bwd (writes d h), a column-sum reduction, a skinny GEMM
+// for d agg, and -- the expensive part -- a 20 x 20 weight gradient contracted over 57.7 k rows as a split-K GEMM on 128 x 32
+// tiles (3 % of the tile is output) plus its deterministic combine: 7 launches, ~55 us.  Here: 1 launch + 1 slot reduction.
+//
+// One wave owns 32 rows.  Layout: lane (f = lane & 31, half = lane >> 5) holds column f of the rows 2s + half, s = 0..15 (16
+// registers per operand) -- exactly the B operand of v_mfma_f32_32x32x2_f32 for a contraction over ROWS, so
+//   d W [k][f] += sum_rows agg[row][k] * d h[row][f]   runs on the matrix core with agg loaded in the same row-pair layout (lane = k)
+// and accumulates in 16 registers per wave over all its row tiles; d b is a per-lane sum.  The per-row dot <hn, d hn> of the
+// L2-norm backward is a 5-step shuffle reduction inside each half.  For d agg = d h W^T the tile takes one trip through a
+// wave-private LDS strip (rows become lanes: the A operand), W^T sits in registers as B fragments.  Each workgroup leaves one slot
+// row [d W | d b] (its four waves folded through LDS); cgc's fixed-order slot reduction folds the slots (deterministic).
+#include "common.hpp"
+
+#define L2_EPS 1e-12f
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+#define SN_LDT 33       // LDS row stride of the transposition strip (words): conflict-free column reads
+
+template <int FS>       // FS = ceil(F / 2): MFMA steps of the d agg product
+__global__ __launch_bounds__(256) void k_sage_narrow_bwd(const float* __restrict__ dy, int ldy, const float* __restrict__ hn,
+                                                         const float* __restrict__ rinv, int n, int F, int act, int normalize, int mode,
+                                                         const float* __restrict__ mean, const float* __restrict__ istd,
+                                                         const float* __restrict__ gamma, const float* __restrict__ sums, float inv_count,
+                                                         const float* __restrict__ agg, int lda, int fin, const float* __restrict__ W,
+                                                         float* __restrict__ dagg, float* __restrict__ ws, int tiles) {
+  __shared__ float strip[4][17 * 64];              // per wave: the 32 x 33 transposition strip; at the end the [17][64] exchange buffer
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int f = lane & 31, half = lane >> 5;
+  const bool fok = f < F;
+  // per-column constants of the BatchNorm backward: do = ca*dy - cb - xhat*cc
+  float ca = 1.f, cb = 0.f, cc = 0.f, mu = 0.f, is = 0.f;
+  if (mode != 0 && fok) {
+    ca = gamma[f] * istd[f];
+    if (mode == 2) {
+      cb = ca * sums[f] * inv_count;
+      cc = ca * sums[F + f] * inv_count;
+      mu = mean[f];
+      is = istd[f];
+    }
+  }
+  // B fragments of d agg = d h W^T: lane (k = f index, half) holds W[k][2t + half]
+  float wb[FS];
+#pragma unroll
+  for (int t = 0; t < FS; ++t) {
+    const int ff = 2 * t + half;
+    wb[t] = (dagg != nullptr && f < fin && ff < F) ? W[(size_t)f * F + ff] : 0.f;
+  }
+  floatx16 dw;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dw[r] = 0.f;
+  float db = 0.f;
+  float* __restrict__ st = strip[wave];
+
+  for (int tile = blockIdx.x * 4 + wave; tile < tiles; tile += gridDim.x * 4) {
+    const int row0 = tile * 32;
+    float dh[16], ag[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int row = row0 + 2 * s + half;
+      const bool ok = row < n;
+      const float g = (ok && fok) ? dy[(size_t)row * ldy + f] : 0.f;
+      const float x = (ok && fok) ? hn[(size_t)row * F + f] : 0.f;
+      ag[s] = (ok && f < fin) ? agg[(size_t)row * lda + f] : 0.f;
+      float go = ca * g;
+      if (mode == 2) go = go - cb - (act_fwd(x, act) - mu) * is * cc;
+      go *= act_bwd(x, act);
+      if (!(ok && fok)) go = 0.f;
+      float o = go;
+      if (normalize) {
+        float dot = x * go;
+        for (int sh = 16; sh > 0; sh >>= 1) dot += __shfl_xor(dot, sh);       // over the 32 columns of this row (inside the half)
+        const float r = ok ? rinv[row] : 1.f;
+        const bool clamped = !(r < 1.f / L2_EPS);                              // ||h|| <= eps: F.normalize divided by eps
+        o = clamped ? go * (1.f / L2_EPS) : r * (go - x * dot);
+      }
+      dh[s] = o;
+      db += o;
+    }
+    // d W [k][f] += agg^T d h: contraction over the 32 rows, two per MFMA
+#pragma unroll
+    for (int s = 0; s < 16; ++s) dw = __builtin_amdgcn_mfma_f32_32x32x2f32(ag[s], dh[s], dw, 0, 0, 0);
+    if (dagg != nullptr) {
+      // rows become lanes: park the tile ([row][f], row stride 33 words) and read the A fragments d h[row][2t + half]
+#pragma unroll
+      for (int s = 0; s < 16; ++s) st[(2 * s + half) * SN_LDT + f] = dh[s];
+      __builtin_amdgcn_wave_barrier();
+      floatx16 da;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) da[r] = 0.f;
+#pragma unroll
+      for (int t = 0; t < FS; ++t) da = __builtin_amdgcn_mfma_f32_32x32x2f32(st[f * SN_LDT + 2 * t + half], wb[t], da, 0, 0, 0);
+      __builtin_amdgcn_wave_barrier();
+      // D[row][k]: lane = k, register r = row (r&3) + 8(r>>2) + 4*half
+      if (f < fin) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (row < n) dagg[(size_t)row * fin + f] = da[r];
+        }
+      }
+    }
+  }
+  // the four waves' partial d W / d b are folded through LDS (fixed order); one slot row per workgroup:
+  // [d W (fin x F, row-major) | d b (F)]
+  __syncthreads();                                   // the strips are free now: reuse them as the exchange buffer
+  float* __restrict__ xch = &strip[0][0];            // [wave][17][64]
+  static_assert(32 * SN_LDT <= 17 * 64, "transposition strip exceeds the per-wave LDS");
+#pragma unroll
+  for (int r = 0; r < 16; ++r) xch[(wave * 17 + r) * 64 + lane] = dw[r];
+  xch[(wave * 17 + 16) * 64 + lane] = db;
+  __syncthreads();
+  if (wave == 0) {
+    float* __restrict__ slot = ws + (size_t)blockIdx.x * (fin * F + F);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float v = (xch[(0 * 17 + r) * 64 + lane] + xch[(1 * 17 + r) * 64 + lane]) + (xch[(2 * 17 + r) * 64 + lane] + xch[(3 * 17 + r) * 64 + lane]);
+      const int k = (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (fok && k < fin) slot[k * F + f] = v;
+    }
+    float d = (xch[(0 * 17 + 16) * 64 + lane] + xch[(1 * 17 + 16) * 64 + lane]) + (xch[(2 * 17 + 16) * 64 + lane] + xch[(3 * 17 + 16) * 64 + lane]);
+    d += __shfl_xor(d, 32);
+    if (fok && half == 0) slot[fin * F + f] = d;
+  }
+}
+
+int launch_reduce_slots_f32(const float* ws, int slots, int width, float* out, hipStream_t stream);   // rowops.hip
+
+static int sn_grid(int n) {
+  const int tiles = ceil_div(n, 32);
+  int g = ceil_div(tiles, 4);
+  return g < 1024 ? g : 1024;
+}
+
+extern "C" int64_t cgc_sage_narrow_ws_floats(int n, int fin, int F) { return (int64_t)sn_grid(n > 0 ? n : 1) * (fin * F + F); }
+
+// dy [n,F] (row stride ldy), hn [n,F], rinv [n], BatchNorm vectors and sums [2,F] exactly as cgc_bn_act_l2_bwd (mode 0 / 1 / 2);
+// agg [n,fin] (row stride lda), W [fin,F].  Out: dagg [n,fin] (NULL: not needed), dwdb [fin*F + F] = d W row-major followed by d b.
+// ws: cgc_sage_narrow_ws_floats(n, fin, F) floats.  Envelope fin <= 32, F <= 32; otherwise CGC_EINVAL, nothing launched.
+extern "C" int cgc_sage_narrow_bwd(const float* dy, int ldy, const float* hn, const float* rinv, int n, int F, int act, int normalize,
+                                   int mode, const float* mean, const float* istd, const float* gamma, const float* sums, double count,
+                                   const float* agg, int lda, int fin, const float* W, float* dagg, float* dwdb, float* ws,
+                                   cgc_stream_t stream_) {
+  hipStream_t st = as_stream(stream_);
+  if (F <= 0 || fin <= 0) return 0;
+  if (F > 32 || fin > 32 || ws == nullptr || dwdb == nullptr) return CGC_EINVAL;
+  const int width = fin * F + F;
+  if (n <= 0) {
+    (void)hipMemsetAsync(dwdb, 0, sizeof(float) * width, st);
+    return 0;
+  }
+  const int tiles = ceil_div(n, 32), grid = sn_grid(n);
+  const float inv_count = (float)(1.0 / count);
+  const int fs = (F + 1) / 2;
+#define SN_LAUNCH(FS_)                                                                                                         \
+  hipLaunchKernelGGL(k_sage_narrow_bwd<FS_>, dim3(grid), dim3(256), 0, st, dy, ldy, hn, rinv, n, F, act, normalize, mode, mean, \
+                     istd, gamma, sums, inv_count, agg, lda, fin, W, dagg, ws, tiles)
+  if (fs <= 8) SN_LAUNCH(8); else if (fs <= 10) SN_LAUNCH(10); else SN_LAUNCH(16);
+#undef SN_LAUNCH
+  CGC_RETURN_IF_LAUNCH_FAILED();
+  return launch_reduce_slots_f32(ws, grid, width, dwdb, st);
+}

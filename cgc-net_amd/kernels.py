@@ -147,6 +147,12 @@ class KernelSpec(object):
         """out[f] = sum_i x[i,f]."""
         raise NotImplementedError
 
+    def sage_narrow_bwd(self, dy, ldy, hn, rinv, n, F, act, normalize, mode, mean, istd, gamma, sums, count, agg, lda, fin, weight,
+                        dagg_out, dwdb_out):
+        """bn_act_l2_bwd without writing dh, plus its three consumers: dagg_out [n,fin] = dh @ weight^T (None: skipped) and
+        dwdb_out [fin*F + F] = (agg^T dh).ravel() followed by colsum(dh).  Returns False (nothing done) unless fin, F <= 32."""
+        raise NotImplementedError
+
     # ------------------------------------------------------------------ assignment softmax (A8), readout (A9)
     def softmax_fwd(self, x, n, C, out, ld=None):
         raise NotImplementedError
@@ -540,6 +546,18 @@ class HipKernels(KernelSpec):
                                              _ptr(mean), _ptr(istd), _ptr(gamma), _ptr(sums),
                                              ctypes.c_double(count), _ptr(dh_out), _ptr(dh_colsum_out), _ptr(ws),
                                              self._stream()), 'cgc_bn_act_l2_bwd')
+
+    def sage_narrow_bwd(self, dy, ldy, hn, rinv, n, F, act, normalize, mode, mean, istd, gamma, sums, count, agg, lda, fin, weight,
+                        dagg_out, dwdb_out):
+        if F > 32 or fin > 32:
+            return False
+        self._dev(dy, hn, rinv, mean, istd, gamma, sums, agg, weight, dagg_out, dwdb_out)
+        ws = torch.empty(int(self.lib.cgc_sage_narrow_ws_floats(n, fin, F)), dtype=torch.float32, device=hn.device)
+        self._chk(self.lib.cgc_sage_narrow_bwd(_ptr(dy), ldy, _ptr(hn), _ptr(rinv), n, F, act, int(normalize), mode, _ptr(mean),
+                                               _ptr(istd), _ptr(gamma), _ptr(sums), ctypes.c_double(count), _ptr(agg), lda, fin,
+                                               _ptr(weight), _ptr(dagg_out), _ptr(dwdb_out), _ptr(ws), self._stream()),
+                  'cgc_sage_narrow_bwd')
+        return True
 
     def colsum(self, x, ld, n, F, out):
         self._dev(x, out)

@@ -429,6 +429,16 @@ class _SageProject(Function):
             sums = torch.empty(2, F, dtype=torch.float32, device=dev)
             K().bn_bwd_reduce(dy, ld, hn, n, F, act, mean, istd, sums)
             dbeta, dgamma = sums[0], sums[1]
+        if F <= 32 and fin <= 32 and ctx.needs_input_grad[1]:
+            # narrow layer: BN / activation / L2-norm backward and its three consumers (d agg, d W, d b) in ONE kernel; dh is never
+            # written, the 20 x 20 weight gradient is accumulated on the matrix cores instead of a split-K GEMM over 57.7 k rows
+            dagg = torch.empty(n, fin, dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+            dwdb = torch.empty(fin * F + F, dtype=torch.float32, device=dev)
+            if K().sage_narrow_bwd(dy, ld, hn, rinv, n, F, act, normalize, bn_mode, mean, istd, gamma, sums, count, agg, lda, fin,
+                                   weight, dagg, dwdb):
+                dw = dwdb[:fin * F].view(fin, F)
+                db = dwdb[fin * F:] if has_bias else None
+                return dagg, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
         dh = torch.empty_like(hn)
         db = torch.empty(F, dtype=torch.float32, device=dev) if has_bias else None
         K().bn_act_l2_bwd(dy, ld, hn, rinv, n, F, act, normalize, bn_mode, mean, istd, gamma, sums, count, dh, db)

@@ -224,6 +224,17 @@ int cgc_sage_wide_fwd(const float* agg, int lda, const float* W, const float* bi
                       float* running_mean, float* running_var, int64_t* num_batches_tracked, float* mean, float* istd,
                       cgc_stream_t stream);
 
+/* ---- backward of a NARROW SAGE projection y = BN(act(l2norm(agg W + b))) (the 13 hidden-width layers of a step,
+ * model/network.py:109-125) in one kernel + one slot reduction: dy [n,F] (row stride ldy), hn, rinv, mode / mean / istd / gamma /
+ * sums / count exactly as cgc_bn_act_l2_bwd; agg [n,fin] (row stride lda), W [fin,F].  Out: dagg [n,fin] = dh W^T (NULL: skipped),
+ * dwdb [fin*F + F] = dW (= agg^T dh, row-major [fin,F]) followed by db (= column sums of dh); dh itself is never written.
+ * ws: cgc_sage_narrow_ws_floats(n, fin, F) floats.  Envelope fin <= 32, F <= 32 -- otherwise CGC_EINVAL, nothing launched. */
+int64_t cgc_sage_narrow_ws_floats(int n, int fin, int F);
+int cgc_sage_narrow_bwd(const float* dy, int ldy, const float* hn, const float* rinv, int n, int F, int act, int normalize,
+                        int mode, const float* mean, const float* istd, const float* gamma, const float* sums, double count,
+                        const float* agg, int lda, int fin, const float* W, float* dagg, float* dwdb, float* ws,
+                        cgc_stream_t stream);
+
 /* ---- A4/A6 at levels 2-3 (dense, real-valued adjacency that carries gradient) */
 int cgc_dense_rownorm_fwd(const float* A, int R, int C, float* out, float* invd, float* ge1, cgc_stream_t stream);
 int cgc_dense_rownorm_bwd(const float* dOut, const float* Anorm, const float* invd, const float* ge1, int R, int C,

@@ -465,3 +465,17 @@ class TorchKernels(KernelSpec):
         gp = gptr.long()
         dx_out[int(gp[0]):int(gp[B])] = 0
         self.segment_max_bwd(dout, arg, B, D, dx_out)
+
+    def sage_narrow_bwd(self, dy, ldy, hn, rinv, n, F, act, normalize, mode, mean, istd, gamma, sums, count, agg, lda, fin, weight,
+                        dagg_out, dwdb_out):
+        if F > 32 or fin > 32:
+            return False
+        dh = torch.empty(n, F, dtype=hn.dtype, device=hn.device)
+        db = torch.empty(F, dtype=hn.dtype, device=hn.device)
+        self.bn_act_l2_bwd(dy, ldy, hn, rinv, n, F, act, normalize, mode, mean, istd, gamma, sums, count, dh, db)
+        a = agg[:, :fin]
+        if dagg_out is not None:
+            dagg_out.copy_(dh @ weight.t())
+        dwdb_out[:fin * F].copy_((a.t() @ dh).reshape(-1))
+        dwdb_out[fin * F:].copy_(db)
+        return True

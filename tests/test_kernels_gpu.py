@@ -421,6 +421,52 @@ def test_fused_wide_sage_forward(n, K_, F, lda, stats):
         close(res['hip'][i], res['ref'][i], TOL, 'sage_wide %d' % i)
 
 
+@pytest.mark.parametrize('n,fin,F', [(1, 20, 20), (37, 16, 20), (1000, 20, 20), (4100, 20, 18), (333, 8, 32), (64, 32, 8), (50, 20, 33)])
+@pytest.mark.parametrize('mode,act,normalize', [(2, 1, True), (1, 3, True), (0, 2, False), (2, 2, True)])
+def test_fused_narrow_sage_backward(n, fin, F, mode, act, normalize):
+    """cgc_sage_narrow_bwd (BN / activation / L2 backward + d agg + d W + d b in one kernel, dh never written) against the
+    composition bn_act_l2_bwd -> matmuls of the contract; strided dy / agg windows, a zero row (norm clamp), all BN modes."""
+    k = hip()
+    h = rnd(n, F, seed=n + F)
+    h[min(3, n - 1)] = 0.0
+    big_dy, big_agg = rnd(n, F + 8, seed=1), rnd(n, fin + 5, seed=2)
+    W = rnd(fin, F, seed=3)
+    gamma, count = rnd(F, seed=4).abs() + 0.5, float(n + 9)
+    res = {}
+    for name, K_, dev in (('ref', REF, 'cpu'), ('hip', k, DEV)):
+        t = lambda v: v.to(dev)
+        hn, rinv = torch.empty(n, F, device=dev), torch.empty(n, device=dev)
+        stats = torch.empty(2, F, device=dev, dtype=torch.float64)
+        K_.l2norm_act_stats(t(h), n, F, normalize, act, hn, rinv, stats)
+        mean, istd = torch.empty(F, device=dev), torch.empty(F, device=dev)
+        K_.bn_finalize(stats, count, 1e-5, 0.1, None, None, mean, istd)
+        dy, agg = t(big_dy)[:, 4:4 + F], t(big_agg)[:, 5:5 + fin]
+        sums = torch.zeros(2, F, device=dev)
+        if mode == 2:
+            K_.bn_bwd_reduce(dy, F + 8, hn, n, F, act, mean, istd, sums)
+        dagg, dwdb = torch.full((n, fin), 7.0, device=dev), torch.full((fin * F + F,), 7.0, device=dev)
+        ok = K_.sage_narrow_bwd(dy, F + 8, hn, rinv, n, F, act, normalize, mode, mean if mode else None, istd if mode else None,
+                                t(gamma) if mode else None, sums if mode == 2 else None, count, agg, fin + 5, fin, t(W), dagg, dwdb)
+        ok2 = K_.sage_narrow_bwd(dy, F + 8, hn, rinv, n, F, act, normalize, mode, mean if mode else None, istd if mode else None,
+                                 t(gamma) if mode else None, sums if mode == 2 else None, count, agg, fin + 5, fin, t(W), None,
+                                 torch.empty_like(dwdb))
+        res[name] = (ok and ok2, dagg, dwdb)
+    torch.cuda.synchronize()
+    assert res['hip'][0] == res['ref'][0] == (F <= 32 and fin <= 32)
+    if not res['hip'][0]:
+        assert float(res['hip'][1].min()) == 7.0
+        return
+    mask = torch.ones(n, dtype=torch.bool)
+    if normalize:
+        mask[min(3, n - 1)] = False                 # the clamped zero row carries a 1e12 factor: compared on its own scale
+    close(res['hip'][1].cpu()[mask], res['ref'][1][mask], TOL, 'dagg')
+    close(res['hip'][1].cpu()[~mask], res['ref'][1][~mask], 1e-3, 'dagg (clamped row)')
+    if bool(mask.all()) or not normalize:
+        close(res['hip'][2], res['ref'][2], TOL, 'dW | db')
+    else:
+        close(res['hip'][2], res['ref'][2], 1e-3, 'dW | db (with the clamped row)')
+
+
 def test_epilogue_without_bn_and_without_normalize():
     k = hip()
     n, F = 77, 20
