@@ -32,6 +32,7 @@ PROTOTYPES = {
     'cgc_bn_act_apply': [P, I, I, I, P, P, P, P, P, I, P],
     'cgc_bn_bwd_reduce': [P, I, P, I, I, I, P, P, P, P, P],
     'cgc_bn_act_l2_bwd': [P, I, P, P, I, I, I, I, I, P, P, P, P, D, P, P, P, P],
+    'cgc_sage_narrow_fwd': [P, I, P, P, I, I, I, I, I, P, P, I, P, D, F, F, P, P, P, P, P, P],
     'cgc_sage_narrow_ws_floats': [I, I, I],
     'cgc_sage_narrow_bwd': [P, I, P, P, I, I, I, I, I, P, P, P, P, D, P, I, I, P, P, P, P, P],
     'cgc_colsum': [P, I, I, I, P, P, P],

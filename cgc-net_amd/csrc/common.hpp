@@ -19,13 +19,30 @@ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-// ---- cross-lane reductions over the `lpr` (power of two, <= 64) consecutive lanes that share a row
+// ---- cross-lane reductions over the `lpr` (power of two, 8..64) consecutive lanes that share a row; every lane of the group
+// receives the result.  The steps inside a row of 16 lanes are DPP moves (quad swaps, half mirror, mirror: register to register);
+// only the strides 16 and 32 need a cross-row exchange.  __shfl_xor alone compiles to one ds_bpermute_b32 -- an LDS round trip
+// -- per step, i.e. 6 dependent round trips per row value for 64-lane rows.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float group_sum(float v, int lpr) {
-  for (int o = lpr >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  v += dpp_mov<0xB1>(v);                  // quad_perm [1,0,3,2]   (stride 1)
+  v += dpp_mov<0x4E>(v);                  // quad_perm [2,3,0,1]   (stride 2)
+  if (lpr >= 8) v += dpp_mov<0x141>(v);   // row_half_mirror       (stride 4)
+  if (lpr >= 16) v += dpp_mov<0x140>(v);  // row_mirror            (stride 8)
+  if (lpr >= 32) v += __shfl_xor(v, 16);
+  if (lpr >= 64) v += __shfl_xor(v, 32);
   return v;
 }
 __device__ __forceinline__ float group_max(float v, int lpr) {
-  for (int o = lpr >> 1; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  v = fmaxf(v, dpp_mov<0xB1>(v));
+  v = fmaxf(v, dpp_mov<0x4E>(v));
+  if (lpr >= 8) v = fmaxf(v, dpp_mov<0x141>(v));
+  if (lpr >= 16) v = fmaxf(v, dpp_mov<0x140>(v));
+  if (lpr >= 32) v = fmaxf(v, __shfl_xor(v, 16));
+  if (lpr >= 64) v = fmaxf(v, __shfl_xor(v, 32));
   return v;
 }
 

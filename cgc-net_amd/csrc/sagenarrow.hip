@@ -19,11 +19,26 @@
 #define L2_EPS 1e-12f
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
+// Sum over the 32 lanes of a half (lanes 0-31 / 32-63) delivered to every lane: four DPP steps inside each row of 16 lanes (quad
+// swaps, half mirror, mirror -- register-to-register, no LDS round trip) and one cross-row exchange.  __shfl_xor compiles to
+// ds_bpermute_b32 for every step; with 16 row values per tile that was 80 dependent LDS round trips per wave.
+template <int CTRL>
+__device__ __forceinline__ float dpp_step(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float half_sum(float v) {
+  v = dpp_step<0xB1>(v);      // quad_perm [1,0,3,2]
+  v = dpp_step<0x4E>(v);      // quad_perm [2,3,0,1]
+  v = dpp_step<0x141>(v);     // row_half_mirror
+  v = dpp_step<0x140>(v);     // row_mirror
+  return v + __shfl_xor(v, 16);
+}
+
 #define SN_LDT 33       // LDS row stride of the transposition strip (words): conflict-free column reads
 
-template <int FS>       // FS = ceil(F / 2): MFMA steps of the d agg product
+template <int FS, int ACT>       // FS = ceil(F / 2): MFMA steps of the d agg product; ACT: activation code (compile time: no per-element branch)
 __global__ __launch_bounds__(256) void k_sage_narrow_bwd(const float* __restrict__ dy, int ldy, const float* __restrict__ hn,
-                                                         const float* __restrict__ rinv, int n, int F, int act, int normalize, int mode,
+                                                         const float* __restrict__ rinv, int n, int F, int /*act*/, int normalize, int mode,
                                                          const float* __restrict__ mean, const float* __restrict__ istd,
                                                          const float* __restrict__ gamma, const float* __restrict__ sums, float inv_count,
                                                          const float* __restrict__ agg, int lda, int fin, const float* __restrict__ W,
@@ -67,13 +82,12 @@ __global__ __launch_bounds__(256) void k_sage_narrow_bwd(const float* __restrict
       const float x = (ok && fok) ? hn[(size_t)row * F + f] : 0.f;
       ag[s] = (ok && f < fin) ? agg[(size_t)row * lda + f] : 0.f;
       float go = ca * g;
-      if (mode == 2) go = go - cb - (act_fwd(x, act) - mu) * is * cc;
-      go *= act_bwd(x, act);
+      if (mode == 2) go = go - cb - (act_fwd(x, ACT) - mu) * is * cc;
+      go *= act_bwd(x, ACT);
       if (!(ok && fok)) go = 0.f;
       float o = go;
       if (normalize) {
-        float dot = x * go;
-        for (int sh = 16; sh > 0; sh >>= 1) dot += __shfl_xor(dot, sh);       // over the 32 columns of this row (inside the half)
+        const float dot = half_sum(x * go);                                    // over the 32 columns of this row (inside the half)
         const float r = ok ? rinv[row] : 1.f;
         const bool clamped = !(r < 1.f / L2_EPS);                              // ||h|| <= eps: F.normalize divided by eps
         o = clamped ? go * (1.f / L2_EPS) : r * (go - x * dot);
@@ -156,11 +170,131 @@ extern "C" int cgc_sage_narrow_bwd(const float* dy, int ldy, const float* hn, co
   const int tiles = ceil_div(n, 32), grid = sn_grid(n);
   const float inv_count = (float)(1.0 / count);
   const int fs = (F + 1) / 2;
-#define SN_LAUNCH(FS_)                                                                                                         \
-  hipLaunchKernelGGL(k_sage_narrow_bwd<FS_>, dim3(grid), dim3(256), 0, st, dy, ldy, hn, rinv, n, F, act, normalize, mode, mean, \
+#define SN_LAUNCH(FS_, ACT_)                                                                                                         \
+  hipLaunchKernelGGL((k_sage_narrow_bwd<FS_, ACT_>), dim3(grid), dim3(256), 0, st, dy, ldy, hn, rinv, n, F, act, normalize, mode, mean, \
                      istd, gamma, sums, inv_count, agg, lda, fin, W, dagg, ws, tiles)
-  if (fs <= 8) SN_LAUNCH(8); else if (fs <= 10) SN_LAUNCH(10); else SN_LAUNCH(16);
+#define SN_ACT(FS_)                                                                                        \
+  switch (act) {                                                                                           \
+    case CGC_ACT_RELU: SN_LAUNCH(FS_, CGC_ACT_RELU); break;                                                \
+    case CGC_ACT_ELU: SN_LAUNCH(FS_, CGC_ACT_ELU); break;                                                  \
+    case CGC_ACT_LEAKYRELU: SN_LAUNCH(FS_, CGC_ACT_LEAKYRELU); break;                                      \
+    default: SN_LAUNCH(FS_, CGC_ACT_IDENTITY); break;                                                      \
+  }
+  if (fs <= 8) { SN_ACT(8); } else if (fs <= 10) { SN_ACT(10); } else { SN_ACT(16); }
+#undef SN_ACT
 #undef SN_LAUNCH
   CGC_RETURN_IF_LAUNCH_FAILED();
   return launch_reduce_slots_f32(ws, grid, width, dwdb, st);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Forward of a narrow SAGE projection: hn = l2norm(agg W + b) + the BatchNorm statistics of act(hn), one kernel (was a
+// short-K GEMM + cgc_l2norm_act_stats).  One wave owns 32 rows: the product runs as K/2 MFMAs with the rows as M (agg loaded
+// row-per-lane: the A operand) and lands in the lane = column layout, where the row norm is a 5-step shuffle reduction per
+// register and the column statistics are per-lane sums.  One slot row [2, F] per workgroup (four waves folded through LDS).
+template <int KS, int ACT>
+__global__ __launch_bounds__(256) void k_sage_narrow_fwd(const float* __restrict__ agg, int lda, const float* __restrict__ W,
+                                                         const float* __restrict__ bias, int n, int K, int F, int normalize, int /*act*/,
+                                                         float* __restrict__ hn, float* __restrict__ rinv_out, float* __restrict__ ws,
+                                                         int tiles) {
+  __shared__ float xch[4][2][32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int f = lane & 31, half = lane >> 5;
+  const bool fok = f < F;
+  float bw[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const int k = 2 * s + half;
+    bw[s] = (fok && k < K) ? W[(size_t)k * F + f] : 0.f;
+  }
+  const float bia = (fok && bias != nullptr) ? bias[f] : 0.f;
+  float s1 = 0.f, s2 = 0.f;
+  for (int tile = blockIdx.x * 4 + wave; tile < tiles; tile += gridDim.x * 4) {
+    const int row0 = tile * 32;
+    const float* __restrict__ a = agg + (size_t)min(row0 + f, n - 1) * lda;        // A operand: lane = row
+    float av[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int k = 2 * s + half;
+      av[s] = k < K ? a[k] : 0.f;
+    }
+    floatx16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = bia;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bw[s], acc, 0, 0, 0);
+    // lane = column f, register r = row (r&3) + 8(r>>2) + 4*half
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      float v = fok ? acc[r] : 0.f;
+      float rin = 1.f;
+      if (normalize) {
+        const float q = half_sum(v * v);
+        rin = 1.f / fmaxf(sqrtf(q), L2_EPS);
+        v *= rin;
+      }
+      if (row < n) {
+        if (fok) {
+          const float o = act_fwd(v, ACT);
+          s1 += o;
+          s2 = fmaf(o, o, s2);
+          hn[(size_t)row * F + f] = v;
+        }
+        if (f == 0) rinv_out[row] = rin;
+      }
+    }
+  }
+  if (ws == nullptr) return;
+  s1 += __shfl_xor(s1, 32);
+  s2 += __shfl_xor(s2, 32);
+  if (half == 0) { xch[wave][0][f] = s1; xch[wave][1][f] = s2; }
+  __syncthreads();
+  if (wave == 0 && half == 0 && fok) {
+    float* __restrict__ slot = ws + (size_t)blockIdx.x * 2 * F;
+    slot[f] = (xch[0][0][f] + xch[1][0][f]) + (xch[2][0][f] + xch[3][0][f]);
+    slot[F + f] = (xch[0][1][f] + xch[1][1][f]) + (xch[2][1][f] + xch[3][1][f]);
+  }
+}
+
+extern "C" int cgc_stats_blocks(int n, int F);
+int launch_stats_finalize(const float* ws, int slots, int F, double count, float eps, float momentum, float* running_mean,
+                          float* running_var, float* mean, float* istd, int64_t* nbt, hipStream_t stream);   // rowops.hip
+
+// hn [n,F] (contiguous) = l2norm(agg [n,K] (row stride lda) @ W [K,F] + bias), rinv [n]; stats != 0: mean / istd / running statistics /
+// num_batches_tracked as cgc_l2norm_act_bn (ws: its slot area).  Envelope K <= 32, F <= 32; otherwise CGC_EINVAL, nothing launched.
+extern "C" int cgc_sage_narrow_fwd(const float* agg, int lda, const float* W, const float* bias, int n, int K, int F, int normalize,
+                                   int act, float* hn, float* rinv, int stats, float* ws, double count, float eps, float momentum,
+                                   float* running_mean, float* running_var, int64_t* num_batches_tracked, float* mean, float* istd,
+                                   cgc_stream_t stream_) {
+  hipStream_t st = as_stream(stream_);
+  if (F <= 0) return 0;
+  if (K <= 0 || K > 32 || F > 32) return CGC_EINVAL;
+  if (stats && (ws == nullptr || mean == nullptr || istd == nullptr)) return CGC_EINVAL;
+  int slots = 0;
+  if (n > 0) {
+    const int tiles = ceil_div(n, 32);
+    int grid = ceil_div(tiles, 4);
+    const int cap = cgc_stats_blocks(n, F);
+    if (grid > 1024) grid = 1024;
+    if (stats && grid > cap) grid = cap > 0 ? cap : 1;
+    float* wsp = stats ? ws : nullptr;
+    const int ks = (K + 1) / 2;
+#define SNF_LAUNCH(KS_, ACT_)                                                                                                      \
+  hipLaunchKernelGGL((k_sage_narrow_fwd<KS_, ACT_>), dim3(grid), dim3(256), 0, st, agg, lda, W, bias, n, K, F, normalize, act, hn, rinv, wsp, tiles)
+#define SNF_ACT(KS_)                                                                                       \
+  switch (act) {                                                                                           \
+    case CGC_ACT_RELU: SNF_LAUNCH(KS_, CGC_ACT_RELU); break;                                               \
+    case CGC_ACT_ELU: SNF_LAUNCH(KS_, CGC_ACT_ELU); break;                                                 \
+    case CGC_ACT_LEAKYRELU: SNF_LAUNCH(KS_, CGC_ACT_LEAKYRELU); break;                                     \
+    default: SNF_LAUNCH(KS_, CGC_ACT_IDENTITY); break;                                                     \
+  }
+    if (ks <= 8) { SNF_ACT(8); } else if (ks <= 10) { SNF_ACT(10); } else { SNF_ACT(16); }
+#undef SNF_ACT
+#undef SNF_LAUNCH
+    CGC_RETURN_IF_LAUNCH_FAILED();
+    slots = grid;
+  }
+  if (stats) return launch_stats_finalize(ws, slots, F, count, eps, momentum, running_mean, running_var, mean, istd, num_batches_tracked, st);
+  return 0;
 }

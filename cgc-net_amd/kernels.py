@@ -117,8 +117,8 @@ class KernelSpec(object):
 
     def sage_wide_fwd(self, agg, lda, weight, bias, n, Kin, F, normalize, act, hn_out, rinv_out, stats, count, eps, momentum,
                       running_mean, running_var, num_batches_tracked, mean_out, istd_out):
-        """hn = l2norm(agg[:, :Kin] @ weight + bias) and (stats) the statistics part of l2norm_act_bn, as one kernel for the
-        wide layer of the assignment block.  Returns False (nothing done) when the shape is outside the kernel's envelope."""
+        """hn = l2norm(agg[:, :Kin] @ weight + bias) and (stats) the statistics part of l2norm_act_bn, as one kernel: narrow
+        inputs (Kin <= 32) into narrow (F <= 32) or wide (F <= 1664) outputs.  Returns False (nothing done) outside that envelope."""
         raise NotImplementedError
 
     def bn_finalize(self, stats, count, eps, momentum, running_mean, running_var, mean_out, istd_out):
@@ -495,10 +495,14 @@ class HipKernels(KernelSpec):
         if stats:
             nblk = self.lib.cgc_stats_blocks(n, F)
             ws = torch.empty(max(nblk, 1) * 2 * F + 4 * F + 2, dtype=torch.float32, device=agg.device)
-        rc = self.lib.cgc_sage_wide_fwd(_ptr(agg), lda, _ptr(weight), _ptr(bias), n, Kin, F, int(normalize), act, _ptr(hn_out),
-                                        hn_out.stride(0), _ptr(rinv_out), int(bool(stats)), _ptr(ws), ctypes.c_double(count),
-                                        ctypes.c_float(eps), ctypes.c_float(momentum), _ptr(running_mean), _ptr(running_var),
-                                        _ptr(num_batches_tracked), _ptr(mean_out), _ptr(istd_out), self._stream())
+        tail = (int(bool(stats)), _ptr(ws), ctypes.c_double(count), ctypes.c_float(eps), ctypes.c_float(momentum), _ptr(running_mean),
+                _ptr(running_var), _ptr(num_batches_tracked), _ptr(mean_out), _ptr(istd_out), self._stream())
+        if F <= 32 and hn_out.stride(0) == F:          # narrow output: one wave per 32 rows (csrc/sagenarrow.hip)
+            rc = self.lib.cgc_sage_narrow_fwd(_ptr(agg), lda, _ptr(weight), _ptr(bias), n, Kin, F, int(normalize), act, _ptr(hn_out),
+                                              _ptr(rinv_out), *tail)
+        else:
+            rc = self.lib.cgc_sage_wide_fwd(_ptr(agg), lda, _ptr(weight), _ptr(bias), n, Kin, F, int(normalize), act, _ptr(hn_out),
+                                            hn_out.stride(0), _ptr(rinv_out), *tail)
         if rc == -1:
             return False
         self._chk(rc, 'cgc_sage_wide_fwd')

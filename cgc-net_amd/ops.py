@@ -393,9 +393,10 @@ class _SageProject(Function):
         if bn_mode == 2:
             mean = torch.empty(F, dtype=torch.float32, device=dev)
             istd = torch.empty(F, dtype=torch.float32, device=dev)
-        # wide output from a narrow input (the assignment block's last convolution, [Ntot, 20] -> [Ntot, 1140]): projection,
-        # L2 normalisation and BatchNorm statistics in ONE kernel that writes only hn; everything else: MFMA GEMM + row kernel
-        fused = F >= _WIDE_MIN and fin <= 32 and K().sage_wide_fwd(
+        # narrow input (hidden width): projection, L2 normalisation and BatchNorm statistics in ONE kernel that writes only hn --
+        # for the wide output of the assignment block's last convolution ([Ntot, 20] -> [Ntot, 1140]) and for the narrow layers;
+        # everything else: MFMA GEMM + row kernel
+        fused = (F >= _WIDE_MIN or F <= 32) and fin <= 32 and K().sage_wide_fwd(
             agg, lda, weight, bias, n, fin, F, normalize, act, h, rinv, bn_mode == 2, float(count), eps, momentum,
             running_mean, running_var, nbt, mean, istd)
         if not fused:

@@ -224,6 +224,13 @@ int cgc_sage_wide_fwd(const float* agg, int lda, const float* W, const float* bi
                       float* running_mean, float* running_var, int64_t* num_batches_tracked, float* mean, float* istd,
                       cgc_stream_t stream);
 
+/* ---- forward of a NARROW SAGE projection (hidden width -> hidden width): as cgc_sage_wide_fwd, for F <= 32, K <= 32, hn contiguous:
+ * one kernel instead of a short-K cgc_gemm_f32 + cgc_l2norm_act_stats.  Otherwise CGC_EINVAL, nothing launched. */
+int cgc_sage_narrow_fwd(const float* agg, int lda, const float* W, const float* bias, int n, int K, int F, int normalize, int act,
+                        float* hn, float* rinv, int stats, float* ws, double count, float eps, float momentum,
+                        float* running_mean, float* running_var, int64_t* num_batches_tracked, float* mean, float* istd,
+                        cgc_stream_t stream);
+
 /* ---- backward of a NARROW SAGE projection y = BN(act(l2norm(agg W + b))) (the 13 hidden-width layers of a step,
  * model/network.py:109-125) in one kernel + one slot reduction: dy [n,F] (row stride ldy), hn, rinv, mode / mean / istd / gamma /
  * sums / count exactly as cgc_bn_act_l2_bwd; agg [n,fin] (row stride lda), W [fin,F].  Out: dagg [n,fin] = dh W^T (NULL: skipped),

@@ -392,7 +392,8 @@ def test_fused_statistics_and_finalize(n, F):
 
 
 @pytest.mark.parametrize('n,K_,F,lda', [(1, 20, 256, 20), (37, 20, 1140, 40), (1000, 16, 1600, 16), (4100, 20, 1140, 40), (300, 7, 257, 12),
-                                         (50, 32, 200, 32), (50, 20, 1700, 20), (50, 33, 512, 36)])
+                                         (50, 32, 200, 32), (50, 20, 1700, 20), (50, 33, 512, 36),
+                                         (1000, 20, 20, 40), (37, 16, 20, 16), (5, 32, 32, 32), (4100, 20, 18, 20), (1, 8, 4, 8)])
 @pytest.mark.parametrize('stats', [True, False])
 def test_fused_wide_sage_forward(n, K_, F, lda, stats):
     """cgc_sage_wide_fwd: rank-K projection + bias + L2 normalisation (+ BatchNorm statistics, running stats, batch counter) in one
