@@ -33,7 +33,7 @@ def step():
 for _ in range(3):
     step()
 counts, sites = collections.Counter(), collections.Counter()
-SKIP = ('aten.empty', 'aten.view', 'aten.as_strided', 'aten.slice', 'aten.select', 'aten.detach', 'aten.t.', 'aten.transpose',
+SKIP = ('aten.empty', 'aten.view', 'aten.as_strided', 'aten.slice.', 'aten.select.', 'aten.detach', 'aten.t.', 'aten.transpose',
         'aten.reshape', 'aten._unsafe_view', 'aten.expand', 'aten.unsqueeze', 'aten.squeeze', 'aten.alias', 'aten.permute', 'aten.stride',
         'aten.sym_', 'aten.is_', 'aten.size', 'aten.numel', 'aten.dim', 'aten.unbind', 'aten.split', 'aten._local_scalar')
 
