@@ -234,7 +234,8 @@ _instance = None
 
 
 def lib_path():
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc', _LIB_NAME)
+    # CGC_LIB: another build of the same library (A/B timing of kernel changes on one box); default: the in-tree build
+    return os.environ.get('CGC_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc', _LIB_NAME)
 
 
 def get():
