@@ -24,12 +24,6 @@ _VALIDATE_INPUTS = os.environ.get('CGC_VALIDATE_INPUTS', '0') == '1'     # one d
 RENORM_P = 0.4      # model/network.py:260,271,280
 
 
-def _cpu_seam():
-    """True only when tests have swapped the kernel table for the torch restatement (never in product runs)."""
-    from . import kernels
-    return kernels._instance is not None and not kernels.is_native()
-
-
 def _activation_module(name):
     assert name in ('relu', 'elu', 'leakyrelu')          # model/network.py:84-91
     return {'relu': nn.ReLU, 'elu': nn.ELU, 'leakyrelu': nn.LeakyReLU}[name](inplace=True)
@@ -144,11 +138,10 @@ class DenseJK(nn.Module):
         """[..., layers*channels] -> [..., channels]; works on [B, N, 3C] and on flat [Ntot, 3C] rows alike."""
         lead = xs.shape[:-1]
         layers = xs.shape[-1] // self.channel
-        if not xs.is_cuda and not _cpu_seam():
-            raise RuntimeError('cgc_net_amd.DenseJK takes GPU tensors only (there is no CPU fallback)')
         if layers == 3 and ops.K().jk_supported(self.channel):
             # fused bi-LSTM + attention kernels (one thread per node); nn.LSTM / nn.Linear only hold the parameters
             return ops.dense_jk(xs.reshape(-1, 3 * self.channel), self.lstm, self.att).reshape(*lead, self.channel)
+        getattr(ops.K(), '_dev', lambda *a: None)(xs)    # GPU tensors only here as well (no silent CPU path through torch)
         seq = xs.reshape(-1, layers, self.channel)   # [rows, layers, channels]: other shapes stay on torch.nn.LSTM (MIOpen)
         alpha, _ = self.lstm(seq)
         alpha = torch.softmax(self.att(alpha).squeeze(-1), dim=-1)
