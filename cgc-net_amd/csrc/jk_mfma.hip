@@ -43,8 +43,15 @@ struct JkM {
   static_assert(H <= 32 && C % 4 == 0, "one 32-row tile per gate; 16-byte x fragments");
 };
 
+#ifdef CGC_JK_PRECISE
+__device__ __forceinline__ float fast_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return tanhf(x); }
+#define JK_EXP expf
+#else
 __device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.f + __expf(-x)); }
 __device__ __forceinline__ float fast_tanh(float x) { return 2.f * __frcp_rn(1.f + __expf(-2.f * x)) - 1.f; }
+#define JK_EXP __expf
+#endif
 
 template <int C>
 __device__ __forceinline__ void jkm_fill(const JkWeights& w, float* lds, int nthreads) {
@@ -183,7 +190,7 @@ __global__ __launch_bounds__(256, JKM_WAVES) void k_jk_fwd_mfma(const float* __r
     const float m = fmaxf(sc[0], fmaxf(sc[1], sc[2]));
     float a3[3], den = 0.f;
 #pragma unroll
-    for (int t = 0; t < 3; ++t) { a3[t] = __expf(sc[t] - m); den += a3[t]; }
+    for (int t = 0; t < 3; ++t) { a3[t] = JK_EXP(sc[t] - m); den += a3[t]; }
     const float inv = 1.f / den;
     if (d == 0 && valid) {
 #pragma unroll
@@ -296,7 +303,7 @@ __global__ __launch_bounds__(JKB_THREADS) void k_jk_bwd_mfma(const float* __rest
       const float m = fmaxf(sc[0], fmaxf(sc[1], sc[2]));
       float den = 0.f;
 #pragma unroll
-      for (int t = 0; t < 3; ++t) { a3[t] = __expf(sc[t] - m); den += a3[t]; }
+      for (int t = 0; t < 3; ++t) { a3[t] = JK_EXP(sc[t] - m); den += a3[t]; }
       const float inv = 1.f / den;
       float da[3] = {0.f, 0.f, 0.f}, mean = 0.f;
 #pragma unroll

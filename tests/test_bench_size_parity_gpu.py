@@ -9,6 +9,7 @@
   C1 = 1600) against the dense CPU oracle (oracle/dense_ref.py; model/network.py:245-291, parallel_train.sh:2-3).
 
 Tolerances: outputs 1e-4 (max-norm AND elementwise, tests/util.py), gradients 5e-4."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -17,6 +18,7 @@ import cgc_net_amd  # noqa: F401
 from cgc_net_amd import kernels, network
 from cgc_net_amd.data import Batch, Data, SyntheticCellGraphs, radius_graph, sample_nodes_batch
 from oracle import dense_ref
+import discrete
 from util import elementwise_excess, rel_err
 
 pytestmark = pytest.mark.gpu
@@ -147,13 +149,17 @@ def test_dominant_gemm_weight_gradient_tn_flat_and_split(spy):
     assert spy.records.get('gemm_128x128', 0) >= 1
 
 
-def _compare_model(cpu_batch, maxn, feat, flags, tol_grad=5e-4):
+def _compare_model(cpu_batch, maxn, feat, flags, tol_grad=1e-4):
     """HIP path vs the dense oracle in fp32 AND in fp64.  Outputs: 1e-4 against the fp32 oracle (north star).  Gradients:
-    at these sizes several parameter gradients are sums of ~10^4..10^5 mixed-sign terms that cancel almost completely
-    (e.g. d/dW of an L2-normalised convolution: the loss is invariant to the row scale), and the REFERENCE's own fp32
-    arithmetic is then only good to a few 1e-3 of the fp64 value (measured here, per parameter: ``spread``).  The bar for the
-    HIP path is therefore stated against the fp64 truth: its error must stay within max(5e-4, 2 x the fp32 oracle's own
-    error) -- i.e. 5e-4 wherever the reference itself is that well conditioned, and never worse than twice the reference."""
+    1e-4 of the fp64 gradient's max-norm per parameter -- the north-star tolerance, held against the fp64 truth because at
+    these sizes the REFERENCE's own fp32 arithmetic is only good to a few 1e-3 of it on some parameters (measured here per
+    parameter and printed as ``fp32 oracle``: sums of ~10^4..10^5 mixed-sign terms that cancel almost completely, and
+    discrete decisions that two fp32 evaluations take differently).
+
+    Undecidable discrete decisions (max-readout winners, ReLU signs at |value| < fp32 resolution) are taken out of the
+    yardstick as tests/discrete.py describes: the HIP path's decisions must agree with fp64 wherever fp64 decides, and the
+    fp64 gradient is evaluated with the HIP path's choice at the undecidable points.  Measured with that: <= 4e-5 on every
+    parameter of every configuration below, 9e-6 on the benchmarked batch."""
     import copy
     args = (maxn, feat, 20, 20, True, True, 20, 3, 0.1, [50])
     kw = dict(concat=True, gcn_name='SAGE', load_data_sparse=True, drop_out=0., collect_assign=True)
@@ -170,25 +176,33 @@ def _compare_model(cpu_batch, maxn, feat, flags, tol_grad=5e-4):
     spy = _Spy()
     K.timer = spy
     try:
-        logits, loss = model(cpu_batch.to(DEV))
-        loss.backward()
-        torch.cuda.synchronize()
+        with discrete.record_hip_decisions(model) as dec:
+            logits, loss = model(cpu_batch.to(DEV))
+            loss.backward()
+            torch.cuda.synchronize()
     finally:
         K.timer = None
-    assert kernels.is_native()
+    assert kernels.is_native() and len(dec.winners) == 3
     rl, rloss = ref(cpu_batch)
     rloss.backward()
     adj = dense_ref.to_dense_adj(cpu_batch.edge_index, cpu_batch.batch)
     xd, counts = dense_ref.to_dense_batch(cpu_batch.x, cpu_batch.batch)
-    l64, loss64 = ref64((xd.double(), adj.double(), counts, cpu_batch.y))
+    inp64 = (xd.double(), adj.double(), counts, cpu_batch.y)
+    l64, loss64, pre64, embeds64 = discrete.run_oracle_recording(ref64, inp64)
     assert l64.dtype == torch.float64
-    loss64.backward()
+    g64_natural = {k: p.grad.clone() for k, p in ref64.named_parameters()}
+    routing, masks, winner_flips, relu_flips = discrete.hip_choices(dec, pre64, embeds64, [int(c) for c in counts])
+    if winner_flips or relu_flips:
+        l64r, _ = discrete.run_oracle_routed(ref64, inp64, routing, masks)
+        assert rel_err(l64r, l64) < 1e-6                # undecidable points: the outputs do not notice
+    print('decisions differing from the fp64 evaluation: %d of %d readout winners, %d of %d ReLU signs'
+          % (winner_flips, sum(r.numel() for r in routing), relu_flips, sum(m.numel() for m in masks.values())))
     assert rel_err(logits, rl) < 1e-4 and elementwise_excess(logits, rl, 1e-4) <= 1.0, rel_err(logits, rl)
     assert rel_err(logits, l64) < 1e-4 and rel_err(loss, loss64) < 1e-4
     assert rel_err(loss, rloss) < 1e-4
     for i, (s, rs) in enumerate(zip(model.assign_matrix, ref.assign_matrix)):
         assert rel_err(s, rs) < 1e-4, ('assign', i, rel_err(s, rs))
-    g32, g64 = dict(ref.named_parameters()), dict(ref64.named_parameters())
+    g32, g64 = dict(ref.named_parameters()), dict(ref64.named_parameters())     # g64: with the HIP path's routing
 
     def strict(a, b):
         """max|a-b| / max|b| with NO absolute slack (tests/util.rel_err adds 1e-3 to the denominator, which is most of it
@@ -197,22 +211,26 @@ def _compare_model(cpu_batch, maxn, feat, flags, tol_grad=5e-4):
         element by element above."""
         a, b = a.detach().double().cpu(), b.detach().double().cpu()
         return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
-    report = []
+    report, failures = [], []
     for k, p in model.named_parameters():
-        if float(g64[k].grad.abs().max()) < 1e-12:              # mathematically zero (softmax-invariant attention bias): absolute
+        if float(g64_natural[k].abs().max()) < 1e-12:           # mathematically zero (softmax-invariant attention bias): absolute
             assert float(p.grad.abs().max()) < 1e-7, k
             continue
-        spread = strict(g32[k].grad, g64[k].grad)               # the reference's own fp32 rounding on this parameter
+        spread = strict(g32[k].grad, g64_natural[k])            # the reference's own fp32 rounding on this parameter
         e = strict(p.grad, g64[k].grad)
-        tol = max(tol_grad, 2.0 * spread)
         report.append((e, spread, k))
-        assert e < tol, (k, e, spread)
+        if not e < tol_grad:
+            failures.append((k, e, spread))
     rbuf = dict(ref.named_buffers())
     for k, a in model.named_buffers():
         if a.dtype.is_floating_point:
             assert rel_err(a, rbuf[k]) < 1e-4, k
     report.sort(reverse=True)
     print('worst gradient errors vs fp64 (hip, fp32 oracle):', [(k, '%.1e' % e, '%.1e' % sp) for e, sp, k in report[:4]])
+    if os.environ.get('CGC_PARITY_REPORT'):
+        for e, sp, k in report:
+            print('  %-40s hip %.2e   fp32 oracle %.2e' % (k, e, sp))
+    assert not failures, failures
     return spy.records, report[0]
 
 
@@ -246,3 +264,36 @@ def test_full_model_c5_shapes_fuse_sampled_vs_oracle():
     cpu_batch = Batch.from_data_list(items)
     records, worst = _compare_model(cpu_batch, 16000, 64, dict(norm_adj=True, jk=True))
     assert records.get('gemm_128x128', 0) >= 6 and records.get('spmm_wide', 0) == 2, records
+
+
+def test_full_model_exact_bench_batch_vs_oracle():
+    """THE benchmarked batch itself: 32 graphs (bench.py's seed 0 pool, batch 0), shipped flags, max_num_nodes = 11404 --
+    forward + backward against the dense oracle in fp32 and fp64 (the oracle needs ~20 s of host time for it)."""
+    ds = SyntheticCellGraphs(32, 1800, 16, base_seed=0)
+    cpu_batch = Batch.from_data_list([ds[i] for i in range(32)])
+    records, worst = _compare_model(cpu_batch, 11404, 16, dict(norm_adj=True, jk=True))
+    assert records.get('gemm_128x128', 0) >= 6 and records.get('spmm_wide', 0) == 2, records
+
+
+def test_training_step_is_deterministic():
+    """Every reduction in the path has a fixed order (slot reductions, split-K combines, in-kernel accumulations): the same
+    step from the same state gives BITWISE the same loss and gradients, run after run."""
+    ds = SyntheticCellGraphs(8, 1800, 16, base_seed=3)
+    batch = Batch.from_data_list([ds[i] for i in range(8)]).to(DEV)
+    torch.manual_seed(1)
+    model = network.SoftPoolingGcnEncoder(11404, 16, 20, 20, True, True, 20, 3, 0.1, [50], concat=True, load_data_sparse=True,
+                                          norm_adj=True, jk=True, drop_out=0.).to(DEV)
+    model.train()
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    runs = []
+    for _ in range(3):
+        model.load_state_dict(state)
+        model.zero_grad()
+        logits, loss = model(batch)
+        loss.backward()
+        torch.cuda.synchronize()
+        runs.append((logits.detach().clone(), loss.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters()}))
+    for other in runs[1:]:
+        assert torch.equal(runs[0][0], other[0]) and torch.equal(runs[0][1], other[1])
+        for k in runs[0][2]:
+            assert torch.equal(runs[0][2][k], other[2][k]), k
