@@ -9,7 +9,6 @@
   C1 = 1600) against the dense CPU oracle (oracle/dense_ref.py; model/network.py:245-291, parallel_train.sh:2-3).
 
 Tolerances: outputs 1e-4 (max-norm AND elementwise, tests/util.py), gradients 5e-4."""
-import os
 import numpy as np
 import pytest
 import torch
@@ -149,89 +148,11 @@ def test_dominant_gemm_weight_gradient_tn_flat_and_split(spy):
     assert spy.records.get('gemm_128x128', 0) >= 1
 
 
-def _compare_model(cpu_batch, maxn, feat, flags, tol_grad=1e-4):
-    """HIP path vs the dense oracle in fp32 AND in fp64.  Outputs: 1e-4 against the fp32 oracle (north star).  Gradients:
-    1e-4 of the fp64 gradient's max-norm per parameter -- the north-star tolerance, held against the fp64 truth because at
-    these sizes the REFERENCE's own fp32 arithmetic is only good to a few 1e-3 of it on some parameters (measured here per
-    parameter and printed as ``fp32 oracle``: sums of ~10^4..10^5 mixed-sign terms that cancel almost completely, and
-    discrete decisions that two fp32 evaluations take differently).
-
-    Undecidable discrete decisions (max-readout winners, ReLU signs at |value| < fp32 resolution) are taken out of the
-    yardstick as tests/discrete.py describes: the HIP path's decisions must agree with fp64 wherever fp64 decides, and the
-    fp64 gradient is evaluated with the HIP path's choice at the undecidable points.  Measured with that: <= 4e-5 on every
-    parameter of every configuration below, 9e-6 on the benchmarked batch."""
-    import copy
-    args = (maxn, feat, 20, 20, True, True, 20, 3, 0.1, [50])
-    kw = dict(concat=True, gcn_name='SAGE', load_data_sparse=True, drop_out=0., collect_assign=True)
-    kw.update(flags)
-    torch.manual_seed(0)
-    ref = dense_ref.SoftPoolingGcnEncoder(*args, **kw)
-    model = network.SoftPoolingGcnEncoder(*args, **kw)
-    model.load_state_dict(ref.state_dict())
-    model.to(DEV).train()
-    ref.train()
-    ref64 = copy.deepcopy(ref).double()
-    ref64.load_data_sparse = False
-    K = kernels.get()
+def _compare_model(cpu_batch, maxn, feat, flags):
+    """tests/discrete.py::compare_model with the kernel-name spy of this file: returns (launch counts, worst gradient)."""
     spy = _Spy()
-    K.timer = spy
-    try:
-        with discrete.record_hip_decisions(model) as dec:
-            logits, loss = model(cpu_batch.to(DEV))
-            loss.backward()
-            torch.cuda.synchronize()
-    finally:
-        K.timer = None
-    assert kernels.is_native() and len(dec.winners) == 3
-    rl, rloss = ref(cpu_batch)
-    rloss.backward()
-    adj = dense_ref.to_dense_adj(cpu_batch.edge_index, cpu_batch.batch)
-    xd, counts = dense_ref.to_dense_batch(cpu_batch.x, cpu_batch.batch)
-    inp64 = (xd.double(), adj.double(), counts, cpu_batch.y)
-    l64, loss64, pre64, embeds64 = discrete.run_oracle_recording(ref64, inp64)
-    assert l64.dtype == torch.float64
-    g64_natural = {k: p.grad.clone() for k, p in ref64.named_parameters()}
-    routing, masks, winner_flips, relu_flips = discrete.hip_choices(dec, pre64, embeds64, [int(c) for c in counts])
-    if winner_flips or relu_flips:
-        l64r, _ = discrete.run_oracle_routed(ref64, inp64, routing, masks)
-        assert rel_err(l64r, l64) < 1e-6                # undecidable points: the outputs do not notice
-    print('decisions differing from the fp64 evaluation: %d of %d readout winners, %d of %d ReLU signs'
-          % (winner_flips, sum(r.numel() for r in routing), relu_flips, sum(m.numel() for m in masks.values())))
-    assert rel_err(logits, rl) < 1e-4 and elementwise_excess(logits, rl, 1e-4) <= 1.0, rel_err(logits, rl)
-    assert rel_err(logits, l64) < 1e-4 and rel_err(loss, loss64) < 1e-4
-    assert rel_err(loss, rloss) < 1e-4
-    for i, (s, rs) in enumerate(zip(model.assign_matrix, ref.assign_matrix)):
-        assert rel_err(s, rs) < 1e-4, ('assign', i, rel_err(s, rs))
-    g32, g64 = dict(ref.named_parameters()), dict(ref64.named_parameters())     # g64: with the HIP path's routing
-
-    def strict(a, b):
-        """max|a-b| / max|b| with NO absolute slack (tests/util.rel_err adds 1e-3 to the denominator, which is most of it
-        for gradients of magnitude 1e-4..1e-3).  The rounding error of a long mixed-sign sum is absolute -- it does not
-        shrink with the element -- so the max-norm is the meaningful yardstick for gradients; outputs are also checked
-        element by element above."""
-        a, b = a.detach().double().cpu(), b.detach().double().cpu()
-        return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
-    report, failures = [], []
-    for k, p in model.named_parameters():
-        if float(g64_natural[k].abs().max()) < 1e-12:           # mathematically zero (softmax-invariant attention bias): absolute
-            assert float(p.grad.abs().max()) < 1e-7, k
-            continue
-        spread = strict(g32[k].grad, g64_natural[k])            # the reference's own fp32 rounding on this parameter
-        e = strict(p.grad, g64[k].grad)
-        report.append((e, spread, k))
-        if not e < tol_grad:
-            failures.append((k, e, spread))
-    rbuf = dict(ref.named_buffers())
-    for k, a in model.named_buffers():
-        if a.dtype.is_floating_point:
-            assert rel_err(a, rbuf[k]) < 1e-4, k
-    report.sort(reverse=True)
-    print('worst gradient errors vs fp64 (hip, fp32 oracle):', [(k, '%.1e' % e, '%.1e' % sp) for e, sp, k in report[:4]])
-    if os.environ.get('CGC_PARITY_REPORT'):
-        for e, sp, k in report:
-            print('  %-40s hip %.2e   fp32 oracle %.2e' % (k, e, sp))
-    assert not failures, failures
-    return spy.records, report[0]
+    worst = discrete.compare_model(cpu_batch, maxn, feat, flags, timer=spy)
+    return spy.records, worst
 
 
 @pytest.mark.parametrize('flags', [dict(norm_adj=True, jk=True), dict()], ids=['shipped', 'plain'])

@@ -89,6 +89,16 @@ def test_synthetic_cell_graphs_vs_oracle(flags):
             assert rel_err(a, rbuf[k]) < TOL, k                       # BatchNorm running statistics (count = B*Nmax)
 
 
+@pytest.mark.parametrize('flags', [dict(), dict(norm_adj=True, jk=True)], ids=['plain', 'shipped'])
+def test_synthetic_cell_graphs_gradients_within_1e4_of_fp64(flags):
+    """The same graphs with the gradient bar at the north-star 1e-4: against the fp64 evaluation of the oracle, undecidable
+    ReLU signs / max-readout winners taken as the HIP path took them (tests/discrete.py)."""
+    import discrete
+    ds = SyntheticCellGraphs(6, 300, num_features=16, base_seed=42)
+    cpu_batch = Batch.from_data_list([ds[i] for i in range(6)])
+    discrete.compare_model(cpu_batch, 600, 16, flags, seed=3)
+
+
 def test_dense_tuple_input_form_and_eval():
     """model/network.py:253-256: (x[B,N,F], adj[B,N,N], num_nodes[, label]) input; eval mode returns logits only."""
     ds = SyntheticCellGraphs(3, 80, num_features=16, base_seed=9)
