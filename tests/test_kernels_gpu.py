@@ -226,6 +226,42 @@ def test_gemm_leading_dimensions_and_unaligned_views():
     close(gc, want, 2e-5, 'gemm with lds')
 
 
+SKINNY_CASES = [
+    # (rows per batch item, batch, N, K, tB, ragged)   -- the step's thin products at their real sizes
+    (16500, 1, 20, 1140, False, False), (16500, 1, 40, 1140, False, False), (16411, 1, 20, 1140, True, False),
+    (1140, 16, 114, 1140, False, False), (1140, 16, 40, 1140, False, False), (1100, 16, 128, 516, True, False),
+    (2153, 12, 20, 1140, False, True), (2153, 12, 100, 1140, True, True),
+]
+
+
+@pytest.mark.parametrize('rows,batch,N,K,tB,ragged', SKINNY_CASES)
+def test_gemm_skinny_products(rows, batch, N, K, tB, ragged):
+    """C = A op(B) with N <= 128 and a long K (S dX', dz W_narrow^T, A2 [h_e | h_p], A2 S2) on the 128x32 / 64x64 / 128x64
+    tile shapes gemm_dispatch picks for them -- flat, strided batches and ragged-M batches (a B per graph), bias, K with a
+    partial last k tile -- against fp64."""
+    rng = np.random.RandomState(rows + N)
+    if ragged:
+        counts = rng.randint(rows // 2, rows + 1, size=batch)
+        counts[0], counts[1] = rows, 1
+        gptr = torch.tensor(np.concatenate([[0], np.cumsum(counts)]), dtype=torch.int32)
+        n = int(counts.sum())
+        A = rnd(n, K, seed=1)
+        Bm = rnd(batch, *((N, K) if tB else (K, N)), seed=2)
+        got = torch.full((n, N), float('nan'), device=DEV)
+        hip().gemm(g(A), g(Bm), got, 0, N, K, False, tB, K, Bm.shape[2], N, 1.0, 0.0, None, batch, 0, K * N, 0, g(gptr), 1, rows, n)
+        want = torch.cat([A[gptr[b]:gptr[b + 1]].double() @ (Bm[b].double().t() if tB else Bm[b].double()) for b in range(batch)])
+    else:
+        A = rnd(batch, rows, K, seed=1)
+        Bm = rnd(batch, *((N, K) if tB else (K, N)), seed=2)
+        bias = rnd(N, seed=3)
+        got = torch.full((batch, rows, N), float('nan'), device=DEV)
+        hip().gemm(g(A), g(Bm), got, rows, N, K, False, tB, K, Bm.shape[2], N, 0.5, 0.0, g(bias), batch, rows * K, Bm.shape[1] * Bm.shape[2],
+                   rows * N)
+        want = 0.5 * torch.bmm(A.double(), Bm.double().transpose(1, 2) if tB else Bm.double()) + bias.double()
+    err = float((got.double().cpu() - want).abs().max() / want.abs().max())
+    assert err < 2e-6, err
+
+
 @pytest.mark.parametrize('C,D', [(16, 8), (60, 60), (180, 60), (1140, 20)])
 def test_gemm_ragged(C, D):
     counts = [37, 0, 130, 64, 201]
