@@ -110,7 +110,7 @@ static ColCfg col_cfg(int n, int F, bool vec_ok) {
       need = ceil_div(F, 64);
     }
     c.ok = need <= 32;                         // F <= 2048 (covers the reference's cluster counts 1140 / 1600)
-    c.maxj = need <= 2 ? 2 : need <= 4 ? 4 : need <= 8 ? 8 : need <= 16 ? 16 : 32;
+    c.maxj = need <= 2 ? 2 : need <= 4 ? 4 : (need == 5 && c.vec == 4) ? 5 : need <= 8 ? 8 : need <= 16 ? 16 : 32;   // 5: F = 1140
   }
   c.blocks = row_blocks(n, c.lpr, MAX_SLOTS);
   return c;
@@ -124,6 +124,7 @@ static ColCfg col_cfg(int n, int F, bool vec_ok) {
         case 1: hipLaunchKernelGGL((KERNEL<4, 1>), g__, b__, smem_bytes, stream, __VA_ARGS__); break;        \
         case 2: hipLaunchKernelGGL((KERNEL<4, 2>), g__, b__, smem_bytes, stream, __VA_ARGS__); break;        \
         case 4: hipLaunchKernelGGL((KERNEL<4, 4>), g__, b__, smem_bytes, stream, __VA_ARGS__); break;        \
+        case 5: hipLaunchKernelGGL((KERNEL<4, 5>), g__, b__, smem_bytes, stream, __VA_ARGS__); break;        \
         default: hipLaunchKernelGGL((KERNEL<4, 8>), g__, b__, smem_bytes, stream, __VA_ARGS__); break;       \
       }                                                                                                      \
     } else {                                                                                                 \
