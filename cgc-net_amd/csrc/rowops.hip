@@ -484,6 +484,20 @@ __global__ __launch_bounds__(256) void k_bn_act_l2_bwd(const float* __restrict__
         }
       }
   }
+  // wide rows: the five per-column constants live in LDS (filled once per workgroup; 5 F floats behind the 3 F floats of the
+  // column-sum exchange) -- as loads from the parameter vectors they were 25 extra 16-byte loads per row and lane
+  float* const lc = smem + 3 * (size_t)F;
+  if (!REGC && mode != 0) {
+    for (int c = threadIdx.x; c < F; c += blockDim.x) {
+      const float a_ = gamma[c] * istd[c];
+      lc[c] = a_;
+      lc[F + c] = mode == 2 ? a_ * sums[c] * inv_count : 0.f;
+      lc[2 * F + c] = mode == 2 ? a_ * sums[F + c] * inv_count : 0.f;
+      lc[3 * F + c] = mode == 2 ? mean[c] : 0.f;
+      lc[4 * F + c] = mode == 2 ? istd[c] : 0.f;
+    }
+    __syncthreads();
+  }
   for (int base = rg.gwave * rg.rpw; base < n; base += rg.nwaves * rg.rpw) {
     const int row = base + rg.sub;
     const bool valid = row < n;
@@ -495,11 +509,16 @@ __global__ __launch_bounds__(256) void k_bn_act_l2_bwd(const float* __restrict__
       if (valid && c < F) {
         g[j].load(dy + (size_t)row * ldy + c);
         x[j].load(hn + (size_t)row * F + c);
-        Vec<VEC> pg, pi, pm, p0, p1;      // wide rows: parameter vectors for these columns
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+      const int c = (rg.sl + lpr * j) * VEC;
+      if (valid && c < F) {
+        Vec<VEC> pa, pb, pc, pm, pi;      // wide rows: constants of these columns
         if (!REGC && mode != 0) {
-          pg.load(gamma + c);
-          pi.load(istd + c);
-          if (mode == 2) { pm.load(mean + c); p0.load(sums + c); p1.load(sums + F + c); }
+          pa.load(lc + c);
+          if (mode == 2) { pb.load(lc + F + c); pc.load(lc + 2 * F + c); pm.load(lc + 3 * F + c); pi.load(lc + 4 * F + c); }
         }
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
@@ -509,8 +528,8 @@ __global__ __launch_bounds__(256) void k_bn_act_l2_bwd(const float* __restrict__
             a_ = ca[REGC ? j : 0][REGC ? v : 0]; b_ = cb[REGC ? j : 0][REGC ? v : 0]; c_ = cc[REGC ? j : 0][REGC ? v : 0];
             m_ = mu[REGC ? j : 0][REGC ? v : 0]; i_ = is[REGC ? j : 0][REGC ? v : 0];
           } else if (mode != 0) {
-            a_ = pg.v[v] * pi.v[v];
-            if (mode == 2) { b_ = a_ * p0.v[v] * inv_count; c_ = a_ * p1.v[v] * inv_count; m_ = pm.v[v]; i_ = pi.v[v]; }
+            a_ = pa.v[v];
+            if (mode == 2) { b_ = pb.v[v]; c_ = pc.v[v]; m_ = pm.v[v]; i_ = pi.v[v]; }
           } else {
             a_ = 1.f;
           }
@@ -561,7 +580,7 @@ extern "C" int cgc_bn_act_l2_bwd(const float* dy, int ldy, const float* hn, cons
   if (!cfg.ok) return CGC_EINVAL;
   if (dh_colsum == nullptr) cfg.blocks = row_blocks(n, cfg.lpr);   // no reduction slots needed: use the full grid
   const float inv_count = (float)(1.0 / count);
-  const size_t smem = dh_colsum ? sizeof(float) * 3 * F : 0;
+  const size_t smem = sizeof(float) * (3 + 5) * F;      // column-sum exchange + the per-column constants of wide rows
   DISPATCH_COL(k_bn_act_l2_bwd, cfg, smem, as_stream(stream), dy, ldy, hn, rinv, n, F, cfg.lpr, act, normalize, mode, mean, istd,
                gamma, sums, inv_count, dh, dh_colsum ? ws : (float*)nullptr);
   CGC_RETURN_IF_LAUNCH_FAILED();
@@ -659,6 +678,55 @@ __global__ __launch_bounds__(256) void k_softmax_fwd(const float* __restrict__ x
   }
 }
 
+// rows that fit the lanes' registers (C <= 64 * MAXJ * VEC): ONE read of the row, one expf per element (same operations in
+// the same order as the three-pass kernel above: same bits)
+template <int VEC, int MAXJ>
+__global__ __launch_bounds__(256) void k_softmax_fwd_reg(const float* __restrict__ x, int n, int C, int ld, int lpr,
+                                                         float* __restrict__ out) {
+  const RowGroup rg(lpr);
+  for (int base = rg.gwave * rg.rpw; base < n; base += rg.nwaves * rg.rpw) {
+    const int row = base + rg.sub;
+    const bool valid = row < n;
+    const float* xr = x + (size_t)row * ld;
+    Vec<VEC> t[MAXJ];
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+      const int c = (rg.sl + lpr * j) * VEC;
+      if (valid && c < C) {
+        t[j].load(xr + c);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) m = fmaxf(m, t[j].v[v]);
+      }
+    }
+    m = group_max(m, lpr);
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+      const int c = (rg.sl + lpr * j) * VEC;
+      if (valid && c < C) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          t[j].v[v] = expf(t[j].v[v] - m);
+          s += t[j].v[v];
+        }
+      }
+    }
+    s = group_sum(s, lpr);
+    if (!valid) continue;
+    const float inv = 1.f / s;
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+      const int c = (rg.sl + lpr * j) * VEC;
+      if (c < C) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) t[j].v[v] *= inv;
+        t[j].store(out + (size_t)row * ld + c);
+      }
+    }
+  }
+}
+
 template <int VEC, int MAXJ>
 __global__ __launch_bounds__(256) void k_softmax_bwd(const float* __restrict__ S, const float* __restrict__ dS, int n, int C,
                                                      int ld, int lpr, float* __restrict__ dx, float* __restrict__ ws) {
@@ -709,6 +777,13 @@ extern "C" int cgc_softmax_fwd(const float* x, int n, int C, int ld, float* out,
   if (n <= 0 || C <= 0) return 0;
   if (ld < C) return CGC_EINVAL;
   const bool vec = (C % 4 == 0) && (ld % 4 == 0) && aligned16(x) && aligned16(out);
+  ColCfg cfg = col_cfg(n, C, vec);
+  if (cfg.ok && cfg.maxj <= 8) {               // the row fits the lanes' registers
+    cfg.blocks = row_blocks(n, cfg.lpr);
+    DISPATCH_COL(k_softmax_fwd_reg, cfg, 0, as_stream(stream), x, n, C, ld, cfg.lpr, out);
+    CGC_RETURN_IF_LAUNCH_FAILED();
+    return 0;
+  }
   const int lpr = pick_lpr(vec ? C / 4 : C);
   dim3 grid(row_blocks(n, lpr)), block(CGC_BLOCK);
   if (vec)
@@ -1057,6 +1132,117 @@ __global__ __launch_bounds__(256) void k_adj_prep_bwd(const float* __restrict__ 
   }
 }
 
+// register-resident forms of the two kernels above for rows that fit the lanes' registers (C <= 64 * MAXJ * VEC: the 1140 / 1600
+// clusters of level 2): every input is read ONCE, the divisions are done once; same operations in the same order (same bits).
+template <int VEC, int MAXJ>
+__global__ __launch_bounds__(256) void k_adj_prep_fwd_reg(const float* __restrict__ A, int R, int C, int lpr, float p, float* __restrict__ At,
+                                                          float* __restrict__ An, float* __restrict__ invd, float* __restrict__ ge1) {
+  const RowGroup rg(lpr);
+  const bool renorm = p >= 0.f;
+  const float omp = 1.f - p;
+  for (int base = rg.gwave * rg.rpw; base < R; base += rg.nwaves * rg.rpw) {
+    const int row = base + rg.sub;
+    const bool valid = row < R;
+    const int diag = (valid && renorm) ? row % C : -1;
+    Vec<VEC> t[MAXJ];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+      const int c = (rg.sl + lpr * j) * VEC;
+      if (valid && c < C) {
+        t[j].load(A + (size_t)row * C + c);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) s += (c + v == diag) ? 0.f : t[j].v[v];
+      }
+    }
+    s = group_sum(s, lpr);
+    float st = s;
+    const float den = s + RENORM_EPS;
+    if (renorm) {
+      st = 0.f;
+#pragma unroll
+      for (int j = 0; j < MAXJ; ++j) {
+        const int c = (rg.sl + lpr * j) * VEC;
+        if (valid && c < C) {
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) { t[j].v[v] = (c + v == diag) ? p : (t[j].v[v] / den) * omp; st += t[j].v[v]; }
+          t[j].store(At + (size_t)row * C + c);
+        }
+      }
+      st = group_sum(st, lpr);
+    }
+    if (!valid) continue;
+    const float inv = 1.f / fmaxf(st, 1.f);
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+      const int c = (rg.sl + lpr * j) * VEC;
+      if (c < C) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) t[j].v[v] *= inv;
+        t[j].store(An + (size_t)row * C + c);
+      }
+    }
+    if (rg.sl == 0) {
+      invd[row] = inv;
+      ge1[row] = st >= 1.f ? 1.f : 0.f;
+    }
+  }
+}
+
+template <int VEC, int MAXJ>
+__global__ __launch_bounds__(256) void k_adj_prep_bwd_reg(const float* __restrict__ A, const float* __restrict__ An,
+                                                          const float* __restrict__ invd, const float* __restrict__ ge1,
+                                                          const float* __restrict__ gAn, const float* __restrict__ gAt, int R, int C,
+                                                          int lpr, float p, float* __restrict__ dA) {
+  const RowGroup rg(lpr);
+  const bool renorm = p >= 0.f;
+  const float omp = 1.f - p;
+  for (int base = rg.gwave * rg.rpw; base < R; base += rg.nwaves * rg.rpw) {
+    const int row = base + rg.sub;
+    const bool valid = row < R;
+    const int diag = (valid && renorm) ? row % C : -1;
+    float t1 = 0.f, s = 0.f, u = 0.f, w = 0.f;
+    Vec<VEC> g[MAXJ], h[MAXJ];
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+      const int c = (rg.sl + lpr * j) * VEC;
+      if (valid && c < C) {
+        Vec<VEC> an, a;
+        g[j].load(gAn + (size_t)row * C + c);
+        an.load(An + (size_t)row * C + c);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) t1 += g[j].v[v] * an.v[v];
+        if (gAt != nullptr) h[j].load(gAt + (size_t)row * C + c);
+        if (renorm) {
+          a.load(A + (size_t)row * C + c);
+#pragma unroll
+          for (int v = 0; v < VEC; ++v)
+            if (c + v != diag) { s += a.v[v]; u += a.v[v] * g[j].v[v]; if (gAt != nullptr) w += a.v[v] * h[j].v[v]; }
+        }
+      }
+    }
+    t1 = group_sum(t1, lpr);
+    if (renorm) { s = group_sum(s, lpr); u = group_sum(u, lpr); w = group_sum(w, lpr); }
+    if (!valid) continue;
+    const float inv = invd[row], sub = ge1[row] * t1;
+    const float q = 1.f / (s + RENORM_EPS);
+    const float t = inv * (u - sub * s) + w;             // <A, dAt> over the off-diagonal entries
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+      const int c = (rg.sl + lpr * j) * VEC;
+      if (c < C) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          float d = inv * (g[j].v[v] - sub);
+          if (gAt != nullptr) d += h[j].v[v];
+          g[j].v[v] = renorm ? ((c + v == diag) ? 0.f : omp * q * (d - q * t)) : d;
+        }
+        g[j].store(dA + (size_t)row * C + c);
+      }
+    }
+  }
+}
+
 #define LAUNCH_ROW(KERNEL, vec, lpr, R, stream, ...)                                                          \
   do {                                                                                                        \
     dim3 g__(row_blocks(R, lpr)), b__(CGC_BLOCK);                                                             \
@@ -1102,6 +1288,13 @@ extern "C" int cgc_adj_prep_fwd(const float* A, int R, int C, float p, float* At
   if (R <= 0 || C <= 0) return 0;
   if (p >= 0.f && At == nullptr) return CGC_EINVAL;
   const bool vec = (C % 4 == 0) && aligned16(A) && aligned16(An) && (At == nullptr || aligned16(At));
+  ColCfg cfg = col_cfg(R, C, vec);
+  if (cfg.ok && cfg.maxj <= 8) {
+    cfg.blocks = row_blocks(R, cfg.lpr);
+    DISPATCH_COL(k_adj_prep_fwd_reg, cfg, 0, as_stream(stream), A, R, C, cfg.lpr, p, At, An, invd, ge1);
+    CGC_RETURN_IF_LAUNCH_FAILED();
+    return 0;
+  }
   const int lpr = pick_lpr(vec ? C / 4 : C);
   LAUNCH_ROW(k_adj_prep_fwd, vec, lpr, R, as_stream(stream), A, R, C, lpr, p, At, An, invd, ge1);
   CGC_RETURN_IF_LAUNCH_FAILED();
@@ -1111,6 +1304,13 @@ extern "C" int cgc_adj_prep_bwd(const float* A, const float* An, const float* in
                                 int R, int C, float p, float* dA, cgc_stream_t stream) {
   if (R <= 0 || C <= 0) return 0;
   const bool vec = (C % 4 == 0) && aligned16(A) && aligned16(An) && aligned16(gAn) && aligned16(dA) && (gAt == nullptr || aligned16(gAt));
+  ColCfg cfg = col_cfg(R, C, vec);
+  if (cfg.ok && cfg.maxj <= 8) {
+    cfg.blocks = row_blocks(R, cfg.lpr);
+    DISPATCH_COL(k_adj_prep_bwd_reg, cfg, 0, as_stream(stream), A, An, invd, ge1, gAn, gAt, R, C, cfg.lpr, p, dA);
+    CGC_RETURN_IF_LAUNCH_FAILED();
+    return 0;
+  }
   const int lpr = pick_lpr(vec ? C / 4 : C);
   LAUNCH_ROW(k_adj_prep_bwd, vec, lpr, R, as_stream(stream), A, An, invd, ge1, gAn, gAt, R, C, lpr, p, dA);
   CGC_RETURN_IF_LAUNCH_FAILED();
