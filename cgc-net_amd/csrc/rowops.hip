@@ -54,38 +54,39 @@ __device__ __forceinline__ void col_reduce_store(float (&acc)[NQ][MAXJ][VEC], in
 
 // out[c] = sum_s ws[s*width + c]   (fixed summation order: deterministic; accumulated in fp64 so that the
 // BatchNorm variance E[x^2] - E[x]^2 formed from these sums keeps ~1e-7 accuracy even when |mean| >> std).
-// 256 threads = 8 slot groups x 32 columns; every thread keeps 8 independent loads in flight.
+// 1024 threads = 32 slot groups x 32 columns, 4 independent loads in flight per thread: the kernel is a chain of dependent
+// load rounds (slots / 128 of them; it was slots / 64 with 8 groups) and little else -- 6 us -> 4 us for the ~450-slot
+// reductions of the narrow layers, of which a step has ~45.
+#define RS_GROUPS 32
 template <typename OUT>
-__global__ __launch_bounds__(256) void k_reduce_slots(const float* __restrict__ ws, int slots, int width, OUT* __restrict__ out) {
-  __shared__ double part[8][32];
+__global__ __launch_bounds__(32 * RS_GROUPS) void k_reduce_slots(const float* __restrict__ ws, int slots, int width, OUT* __restrict__ out) {
+  __shared__ double part[RS_GROUPS][32];
   const int cl = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
   double s = 0.0;
   if (c < width) {
-    double a[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) a[u] = 0.0;
+    double a[4] = {0.0, 0.0, 0.0, 0.0};
     int k = grp;
-    for (; k + 56 < slots; k += 64) {
+    for (; k + 3 * RS_GROUPS < slots; k += 4 * RS_GROUPS) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) a[u] += (double)ws[(size_t)(k + 8 * u) * width + c];
+      for (int u = 0; u < 4; ++u) a[u] += (double)ws[(size_t)(k + RS_GROUPS * u) * width + c];
     }
-    for (; k < slots; k += 8) a[0] += (double)ws[(size_t)k * width + c];
-    s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    for (; k < slots; k += RS_GROUPS) a[0] += (double)ws[(size_t)k * width + c];
+    s = (a[0] + a[1]) + (a[2] + a[3]);
   }
   part[grp][cl] = s;
   __syncthreads();
   if (grp == 0 && c < width) {
-    double t = part[0][cl];
+    double t[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int g = 1; g < 8; ++g) t += part[g][cl];
-    out[c] = (OUT)t;
+    for (int g = 0; g < RS_GROUPS; g += 4) { t[0] += part[g][cl]; t[1] += part[g + 1][cl]; t[2] += part[g + 2][cl]; t[3] += part[g + 3][cl]; }
+    out[c] = (OUT)((t[0] + t[1]) + (t[2] + t[3]));
   }
 }
 #define REDUCE_SLOTS_GRID(width) dim3(ceil_div((width), 32))
 
 int launch_reduce_slots_f32(const float* ws, int slots, int width, float* out, hipStream_t stream) {
-  hipLaunchKernelGGL(k_reduce_slots<float>, REDUCE_SLOTS_GRID(width), dim3(256), 0, stream, ws, slots, width, out);
+  hipLaunchKernelGGL(k_reduce_slots<float>, REDUCE_SLOTS_GRID(width), dim3(32 * RS_GROUPS), 0, stream, ws, slots, width, out);
   CGC_RETURN_IF_LAUNCH_FAILED();
   return 0;
 }
@@ -213,7 +214,7 @@ extern "C" int cgc_l2norm_act_stats(const float* h, int n, int F, int normalize,
   DISPATCH_COL(k_l2norm_act_stats, cfg, smem, as_stream(stream), h, n, F, cfg.lpr, normalize, act, hn, rinv, wsp);
   CGC_RETURN_IF_LAUNCH_FAILED();
   if (stats) {
-    hipLaunchKernelGGL(k_reduce_slots<double>, REDUCE_SLOTS_GRID(2 * F), dim3(256), 0, as_stream(stream), ws, cfg.blocks, 2 * F, stats);
+    hipLaunchKernelGGL(k_reduce_slots<double>, REDUCE_SLOTS_GRID(2 * F), dim3(32 * RS_GROUPS), 0, as_stream(stream), ws, cfg.blocks, 2 * F, stats);
     CGC_RETURN_IF_LAUNCH_FAILED();
   }
   return 0;
@@ -251,10 +252,10 @@ extern "C" int cgc_bn_finalize(const double* stats, int F, double count, float e
 
 // second stage of the statistics + finalize in one kernel: the column sums of the slots (same grouping and order as
 // k_reduce_slots<double>, so the same bits) and mean / istd / running statistics / num_batches_tracked of k_bn_finalize
-__global__ __launch_bounds__(256) void k_stats_finalize(const float* __restrict__ ws, int slots, int F, double count, float eps,
-                                                        float momentum, float* running_mean, float* running_var,
-                                                        float* __restrict__ mean, float* __restrict__ istd, long long* nbt) {
-  __shared__ double part[2][8][32];
+__global__ __launch_bounds__(32 * RS_GROUPS) void k_stats_finalize(const float* __restrict__ ws, int slots, int F, double count, float eps,
+                                                                  float momentum, float* running_mean, float* running_var,
+                                                                  float* __restrict__ mean, float* __restrict__ istd, long long* nbt) {
+  __shared__ double part[2][RS_GROUPS][32];
   const int cl = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int f = blockIdx.x * 32 + cl;
   if (blockIdx.x == 0 && threadIdx.x == 0 && nbt != nullptr) *nbt += 1;       // nn.BatchNorm1d's num_batches_tracked
@@ -264,24 +265,25 @@ __global__ __launch_bounds__(256) void k_stats_finalize(const float* __restrict_
     if (f < F) {
       const float* col = ws + (size_t)q * F + f;
       const size_t width = 2 * (size_t)F;
-      double a[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) a[u] = 0.0;
+      double a[4] = {0.0, 0.0, 0.0, 0.0};
       int k = grp;
-      for (; k + 56 < slots; k += 64) {
+      for (; k + 3 * RS_GROUPS < slots; k += 4 * RS_GROUPS) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) a[u] += (double)col[(size_t)(k + 8 * u) * width];
+        for (int u = 0; u < 4; ++u) a[u] += (double)col[(size_t)(k + RS_GROUPS * u) * width];
       }
-      for (; k < slots; k += 8) a[0] += (double)col[(size_t)k * width];
-      s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+      for (; k < slots; k += RS_GROUPS) a[0] += (double)col[(size_t)k * width];
+      s = (a[0] + a[1]) + (a[2] + a[3]);
     }
     part[q][grp][cl] = s;
   }
   __syncthreads();
   if (grp != 0 || f >= F) return;
-  double s0 = part[0][0][cl], s1 = part[1][0][cl];
+  double t0[4] = {0.0, 0.0, 0.0, 0.0}, t1[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-  for (int g = 1; g < 8; ++g) { s0 += part[0][g][cl]; s1 += part[1][g][cl]; }
+  for (int g = 0; g < RS_GROUPS; g += 4)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { t0[u] += part[0][g + u][cl]; t1[u] += part[1][g + u][cl]; }
+  const double s0 = (t0[0] + t0[1]) + (t0[2] + t0[3]), s1 = (t1[0] + t1[1]) + (t1[2] + t1[3]);
   const double m = s0 / count;
   double var = s1 / count - m * m;             // biased; the padded zero rows are part of `count`
   if (var < 0.0) var = 0.0;
@@ -296,7 +298,7 @@ __global__ __launch_bounds__(256) void k_stats_finalize(const float* __restrict_
 
 int launch_stats_finalize(const float* ws, int slots, int F, double count, float eps, float momentum, float* running_mean,
                           float* running_var, float* mean, float* istd, int64_t* nbt, hipStream_t stream) {
-  hipLaunchKernelGGL(k_stats_finalize, dim3(ceil_div(F, 32)), dim3(256), 0, stream, ws, slots, F, count, eps, momentum,
+  hipLaunchKernelGGL(k_stats_finalize, dim3(ceil_div(F, 32)), dim3(32 * RS_GROUPS), 0, stream, ws, slots, F, count, eps, momentum,
                      running_mean, running_var, mean, istd, reinterpret_cast<long long*>(nbt));
   CGC_RETURN_IF_LAUNCH_FAILED();
   return 0;
@@ -320,7 +322,7 @@ extern "C" int cgc_l2norm_act_bn(const float* h, int n, int F, int normalize, in
     CGC_RETURN_IF_LAUNCH_FAILED();
     slots = cfg.blocks;
   }
-  hipLaunchKernelGGL(k_stats_finalize, dim3(ceil_div(F, 32)), dim3(256), 0, as_stream(stream), ws, slots, F, count, eps, momentum,
+  hipLaunchKernelGGL(k_stats_finalize, dim3(ceil_div(F, 32)), dim3(32 * RS_GROUPS), 0, as_stream(stream), ws, slots, F, count, eps, momentum,
                      running_mean, running_var, mean, istd, reinterpret_cast<long long*>(num_batches_tracked));
   CGC_RETURN_IF_LAUNCH_FAILED();
   return 0;
@@ -438,7 +440,7 @@ extern "C" int cgc_bn_bwd_reduce(const float* dy, int ldy, const float* hn, int 
   const size_t smem = sizeof(float) * 3 * 2 * F;
   DISPATCH_COL(k_bn_bwd_reduce, cfg, smem, as_stream(stream), dy, ldy, hn, n, F, cfg.lpr, act, mean, istd, ws);
   CGC_RETURN_IF_LAUNCH_FAILED();
-  hipLaunchKernelGGL(k_reduce_slots<float>, REDUCE_SLOTS_GRID(2 * F), dim3(256), 0, as_stream(stream), ws, cfg.blocks, 2 * F, sums);
+  hipLaunchKernelGGL(k_reduce_slots<float>, REDUCE_SLOTS_GRID(2 * F), dim3(32 * RS_GROUPS), 0, as_stream(stream), ws, cfg.blocks, 2 * F, sums);
   CGC_RETURN_IF_LAUNCH_FAILED();
   return 0;
 }
@@ -585,7 +587,7 @@ extern "C" int cgc_bn_act_l2_bwd(const float* dy, int ldy, const float* hn, cons
                gamma, sums, inv_count, dh, dh_colsum ? ws : (float*)nullptr);
   CGC_RETURN_IF_LAUNCH_FAILED();
   if (dh_colsum) {
-    hipLaunchKernelGGL(k_reduce_slots<float>, REDUCE_SLOTS_GRID(F), dim3(256), 0, as_stream(stream), ws, cfg.blocks, F, dh_colsum);
+    hipLaunchKernelGGL(k_reduce_slots<float>, REDUCE_SLOTS_GRID(F), dim3(32 * RS_GROUPS), 0, as_stream(stream), ws, cfg.blocks, F, dh_colsum);
     CGC_RETURN_IF_LAUNCH_FAILED();
   }
   return 0;
@@ -633,7 +635,7 @@ extern "C" int cgc_colsum(const float* x, int ld, int n, int F, float* out, floa
   const size_t smem = sizeof(float) * 3 * F;
   DISPATCH_COL(k_colsum, cfg, smem, as_stream(stream), x, ld, n, F, cfg.lpr, ws);
   CGC_RETURN_IF_LAUNCH_FAILED();
-  hipLaunchKernelGGL(k_reduce_slots<float>, REDUCE_SLOTS_GRID(F), dim3(256), 0, as_stream(stream), ws, cfg.blocks, F, out);
+  hipLaunchKernelGGL(k_reduce_slots<float>, REDUCE_SLOTS_GRID(F), dim3(32 * RS_GROUPS), 0, as_stream(stream), ws, cfg.blocks, F, out);
   CGC_RETURN_IF_LAUNCH_FAILED();
   return 0;
 }
@@ -811,7 +813,7 @@ extern "C" int cgc_softmax_bwd(const float* S, const float* dS, int n, int C, in
   DISPATCH_COL(k_softmax_bwd, cfg, smem, as_stream(stream), S, dS, n, C, ld, cfg.lpr, dx, dx_colsum ? ws : (float*)nullptr);
   CGC_RETURN_IF_LAUNCH_FAILED();
   if (dx_colsum) {
-    hipLaunchKernelGGL(k_reduce_slots<float>, REDUCE_SLOTS_GRID(C), dim3(256), 0, as_stream(stream), ws, cfg.blocks, C, dx_colsum);
+    hipLaunchKernelGGL(k_reduce_slots<float>, REDUCE_SLOTS_GRID(C), dim3(32 * RS_GROUPS), 0, as_stream(stream), ws, cfg.blocks, C, dx_colsum);
     CGC_RETURN_IF_LAUNCH_FAILED();
   }
   return 0;
