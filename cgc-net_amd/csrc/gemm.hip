@@ -91,14 +91,20 @@ struct KContigLoader {
   }
   // Partial k-tile (k_lim % 4 == 0), still branch-free: units past the end of K re-read the last valid 16 bytes of their
   // row and are zeroed with a select -- the guarded loader above costs ~0.75 of a full tile's time on top of its own.
+  // (k_lim need not be a multiple of 4 when the row stride is: the unit that straddles the end is read whole -- the tail of
+  // a padded row, or the head of the next one -- and its elements past k_lim are zeroed one by one.)
   __device__ __forceinline__ void load_fast_masked(const float* __restrict__ base, int ld, int row0, int row_last, int k0, int k_lim) {
+    const int k_last4 = (k_lim - 1) & ~3;
 #pragma unroll
     for (int i = 0; i < PER_T; ++i) {
       const int u = threadIdx.x + i * 256;
       const int row = min(row0 + u / (BK / 4), row_last);
       const int k = k0 + (u % (BK / 4)) * 4;
-      float4 v = *reinterpret_cast<const float4*>(base + (size_t)row * ld + min(k, k_lim - 4));
-      if (k >= k_lim) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 v = *reinterpret_cast<const float4*>(base + (size_t)row * ld + min(k, k_last4));
+      if (k >= k_lim) v.x = 0.f;
+      if (k + 1 >= k_lim) v.y = 0.f;
+      if (k + 2 >= k_lim) v.z = 0.f;
+      if (k + 3 >= k_lim) v.w = 0.f;
       reg[i] = v;
     }
   }
@@ -399,12 +405,16 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const GemmArgs a) {   // 2 
   }
   const int nk = nk_main + nkx0 + nkx1;
   // unguarded 16-byte loads for full k-tiles when the layout allows (block-uniform decision)
-  const bool fastA = vecA && (TA ? (M % 4 == 0 && M >= 4) : true);
-  const bool fastB = vecB && (TB ? true : (N % 4 == 0 && N >= 4));
-  const int a_last = TA ? M - 4 : M - 1, b_last = TB ? N - 1 : N - 4;
+  // (an extent that is not a multiple of 4 is fine: with a row stride that IS one -- vecA / vecB -- the 16-byte group that
+  // straddles the edge stays inside its row's stride: padding, whose values only reach output rows / columns that are never
+  // stored, or k positions that are zeroed.  The level-2 cluster count 114 = int(1140 * 0.1) on 116-float rows is the case.)
+  const bool fastA = vecA && M >= 1 && (TA ? a.lda >= ((M + 3) & ~3) : true);
+  const bool fastB = vecB && N >= 1 && (TB ? true : a.ldb >= ((N + 3) & ~3));
+  const int a_last = TA ? ((M - 1) & ~3) : M - 1, b_last = TB ? N - 1 : ((N - 1) & ~3);
   // partial k-tiles can take the masked fast loads: always when k is the row index of the operand (A stored [K,M], B stored
-  // [K,N]), for k-contiguous operands when K is a multiple of the 16-byte unit
-  const bool k4 = (K % 4 == 0) && K >= 4, k4A = TA ? K >= 1 : k4, k4B = TB ? k4 : K >= 1;
+  // [K,N]); for k-contiguous operands when the row stride covers the 16-byte group that holds the last k
+  const int K4 = (K + 3) & ~3;
+  const bool k4A = K >= 1 && (TA ? true : a.lda >= K4), k4B = K >= 1 && (TB ? a.ldb >= K4 : true);
   auto fetch = [&](LoaderA& la, LoaderB& lb, int kt) {
     if (kt < nk_main) {
       if (fastA && kt < nk_full) la.load_fast(A, a.lda, m0, a_last, kt * BK);
@@ -561,13 +571,17 @@ __global__ __launch_bounds__(256, 3) void k_gemm_f32_shortk(const GemmArgs a) {
 
   const int nk = (K + BK - 1) / BK, nk_full = K / BK;
   // unguarded 16-byte loads for full k-tiles when the layout allows (block-uniform decision)
-  const bool fastA = vecA && (TA ? (M % 4 == 0 && M >= 4) : true);
-  const bool fastB = vecB && (TB ? true : (N % 4 == 0 && N >= 4));
-  const int a_last = TA ? M - 4 : M - 1, b_last = TB ? N - 1 : N - 4;
+  const bool fastA = vecA && M >= 1 && (TA ? a.lda >= ((M + 3) & ~3) : true);     // as in k_gemm_f32
+  const bool fastB = vecB && N >= 1 && (TB ? true : a.ldb >= ((N + 3) & ~3));
+  const int a_last = TA ? ((M - 1) & ~3) : M - 1, b_last = TB ? N - 1 : ((N - 1) & ~3);
+  const int K4 = (K + 3) & ~3;
+  const bool k4A = K >= 1 && (TA ? true : a.lda >= K4), k4B = K >= 1 && (TB ? a.ldb >= K4 : true);
   auto fetch = [&](LoaderA& la, LoaderB& lb, int kt) {
     if (fastA && kt < nk_full) la.load_fast(A, a.lda, m0, a_last, kt * BK);
+    else if (fastA && k4A) la.load_fast_masked(A, a.lda, m0, a_last, kt * BK, K);
     else la.load(A, a.lda, m0, M, kt * BK, K, vecA);
     if (fastB && kt < nk_full) lb.load_fast(B, a.ldb, n0, b_last, kt * BK);
+    else if (fastB && k4B) lb.load_fast_masked(B, a.ldb, n0, b_last, kt * BK, K);
     else lb.load(B, a.ldb, n0, N, kt * BK, K, vecB);
   };
   // Short reductions (K <= 96: rank-k updates such as dS += X dX'^T, dA~ = g x^T, h = agg W): the kernel is bound by the

@@ -29,11 +29,40 @@ _WIDE_MIN = 256      # (128 measured on the 180-cluster configuration: no gain)
 def _wide(n, F, device):
     """[n, F] fp32 rows for kernel outputs.  Wide rows (F >= 256) get a row stride rounded up to 32 floats: every 128-byte
     line then belongs to ONE row, which the GEMM's k-contiguous tile loads (one line per 32-float segment instead of two)
-    and the gather kernels reward with 5-15 % -- measured 109 -> 125 TFLOP/s on the NT contraction for 1140 vs 1152."""
-    if F < _WIDE_MIN or F % 32 == 0:
+    and the gather kernels reward with 5-15 % -- measured 109 -> 125 TFLOP/s on the NT contraction for 1140 vs 1152.
+    Rows of 33..255 floats whose width is not a multiple of 4 (the level-2 cluster count 114) are padded to one: the GEMM's
+    unguarded 16-byte loaders need 16-byte-aligned rows (csrc/gemm.hip)."""
+    if F >= _WIDE_MIN and F % 32 != 0:
+        ld = -(-F // 32) * 32
+    elif F > 32 and F % 4 != 0:
+        ld = -(-F // 4) * 4
+    else:
         return torch.empty(n, F, dtype=torch.float32, device=device)
-    ld = -(-F // 32) * 32
     return torch.empty(n, ld, dtype=torch.float32, device=device)[:, :F]
+
+
+def _pad4(b, r, c, device):
+    """[b, r, c] fp32 for a batched product; large tensors whose rows are not a multiple of 4 floats get padded rows (see _wide)."""
+    if c % 4 == 0 or c <= 32 or b * r * c < (1 << 20):
+        return torch.empty(b, r, c, dtype=torch.float32, device=device)
+    return torch.empty(b, r, -(-c // 4) * 4, dtype=torch.float32, device=device)[:, :, :c]
+
+
+def _like3(t):
+    """empty_like that keeps the row padding of a [b, r, c] tensor (torch.empty_like makes non-dense tensors contiguous)."""
+    if t.is_contiguous():
+        return torch.empty_like(t)
+    b, r, c = t.shape
+    return torch.empty(b, r, t.stride(1), dtype=t.dtype, device=t.device)[:, :, :c]
+
+
+def _b3(t):
+    """A [b, r, c] fp32 operand for _bgemm: as it is when its rows are contiguous and the batch is evenly strided (plain or with
+    padded rows), else a contiguous copy."""
+    if (t.dim() == 3 and t.dtype == torch.float32 and t.stride(2) == 1 and t.stride(1) >= t.shape[2]
+            and t.stride(0) == t.shape[1] * t.stride(1)):
+        return t
+    return _f32c(t)
 
 
 def _window(buf, off, width):
@@ -666,22 +695,22 @@ def _bsplit_ptr(batch, Kd, parts, device):
 
 
 def _bgemm(A, B, C, tA, tB, beta=0.0):
-    """A, B, C: contiguous [batch, r, c] tensors; computes C = op(A) op(B) (+ beta C)."""
+    """A, B, C: [batch, r, c] tensors with contiguous (possibly padded) rows, see _b3; computes C = op(A) op(B) (+ beta C)."""
     batch = C.shape[0]
     M, N = C.shape[1], C.shape[2]
     Kd = A.shape[1] if tA else A.shape[2]
-    if tA and not tB and M <= 128 and N <= 128 and Kd >= 512 and batch * 2 < 256:
+    lda, ldb, ldc = A.stride(1), B.stride(1), C.stride(1)
+    if tA and not tB and M <= 128 and N <= 128 and Kd >= 512 and batch * 2 < 256 and ldc == N:
         # small outputs reduced over a long axis (S2^T P2, S2^T X at level 2): too few tiles to fill the chip -> cut every
         # batch's reduction into slices (ragged-K over the flattened rows), combine deterministically
         parts = max(2, min(Kd // 128, -(-384 // (batch * (2 if N > 64 else 1)))))
         ptr, step = _bsplit_ptr(batch, Kd, parts, A.device)
         ws = torch.empty(batch * parts, M * N, dtype=torch.float32, device=A.device)
-        K().gemm(A, B, ws, M, N, 0, True, False, A.shape[2], B.shape[2], N, 1.0, 0.0, None, batch * parts, 0, 0, M * N,
+        K().gemm(A, B, ws, M, N, 0, True, False, lda, ldb, N, 1.0, 0.0, None, batch * parts, 0, 0, M * N,
                  ptr, 2, step, batch * Kd)
         K().reduce_batched(ws, C, batch, parts, M * N, beta)
         return
-    K().gemm(A, B, C, M, N, Kd, tA, tB, A.shape[2], B.shape[2], N, 1.0, beta, None, batch,
-             A.shape[1] * A.shape[2], B.shape[1] * B.shape[2], M * N)
+    K().gemm(A, B, C, M, N, Kd, tA, tB, lda, ldb, ldc, 1.0, beta, None, batch, A.stride(0), B.stride(0), C.stride(0))
 
 
 class SharedGrad(object):
@@ -718,13 +747,13 @@ class SharedGrad(object):
 class _BMatmul(Function):
     @staticmethod
     def forward(ctx, A, B, tA, tB, shared=None):
-        A, B = _f32c(A), _f32c(B)
+        A, B = _b3(A), _b3(B)
         ctx.shared = shared
         if shared is not None:
             shared.register()
         M = A.shape[2] if tA else A.shape[1]
         N = B.shape[1] if tB else B.shape[2]
-        C = torch.empty(A.shape[0], M, N, dtype=torch.float32, device=A.device)
+        C = _pad4(A.shape[0], M, N, A.device)
         _bgemm(A, B, C, tA, tB)
         ctx.save_for_backward(A, B)
         ctx.t = (tA, tB)
@@ -734,19 +763,19 @@ class _BMatmul(Function):
     def backward(ctx, dC):
         A, B = ctx.saved_tensors
         tA, tB = ctx.t
-        dC = _f32c(dC)
+        dC = _b3(dC)
         dA = dB = None
         if ctx.needs_input_grad[0]:
             if ctx.shared is not None:
                 dA = ctx.shared.contribute(A, dC, B)          # plain A @ B nodes only (asserted in bmatmul)
             else:
-                dA = torch.empty_like(A)
+                dA = _like3(A)
                 if not tA:
                     _bgemm(dC, B, dA, False, not tB)          # dA = dC op(B)^T
                 else:
                     _bgemm(B, dC, dA, tB, True)               # dA = op(B) dC^T
         if ctx.needs_input_grad[1]:
-            dB = torch.empty_like(B)
+            dB = _like3(B)
             if not tB:
                 _bgemm(A, dC, dB, not tA, False)        # dB = op(A)^T dC
             else:

@@ -262,6 +262,33 @@ def test_gemm_skinny_products(rows, batch, N, K, tB, ragged):
     assert err < 2e-6, err
 
 
+@pytest.mark.parametrize('tA,tB', [(False, False), (False, True), (True, False)])
+@pytest.mark.parametrize('M,N,K', [(1140, 114, 1140), (1140, 1140, 114), (114, 114, 1140), (250, 114, 70), (114, 30, 114)])
+def test_gemm_odd_extents_on_padded_rows(M, N, K, tA, tB):
+    """Extents that are not multiples of 4 (the level-2 cluster count 114) on rows padded to a multiple of 4 floats: the
+    unguarded 16-byte loaders read into the padding, which must not reach any stored value -- the padding holds NaN here."""
+    batch = 3
+    pad = lambda w: (w + 3) // 4 * 4
+
+    def padded(rows, cols, seed):
+        full = torch.full((batch, rows, pad(cols)), float('nan'))
+        full[:, :, :cols] = rnd(batch, rows, cols, seed=seed)
+        return full
+    A = padded(K, M, 1) if tA else padded(M, K, 1)
+    Bm = padded(N, K, 2) if tB else padded(K, N, 2)
+    C = torch.full((batch, M, pad(N)), float('nan'))
+    gA, gB, gC = g(A), g(Bm), g(C)
+    hip().gemm(gA, gB, gC, M, N, K, tA, tB, A.shape[2], Bm.shape[2], C.shape[2], 1.0, 0.0, None, batch,
+               A.shape[1] * A.shape[2], Bm.shape[1] * Bm.shape[2], M * C.shape[2])
+    a = A[:, :, :M].transpose(1, 2) if tA else A[:, :, :K]
+    b = Bm[:, :, :K].transpose(1, 2) if tB else Bm[:, :, :N]
+    want = torch.bmm(a.double(), b.double())
+    got = gC.cpu()
+    assert torch.isnan(got[:, :, N:]).all()                  # the padding of C is not written
+    err = float((got[:, :, :N].double() - want).abs().max() / want.abs().max())
+    assert err < 2e-6, err
+
+
 @pytest.mark.parametrize('C,D', [(16, 8), (60, 60), (180, 60), (1140, 20)])
 def test_gemm_ragged(C, D):
     counts = [37, 0, 130, 64, 201]
