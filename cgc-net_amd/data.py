@@ -102,6 +102,9 @@ class Batch(Data):
         out.batch = torch.cat(batch_vec)
         out.num_graphs = len(data_list)
         out._node_counts = [d.num_nodes for d in data_list]   # host-side: lets graph.py skip a device sync
+        # per-graph row offsets: travel to the device with the batch (.to()), so that the model does not start every step with a
+        # blocking host-to-device copy of its own
+        out._gptr = torch.tensor([0] + list(np.cumsum(out._node_counts)), dtype=torch.int32)
         return out
 
 
@@ -202,6 +205,7 @@ def _collate_on_device(data_list, device, knn, mean, std, spatial=False):
     out.batch = batch_vec
     out.num_graphs = B
     out._node_counts = counts
+    out._gptr = dv['_gptr']
     return out
 
 

@@ -16,7 +16,7 @@ from . import kernels
 
 
 class BatchGraph(object):
-    def __init__(self, n, counts, device, npad=None):
+    def __init__(self, n, counts, device, npad=None, gptr=None):
         self.n = int(n)
         self.counts = [int(c) for c in counts]
         self.B = len(self.counts)
@@ -30,7 +30,13 @@ class BatchGraph(object):
             ptr.append(ptr[-1] + c)
         assert ptr[-1] == self.n, 'batch vector and x disagree on the node count'
         self.gptr_host = ptr
-        self.gptr = torch.tensor(ptr, dtype=torch.int32, device=device)
+        # the offsets on the device: the Batch's own copy when the collate made one (it came over with the batch); building it here
+        # is a blocking host-to-device copy that also waits for everything queued before it -- the whole previous step
+        if (torch.is_tensor(gptr) and gptr.dtype == torch.int32 and gptr.device == torch.device(device)
+                and gptr.numel() == self.B + 1 and gptr.is_contiguous()):
+            self.gptr = gptr
+        else:
+            self.gptr = torch.tensor(ptr, dtype=torch.int32, device=device)
         # visiting sequence for the wide aggregation when the graphs are LARGE (thousands of nodes: the tensors no longer fit the
         # Infinity Cache, so the recency hints are worthless, and four graphs of unequal size per XCD leave up to 20 % imbalance):
         # graphs sorted by size and dealt to the 8 XCDs in serpentine order, each XCD's graphs listed consecutively
@@ -64,7 +70,7 @@ class BatchGraph(object):
     @classmethod
     def from_batch(cls, batch, renorm_p=None):
         x, edge_index = batch.x, batch.edge_index
-        g = cls(x.shape[0], cls.node_counts_of(batch), x.device, getattr(batch, '_dense_rows', None))
+        g = cls(x.shape[0], cls.node_counts_of(batch), x.device, getattr(batch, '_dense_rows', None), getattr(batch, '_gptr', None))
         g._build(edge_index.contiguous(), renorm_p)
         return g
 

@@ -8,6 +8,8 @@ Reference arithmetic being re-expressed:
   segment_max                           max readout incl. zero padding rows           (A9; model/network.py:264)
   rownorm_clamp, renorm_dense           clamp(min=1) mean divisor, _re_norm_adj at levels 2-3 (A4, A6)
 """
+import collections
+
 import torch
 from torch.autograd import Function
 
@@ -83,17 +85,29 @@ def _rows_ld(t):
 # ----------------------------------------------------------------------------------------------
 # split-K helper for the tall-skinny "weight gradient" contractions  out[Fa,Fb] = A[n,Fa]^T B[n,Fb]
 # ----------------------------------------------------------------------------------------------
-_SPLIT_CACHE = {}
+_SPLIT_CACHE = collections.OrderedDict()      # (n, parts, device) -> (ptr, chunk); bounded: n is a batch's node count
+_SPLIT_ARANGE = {}
 
 
 def _split_ptr(n, parts, device):
+    """Row split points [0, chunk, 2 chunk, .., n] as an int32 device tensor.  Built ON the device (two tiny launches on a
+    miss): a torch.tensor(list, device=...) here would be a blocking host-to-device copy in the middle of backward, once per
+    distinct node count -- i.e. every step of a real epoch."""
     key = (n, parts, str(device))
-    if key not in _SPLIT_CACHE:
-        chunk = -(-n // parts)
-        chunk = -(-chunk // 32) * 32
-        ptr = [min(i * chunk, n) for i in range(parts + 1)]
-        _SPLIT_CACHE[key] = (torch.tensor(ptr, dtype=torch.int32, device=device), chunk)
-    return _SPLIT_CACHE[key]
+    hit = _SPLIT_CACHE.get(key)
+    if hit is not None:
+        _SPLIT_CACHE.move_to_end(key)
+        return hit
+    chunk = -(-n // parts)
+    chunk = -(-chunk // 32) * 32
+    ar = _SPLIT_ARANGE.get((parts, str(device)))
+    if ar is None:
+        ar = _SPLIT_ARANGE[(parts, str(device))] = torch.arange(parts + 1, dtype=torch.int32, device=device)
+    ptr = (ar * chunk).clamp_(max=n)
+    _SPLIT_CACHE[key] = (ptr, chunk)
+    if len(_SPLIT_CACHE) > 64:
+        _SPLIT_CACHE.popitem(last=False)
+    return ptr, chunk
 
 
 _RESIDENT_BLOCKS = 512      # 256 CUs x 2 workgroups (the GEMM's ~70 KB of LDS admits two per CU)
@@ -114,6 +128,8 @@ def _split_parts(Fa, Fb, n, _cache={}):
             score = fill - 0.02 * rounds - (0.5 if blocks < 256 else 0.0)
             if score > best_score + 1e-9:
                 best, best_score = parts, score
+        if len(_cache) > 4096:       # n is a batch's node count: keep the memo bounded over a long run
+            _cache.clear()
         _cache[key] = best
     return _cache[key]
 
