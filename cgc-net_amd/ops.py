@@ -40,7 +40,9 @@ def _wide(n, F, device):
         ld = -(-F // 4) * 4
     else:
         return torch.empty(n, F, dtype=torch.float32, device=device)
-    return torch.empty(n, ld, dtype=torch.float32, device=device)[:, :F]
+    # (an independent tensor on the padded storage, not a view: callers may modify it in place -- nn.ReLU(inplace=True) on a
+    # custom Function's output that is a VIEW is refused by autograd)
+    return _window(torch.empty(n, ld, dtype=torch.float32, device=device), 0, F)
 
 
 def _pad4(b, r, c, device):
@@ -211,11 +213,11 @@ def split_cols(x, w):
 class _LinearBias(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, out_in_layout):
-        x, weight = _f32c(x), _f32c(weight)
+        (x, ldx), weight = _rows_ld(x), _f32c(weight)
         n, fin = x.shape
         fout = weight.shape[0] if out_in_layout else weight.shape[1]
         y = torch.empty(n, fout, dtype=torch.float32, device=x.device)
-        K().gemm(x, weight, y, n, fout, fin, False, out_in_layout, fin, weight.shape[1], fout, 1.0, 0.0, bias)
+        K().gemm(x, weight, y, n, fout, fin, False, out_in_layout, ldx, weight.shape[1], fout, 1.0, 0.0, bias)
         ctx.save_for_backward(x, weight)
         ctx.out_in, ctx.has_bias = out_in_layout, bias is not None
         return y
@@ -225,18 +227,19 @@ class _LinearBias(Function):
         x, weight = ctx.saved_tensors
         dy, ld = _rows_ld(dy)
         n, fin = x.shape
+        ldx = x.stride(0)
         fout = dy.shape[1]
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x)
+            dx = torch.empty(n, fin, dtype=torch.float32, device=dy.device)
             # dx = dy W^T : with W [in,out] that is op(B)=W^T (transB); with W [out,in] it is plain W
             K().gemm(dy, weight, dx, n, fin, fout, False, not ctx.out_in, ld, weight.shape[1], fin)
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(weight)
             if ctx.out_in:      # dW[out,in] = dy^T x
-                gemm_tn_rows(dy, ld, fout, x, fin, fin, n, dw)
+                gemm_tn_rows(dy, ld, fout, x, ldx, fin, n, dw)
             else:               # dW[in,out] = x^T dy
-                gemm_tn_rows(x, fin, fin, dy, ld, fout, n, dw)
+                gemm_tn_rows(x, ldx, fin, dy, ld, fout, n, dw)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = torch.empty(fout, dtype=torch.float32, device=dy.device)
             K().colsum(dy, ld, n, fout, db)
