@@ -824,6 +824,8 @@ extern "C" int cgc_softmax_bwd(const float* S, const float* dS, int n, int C, in
 // max readout per graph (with the implicit zero padding rows of the dense layout)
 // ------------------------------------------------------------------------------------------------
 #define SEGMAX_WAVES 16
+// one workgroup per (graph, 64-column group); with D <= 32 columns a wave carries 64 / D' rows at a time (D' = D rounded up to a
+// power of two) instead of idling 44 of its 64 lanes on the 20-column readouts of this network
 __global__ __launch_bounds__(64 * SEGMAX_WAVES) void k_segment_max_fwd(const float* __restrict__ x, const int* __restrict__ gptr,
                                                                        int D, int nmax, float* __restrict__ out,
                                                                        int* __restrict__ arg) {
@@ -831,24 +833,28 @@ __global__ __launch_bounds__(64 * SEGMAX_WAVES) void k_segment_max_fwd(const flo
   __shared__ int bi[SEGMAX_WAVES][64];
   const int b = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int d = blockIdx.y * 64 + lane;
+  int dp = 64;                                         // lanes per row
+  if (D <= 32) dp = D <= 2 ? 2 : D <= 4 ? 4 : D <= 8 ? 8 : D <= 16 ? 16 : 32;
+  const int rpw = 64 / dp, sub = lane / dp, dl = lane - sub * dp;
+  const int d = blockIdx.y * 64 + dl;
   const int lo = gptr[b], hi = gptr[b + 1];
   float best = -INFINITY;
   int idx = -1;
   if (d < D)
-    for (int r = lo + wave; r < hi; r += SEGMAX_WAVES) {   // increasing rows + strict '>' keeps the FIRST maximum
+    for (int r = lo + wave * rpw + sub; r < hi; r += SEGMAX_WAVES * rpw) {   // increasing rows + strict '>' keeps the FIRST maximum
       const float v = x[(size_t)r * D + d];
       if (v > best) { best = v; idx = r; }
     }
   bv[wave][lane] = best;
   bi[wave][lane] = idx;
   __syncthreads();
-  if (wave == 0 && d < D) {
-    for (int w = 1; w < SEGMAX_WAVES; ++w) {
-      const float v = bv[w][lane];
-      const int i = bi[w][lane];
-      if (i >= 0 && (v > best || (v == best && i < idx) || idx < 0)) { best = v; idx = i; }
-    }
+  if (wave == 0 && sub == 0 && d < D) {
+    for (int w = 0; w < SEGMAX_WAVES; ++w)
+      for (int s2 = (w == 0 ? 1 : 0); s2 < rpw; ++s2) {
+        const float v = bv[w][s2 * dp + dl];
+        const int i = bi[w][s2 * dp + dl];
+        if (i >= 0 && (v > best || (v == best && i < idx) || idx < 0)) { best = v; idx = i; }
+      }
     if (idx < 0) { best = 0.f; }                                   // empty graph: only padding rows
     else if (hi - lo < nmax && best < 0.f) { best = 0.f; idx = -1; }  // a zero padding row wins (ties go to the real row)
     out[(size_t)b * D + d] = best;
