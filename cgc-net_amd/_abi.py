@@ -21,6 +21,9 @@ PROTOTYPES = {
     'cgc_spmm_graphs_ordered': [P, P, P, P, P, P, P, P, I, I, I, P, I, I, I, P, P],
     'cgc_gemm_f32': [I, I, I, I, I, F, P, I, P, I, F, P, I, P, I, L, L, L, P, I, I, P],
     'cgc_gemm_f32_cat': [I, I, I, I, I, F, P, I, P, I, F, P, I, P, I, L, L, L, P, I, I, I, P, P, P, P, P, P, P, P],
+    'cgc_gemm_ws_floats': [],
+    'cgc_gemm_f32_ws': [I, I, I, I, I, F, P, I, P, I, F, P, I, P, I, L, L, L, P, I, I, P, L, P],
+    'cgc_gemm_f32_cat_ws': [I, I, I, I, I, F, P, I, P, I, F, P, I, P, I, L, L, L, P, I, I, I, P, P, P, P, P, P, P, P, L, P],
     'cgc_gemm_tuning': [I],
     'cgc_reduce_batch_sum': [P, P, I, L, F, P],
     'cgc_reduce_batched': [P, P, I, I, I, F, P],

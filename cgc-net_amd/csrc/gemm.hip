@@ -35,7 +35,13 @@ struct GemmArgs {
   float alpha, beta;
   int ragged;
   int tiles_n;
-  int map_mode;   // bit 0: compact tile list for ragged M, bit 1: K-balanced dealing for ragged K (gemm_map_tile)
+  int map_mode;   // bit 0: compact tile list for ragged M, bit 1: K-balanced dealing for ragged K (TileMap)
+  int per_batch;  // tiles of one batch item at the largest extent; the 1-D grid holds per_batch * nb ids (+ tail pieces)
+  int nb;         // batch items
+  // tail split (see TileMap): slabs of raw accumulators for the pieces of the tail tiles; nullptr = every tile is computed whole
+  float* ws;
+  int resident;   // workgroups the chip holds at once = the quantum of a "round"
+  int s_max;      // most pieces a tail tile is cut into
   // optional extra K segments: C += alpha * A_x[s] * B_x[s] (same op() orientation, M, N as the main pair), i.e. the
   // product of the column-concatenated [A | A_x0 | A_x1] with the row-concatenated [B ; B_x0 ; B_x1] without ever
   // materialising the concatenation (Linear over cat[x1,x2,x3]; dS = P dA'^T + X dX'^T)
@@ -47,6 +53,7 @@ struct GemmArgs {
 };
 
 #define BK 32
+enum { PH_FULL = 0, PH_MASK = 1, PH_STORE = 2, PH_LAST = 3, PH_ANY = 4 };   // flavours of a k-loop phase (k_gemm_f32)
 #define KC_LD 36   // LDS row stride (words) of a row-major [mn][k] tile: 16-byte aligned rows, conflict-free ds_read_b128
 
 // Loader for an operand tile whose K index is the CONTIGUOUS one in memory (A stored [M,K]; B stored [N,K]).
@@ -207,50 +214,141 @@ __device__ __forceinline__ void fetch_frag(const float* __restrict__ tile, int k
 //   * ragged K (per-graph reduction length): every graph has the same tiles but a different duration.  Graphs are ranked by
 //     K and dealt to the XCDs in serpentine order (longest first), so that the sums of K per XCD agree within ~1 %
 //     (batch a multiple of 8, <= 64; otherwise the plain cut).
+//
+// TAIL SPLIT (round 3).  T tiles on R resident workgroups run in ceil(T / R) rounds, and the last round is as long as the others
+// however few tiles it holds: 4140 tiles (the step's big products at 32 graphs) on 512 slots are 8.09 -> 9 rounds, 522 tiles
+// (4 graphs per GPU, the strong-scaling shard) 1.02 -> 2.  With a slab workspace the L = T mod R tiles of the last round (all T
+// when T < R) are cut along K into S ~ R / L pieces each; a piece parks its raw accumulators in its slab and k_gemm_fixup adds a
+// tile's S slabs in a fixed order and applies alpha / beta / bias -- the launch-boundary reduce: deterministic, no flags, no
+// spinning.  The L * S pieces fill one round of 1/S the length.  Tail tiles are taken evenly from the END of every XCD's run
+// (the whole-tile part stays a multiple of R, i.e. of 8).  Which tiles are split is a function of (T, R, s_max) only, computed
+// the same way by both kernels.
 template <int BM>
-__device__ __forceinline__ bool gemm_map_tile(const GemmArgs& a, int& b, int& tile_id) {
-  const unsigned per_batch = gridDim.x, nb = gridDim.z, total = per_batch * nb;
-  const unsigned lin = blockIdx.z * per_batch + blockIdx.x;
-  const unsigned xcd = lin & 7u, slot = lin >> 3;
-  const int lane = threadIdx.x & 63;
-  if (a.ragged == 1 && nb <= 64 && (a.map_mode & 1)) {
-    const int ext = lane < (int)nb ? a.gptr[lane + 1] - a.gptr[lane] : 0;
-    const int t = (ext + BM - 1) / BM;                     // m-tile rows of graph `lane`
-    int incl = t;
-    for (int o = 1; o < 64; o <<= 1) {
-      const int up = __shfl_up(incl, o);
-      if (lane >= o) incl += up;
+struct TileMap {
+  int mode;                 // 0 plain cut, 1 compact list (ragged M), 2 serpentine by K (ragged K)
+  unsigned T, Tdp, L, S;    // real tiles; tiles computed whole; tail tiles; pieces per tail tile
+  unsigned q8, r8;          // every XCD owns q8 (+1 for the first r8) consecutive tile ids
+  int incl, t, rank;        // per-lane state of modes 1 / 2
+  __device__ __forceinline__ void init(const GemmArgs& a, int lane) {
+    const unsigned nb = a.nb;
+    mode = 0;
+    incl = t = rank = 0;
+    T = (unsigned)a.per_batch * nb;
+    if (a.ragged == 1 && nb <= 64 && (a.map_mode & 1)) {
+      mode = 1;
+      const int ext = lane < (int)nb ? a.gptr[lane + 1] - a.gptr[lane] : 0;
+      t = (ext + BM - 1) / BM;                     // m-tile rows of graph `lane`
+      incl = t;
+      for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(incl, o);
+        if (lane >= o) incl += up;
+      }
+      T = (unsigned)__shfl(incl, 63) * a.tiles_n;  // real tiles of the launch
+    } else if (a.ragged == 2 && nb <= 64 && (nb & 7u) == 0 && (a.map_mode & 2)) {
+      mode = 2;
+      const int ext = lane < (int)nb ? a.gptr[lane + 1] - a.gptr[lane] : -1;
+      for (int j = 0; j < (int)nb; ++j) {
+        const int ej = __shfl(ext, j);
+        rank += (ej > ext || (ej == ext && j < lane)) ? 1 : 0;
+      }
     }
-    const unsigned T = (unsigned)__shfl(incl, 63) * a.tiles_n;      // real tiles of the launch
-    const unsigned q8 = T >> 3, r8 = T & 7u;
-    if (slot >= q8 + (xcd < r8 ? 1u : 0u)) return false;
-    const unsigned cid = xcd * q8 + (xcd < r8 ? xcd : r8) + slot;
-    const int row = cid / a.tiles_n;
-    b = __popcll(__ballot(incl <= row));                    // graphs that end at or before this row
-    const int first = __shfl(incl - t, b);
-    tile_id = (row - first) * a.tiles_n + (cid - row * a.tiles_n);
+    q8 = T >> 3;
+    r8 = T & 7u;
+    Tdp = T;
+    L = 0;
+    S = 1;
+    if (a.ws != nullptr && a.resident > 0 && T > 0) {
+      const unsigned R = a.resident;
+      const unsigned l = T < R ? T : T % R;
+      if (l > 0) {
+        unsigned s = (R + l / 2) / l;
+        if (s > (unsigned)a.s_max) s = a.s_max;
+        if (s >= 2) {
+          L = l;
+          S = s;
+          Tdp = T - l;
+        }
+      }
+    }
+  }
+  // tail tile j (0 <= j < L) -> its place (XCD, slot) in the runs: the slots behind the whole-tile part, XCD fastest
+  __device__ __forceinline__ void tail_slot(unsigned j, unsigned& xcd, unsigned& slot) const {
+    const unsigned qd = Tdp >> 3, common = (q8 - qd) * 8u;
+    if (j < common) {
+      xcd = j & 7u;
+      slot = qd + (j >> 3);
+    } else {
+      xcd = j - common;
+      slot = q8;
+    }
+  }
+  __device__ __forceinline__ void locate(const GemmArgs& a, unsigned xcd, unsigned slot, int lane, int& b, int& tile_id) const {
+    if (mode == 1) {
+      const unsigned cid = xcd * q8 + (xcd < r8 ? xcd : r8) + slot;
+      const int row = cid / a.tiles_n;
+      b = __popcll(__ballot(incl <= row));                    // graphs that end at or before this row
+      const int first = __shfl(incl - t, b);
+      tile_id = (row - first) * a.tiles_n + (cid - row * a.tiles_n);
+    } else if (mode == 2) {
+      const unsigned per_batch = a.per_batch;
+      const unsigned p = slot / per_batch;
+      const unsigned q = p * 8 + ((p & 1u) ? 7u - xcd : xcd);
+      b = __ffsll((unsigned long long)__ballot(lane < a.nb && rank == (int)q)) - 1;
+      tile_id = slot - p * per_batch;
+    } else {
+      const unsigned vb = xcd * q8 + (xcd < r8 ? xcd : r8) + slot;
+      b = vb / a.per_batch;
+      tile_id = vb - b * a.per_batch;
+    }
+  }
+  // workgroup `lin` of the main kernel: a whole tile (S_out = 1) or piece `piece` of tail tile `tj`
+  __device__ __forceinline__ bool select(const GemmArgs& a, unsigned lin, int lane, int& b, int& tile_id, unsigned& tj, int& piece,
+                                         int& S_out) const {
+    unsigned xcd, slot;
+    tj = 0;
+    piece = 0;
+    S_out = 1;
+    if (lin < Tdp) {
+      xcd = lin & 7u;
+      slot = lin >> 3;
+    } else {
+      const unsigned j = lin - Tdp;
+      if (j >= L * S) return false;
+      tj = j / S;
+      piece = j - tj * S;
+      S_out = S;
+      tail_slot(tj, xcd, slot);
+    }
+    locate(a, xcd, slot, lane, b, tile_id);
     return true;
   }
-  if (a.ragged == 2 && nb <= 64 && (nb & 7u) == 0 && (a.map_mode & 2)) {
-    const int ext = lane < (int)nb ? a.gptr[lane + 1] - a.gptr[lane] : -1;
-    int rank = 0;
-    for (int j = 0; j < (int)nb; ++j) {
-      const int ej = __shfl(ext, j);
-      rank += (ej > ext || (ej == ext && j < lane)) ? 1 : 0;
+};
+
+// Operand / output bases and extents of batch item b (ragged: per-graph row offsets and extents from gptr)
+struct TileBase {
+  const float* A;
+  const float* B;
+  float* C;
+  int M, K;
+  __device__ __forceinline__ TileBase(const GemmArgs& a, int b) {
+    M = a.M;
+    K = a.K;
+    A = a.A + (size_t)b * a.strideA;
+    B = a.B + (size_t)b * a.strideB;
+    C = a.C + (size_t)b * a.strideC;
+    if (a.ragged == 1) {
+      const int g0 = a.gptr[b];
+      M = a.gptr[b + 1] - g0;
+      A += (size_t)g0 * a.lda;
+      C += (size_t)g0 * a.ldc;
+    } else if (a.ragged == 2) {
+      const int g0 = a.gptr[b];
+      K = a.gptr[b + 1] - g0;
+      A += (size_t)g0 * a.lda;
+      B += (size_t)g0 * a.ldb;
     }
-    const unsigned p = slot / per_batch;
-    if (p >= (nb >> 3)) return false;
-    const unsigned q = p * 8 + ((p & 1u) ? 7u - xcd : xcd);
-    b = __ffsll((unsigned long long)__ballot(lane < (int)nb && rank == (int)q)) - 1;
-    tile_id = slot - p * per_batch;
-    return true;
   }
-  const unsigned q8 = total >> 3, r8 = total & 7u;
-  const unsigned vb = xcd * q8 + (xcd < r8 ? xcd : r8) + slot;
-  b = vb / per_batch;
-  tile_id = vb - b * per_batch;
-  return true;
-}
+};
 
 
 // Epilogue shared by the kernels below.  The MFMAs are issued with the operands SWAPPED (B fragment first), i.e. every
@@ -336,7 +434,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, float* __restri
   }
 }
 
-template <int WGM, int WGN, int TM, int TN, bool TA, bool TB>
+// FAST: every operand segment qualifies for the unguarded 16-byte loaders (decided on the host, gemm_all_fast): the kernel then
+// contains no guarded loader and no conditional inside a k-loop phase.  !FAST: the guarded element-wise loaders throughout.
+template <int WGM, int WGN, int TM, int TN, bool TA, bool TB, bool FAST>
 __global__ __launch_bounds__(256, 2) void k_gemm_f32(const GemmArgs a) {   // 2 waves per SIMD = 2 workgroups per CU (the LDS budget)
   constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
   constexpr int LDA_S = TA ? BM + 4 : KC_LD;   // TA: A stored [K,M] -> k-major tile; else row-major [m][k]
@@ -346,23 +446,24 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const GemmArgs a) {   // 2 
   float* const As0 = lds;                 // As[buf] = As0 + buf*A_SZ
   float* const Bs0 = lds + 2 * A_SZ;      // Bs[buf] = Bs0 + buf*B_SZ
 
-  int b, tile_id;
-  if (!gemm_map_tile<BM>(a, b, tile_id)) return;
-  int M = a.M, K = a.K;
-  const float* A = a.A + (size_t)b * a.strideA;
-  const float* B = a.B + (size_t)b * a.strideB;
-  float* C = a.C + (size_t)b * a.strideC;
-  if (a.ragged == 1) {
-    const int g0 = a.gptr[b];
-    M = a.gptr[b + 1] - g0;
-    A += (size_t)g0 * a.lda;
-    C += (size_t)g0 * a.ldc;
-  } else if (a.ragged == 2) {
-    const int g0 = a.gptr[b];
-    K = a.gptr[b + 1] - g0;
-    A += (size_t)g0 * a.lda;
-    B += (size_t)g0 * a.ldb;
+  int b, tile_id, piece, S;
+  unsigned tj;
+  {
+    TileMap<BM> map;
+    map.init(a, threadIdx.x & 63);
+    if (!map.select(a, blockIdx.x, threadIdx.x & 63, b, tile_id, tj, piece, S)) return;
   }
+  // wave-uniform by construction; said explicitly so that everything derived from them (k range, tile origin) lives in SGPRs
+  b = __builtin_amdgcn_readfirstlane(b);
+  tile_id = __builtin_amdgcn_readfirstlane(tile_id);
+  piece = __builtin_amdgcn_readfirstlane(piece);
+  S = __builtin_amdgcn_readfirstlane(S);
+  tj = __builtin_amdgcn_readfirstlane(tj);
+  const TileBase tb(a, b);
+  const int M = tb.M, K = tb.K;
+  const float* A = tb.A;
+  const float* B = tb.B;
+  float* C = tb.C;
   const int tile_m = tile_id / a.tiles_n, tile_n = tile_id - tile_m * a.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   if (m0 >= M) return;
@@ -404,6 +505,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const GemmArgs a) {   // 2 
     }
   }
   const int nk = nk_main + nkx0 + nkx1;
+  // this workgroup's share of the k-tiles: all of them, or piece `piece` of S (tail split)
+  const int kbeg = S > 1 ? (int)(((long long)nk * piece) / S) : 0;
+  const int kend = S > 1 ? (int)(((long long)nk * (piece + 1)) / S) : nk;
   // unguarded 16-byte loads for full k-tiles when the layout allows (block-uniform decision)
   // (an extent that is not a multiple of 4 is fine: with a row stride that IS one -- vecA / vecB -- the 16-byte group that
   // straddles the edge stays inside its row's stride: padding, whose values only reach output rows / columns that are never
@@ -416,6 +520,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const GemmArgs a) {   // 2 
   const int K4 = (K + 3) & ~3;
   const bool k4A = K >= 1 && (TA ? true : a.lda >= K4), k4B = K >= 1 && (TB ? a.ldb >= K4 : true);
   auto fetch = [&](LoaderA& la, LoaderB& lb, int kt) {
+   if constexpr (!FAST) {                 // (the guarded loaders do not exist in the FAST kernel)
     if (kt < nk_main) {
       if (fastA && kt < nk_full) la.load_fast(A, a.lda, m0, a_last, kt * BK);
       else if (fastA && k4A) la.load_fast_masked(A, a.lda, m0, a_last, kt * BK, K);
@@ -439,23 +544,57 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const GemmArgs a) {   // 2 
       if (vb && (TB ? kx4 : (N % 4 == 0 && N >= 4))) lb.load_fast_masked(Bx, ldbx, n0, b_last, kx * BK, Kx);
       else lb.load(Bx, ldbx, n0, N, kx * BK, Kx, vb);
     }
+   }
+  };
+  // Branch-free fetch of ANY k-tile -- a full or partial tile of the main operand pair or of an extra K segment -- for the
+  // prologue and the tail of the k loop: the segment (base pointers, row strides, reduction length) is picked with scalar
+  // selects and both operands take the masked unguarded loads.  Valid when every segment qualifies (FAST).
+  // (the kernel arguments are read into opaque scalars first: a select between two FIELDS of the argument struct is otherwise
+  // turned into a select between their addresses, and the compiler then copies the whole struct to scratch memory)
+  auto sgpr = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+  const int lda0 = sgpr(a.lda), ldb0 = sgpr(a.ldb);
+  const int xlda0 = sgpr(a.xlda[0]), xlda1 = sgpr(a.xlda[1]), xldb0 = sgpr(a.xldb[0]), xldb1 = sgpr(a.xldb[1]);
+  const int xK0 = sgpr(a.xK[0]), xK1 = sgpr(a.xK[1]);
+  auto fetch_seg = [&](LoaderA& la, LoaderB& lb, int kt) {
+    const int kx = kt - nk_main;
+    const bool in_main = kx < 0, in_x0 = kx < nkx0;
+    const float* Ap = in_main ? A : in_x0 ? xA0 : xA1;
+    const float* Bp = in_main ? B : in_x0 ? xB0 : xB1;
+    const int lda_ = in_main ? lda0 : in_x0 ? xlda0 : xlda1;
+    const int ldb_ = in_main ? ldb0 : in_x0 ? xldb0 : xldb1;
+    const int Ks = in_main ? K : in_x0 ? xK0 : xK1;
+    const int k0 = (in_main ? kt : in_x0 ? kx : kx - nkx0) * BK;
+    la.load_fast_masked(Ap, lda_, m0, a_last, k0, Ks);
+    lb.load_fast_masked(Bp, ldb_, n0, b_last, k0, Ks);
   };
   // One k-tile: consume LDS buffer `cur` with 4 groups of TM*TN*4 MFMAs.  The fragments of group kb+1 are read from LDS
   // before the MFMAs of group kb are issued; between the groups a quarter of the NEXT tile (already in registers `ls_*`)
   // is written into the other LDS buffer; the tile after that is requested from memory at the top and lands in `ll_*`
-  // while all of this runs.  One barrier per k-tile.  STEADY = interior of the k loop: no conditionals at all (every
-  // load is an unguarded 16-byte load, every store happens), so the compiler can count vmcnt/lgkmcnt exactly and
-  // interleave freely.
-  auto phase = [&](auto steady, int kt, auto cur_c, LoaderA& ls_a, LoaderB& ls_b, LoaderA& ll_a, LoaderB& ll_b) {
-    constexpr bool STEADY = decltype(steady)::value;
+  // while all of this runs.  One barrier per k-tile.  The phase comes in compile-time flavours so that NO flavour but the
+  // generic one has a conditional inside (the compiler then counts vmcnt / lgkmcnt exactly and interleaves freely):
+  //   PH_FULL   interior of the main operand pair: tile kt+2 is a full tile, unguarded 16-byte loads
+  //   PH_MASK   tile kt+2 is anything (partial tile, extra segment): masked unguarded loads with scalar segment selection
+  //   PH_STORE  kt = kend-2: nothing left to request, tile kt+1 is written to LDS
+  //   PH_LAST   kt = kend-1: compute only
+  //   PH_ANY    operands that do not qualify for unguarded loads (odd strides, unaligned views): guarded element-wise loaders
+  // (round 2 ran the last four to six phases of every output tile -- and every phase of a short piece -- through the generic
+  // flavour: measured at ~3x the time of an interior phase, e.g. the K = 40 segment of the assignment Linear cost 220 us of
+  // a 1.45 ms launch.)
+  auto phase = [&](auto mode_c, int kt, auto cur_c, LoaderA& ls_a, LoaderB& ls_b, LoaderA& ll_a, LoaderB& ll_b) {
+    constexpr int MODE = decltype(mode_c)::value;
     constexpr int cur = decltype(cur_c)::value;
-    if (STEADY) {
+    bool has_next = true;
+    if constexpr (MODE == PH_FULL) {
       ll_a.load_fast(A, a.lda, m0, a_last, (kt + 2) * BK);
       ll_b.load_fast(B, a.ldb, n0, b_last, (kt + 2) * BK);
-    } else if (kt + 2 < nk) {
-      fetch(ll_a, ll_b, kt + 2);
+    } else if constexpr (MODE == PH_MASK) {
+      fetch_seg(ll_a, ll_b, kt + 2);
+    } else if constexpr (MODE == PH_ANY) {
+      if (kt + 2 < kend) fetch(ll_a, ll_b, kt + 2);
+      has_next = kt + 1 < kend;
+    } else if constexpr (MODE == PH_LAST) {
+      has_next = false;
     }
-    const bool has_next = STEADY || kt + 1 < nk;
     const float* as = As0 + cur * A_SZ + (TA ? wm * TM * 32 : wm * TM * 32 * KC_LD);
     const float* bs = Bs0 + cur * B_SZ + (TB ? wn * TN * 32 * KC_LD : wn * TN * 32);
     float* an = As0 + (cur ^ 1) * A_SZ;
@@ -487,33 +626,135 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const GemmArgs a) {   // 2 
     }
     __syncthreads();
   };
-  typedef std::integral_constant<bool, true> T_;
-  typedef std::integral_constant<bool, false> F_;
+  typedef std::integral_constant<int, PH_FULL> FULL_;
+  typedef std::integral_constant<int, PH_MASK> MASK_;
+  typedef std::integral_constant<int, PH_STORE> STORE_;
+  typedef std::integral_constant<int, PH_LAST> LAST_;
+  typedef std::integral_constant<int, PH_ANY> ANY_;
   typedef std::integral_constant<int, 0> B0;
   typedef std::integral_constant<int, 1> B1;
 
-  if (nk > 0) {
-    fetch(la0, lb0, 0);
-    la0.store(As0);
-    lb0.store(Bs0);
-    if (nk > 1) fetch(la0, lb0, 1);
-  }
-  __syncthreads();
-  int kt = 0;
-  if (fastA && fastB) {
-    for (; kt + 3 < nk_full; kt += 2) {      // both phases prefetch full tiles (kt+2, kt+3 < nk_full)
-      phase(T_(), kt, B0(), la0, lb0, la1, lb1);
-      phase(T_(), kt + 1, B1(), la1, lb1, la0, lb0);
+  if constexpr (FAST) {
+    if (kend > kbeg) {
+      fetch_seg(la0, lb0, kbeg);
+      la0.store(As0);
+      lb0.store(Bs0);
+      if (kbeg + 1 < kend) fetch_seg(la0, lb0, kbeg + 1);
+    }
+    __syncthreads();
+    int kt = kbeg;
+    const int fast_end = nk_full < kend ? nk_full : kend;
+    for (; kt + 3 < fast_end; kt += 2) {     // both phases prefetch full tiles of the main pair (kt+2, kt+3 < nk_full)
+      phase(FULL_(), kt, B0(), la0, lb0, la1, lb1);
+      phase(FULL_(), kt + 1, B1(), la1, lb1, la0, lb0);
+    }
+    // the last tiles, still without a conditional inside a phase; even steps consume LDS buffer 0 and hand tile kt+1 over from
+    // the register stage (la0, lb0), odd steps the other way round
+    for (;;) {
+      if (kt + 2 < kend) {
+        phase(MASK_(), kt, B0(), la0, lb0, la1, lb1);
+      } else {
+        if (kt + 1 < kend) {
+          phase(STORE_(), kt, B0(), la0, lb0, la1, lb1);
+          phase(LAST_(), kt + 1, B1(), la1, lb1, la0, lb0);
+        } else if (kt < kend) {
+          phase(LAST_(), kt, B0(), la0, lb0, la1, lb1);
+        }
+        break;
+      }
+      ++kt;
+      if (kt + 2 < kend) {
+        phase(MASK_(), kt, B1(), la1, lb1, la0, lb0);
+      } else {
+        if (kt + 1 < kend) {
+          phase(STORE_(), kt, B1(), la1, lb1, la0, lb0);
+          phase(LAST_(), kt + 1, B0(), la0, lb0, la1, lb1);
+        } else {
+          phase(LAST_(), kt, B1(), la1, lb1, la0, lb0);
+        }
+        break;
+      }
+      ++kt;
+    }
+  } else {
+    if (kend > kbeg) {
+      fetch(la0, lb0, kbeg);
+      la0.store(As0);
+      lb0.store(Bs0);
+      if (kbeg + 1 < kend) fetch(la0, lb0, kbeg + 1);
+    }
+    __syncthreads();
+    int kt = kbeg;
+    if (fastA && fastB) {
+      const int fast_end = nk_full < kend ? nk_full : kend;
+      for (; kt + 3 < fast_end; kt += 2) {
+        phase(FULL_(), kt, B0(), la0, lb0, la1, lb1);
+        phase(FULL_(), kt + 1, B1(), la1, lb1, la0, lb0);
+      }
+    }
+    for (; kt < kend; kt += 2) {
+      phase(ANY_(), kt, B0(), la0, lb0, la1, lb1);
+      if (kt + 1 < kend) phase(ANY_(), kt + 1, B1(), la1, lb1, la0, lb0);
     }
   }
-  for (; kt < nk; kt += 2) {                  // generic tail (or whole loop when a fast path is not available)
-    phase(F_(), kt, B0(), la0, lb0, la1, lb1);
-    if (kt + 1 < nk) phase(F_(), kt + 1, B1(), la1, lb1, la0, lb0);
-  }
 
+  if (S > 1) {
+    // piece of a tail tile: the raw accumulators go to this piece's slab (k_gemm_fixup adds the S slabs of the tile and applies
+    // alpha / beta / bias).  Slab order = register order, 16 bytes per lane: every store instruction writes 1 KiB contiguous.
+    float* slab = a.ws + ((size_t)tj * S + piece) * (size_t)(BM * BN) + (size_t)wave * (TM * TN * 16 * 64) + lane * 4;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<float4*>(slab + ((i * TN + j) * 4 + g) * 256) =
+              make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+    return;
+  }
   // epilogue (the last phase ended with a barrier: nobody reads operand tiles any more, the LDS is free for the parking strips)
   static_assert(4 * 32 * (TN * 32 + 4) <= 2 * A_SZ + 2 * B_SZ, "epilogue parking region exceeds the operand LDS");
   gemm_epilogue<TM, TN>(a, C, M, N, m0 + wm * TM * 32, n0 + wn * TN * 32, acc, lds + wave * 32 * (TN * 32 + 4), lane);
+}
+
+// Second half of the tail split: one workgroup per tail tile adds the tile's S slabs in piece order (fixed: the result does not
+// depend on which piece finished first) in the thread geometry of k_gemm_f32 and runs the same epilogue.
+template <int WGM, int WGN, int TM, int TN>
+__global__ __launch_bounds__(256) void k_gemm_fixup(const GemmArgs a) {
+  constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
+  __shared__ __attribute__((aligned(16))) float park[4 * 32 * (TN * 32 + 4)];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  TileMap<BM> map;
+  map.init(a, lane);
+  const unsigned tj = blockIdx.x;
+  if (tj >= map.L) return;
+  unsigned xcd, slot;
+  map.tail_slot(tj, xcd, slot);
+  int b, tile_id;
+  map.locate(a, xcd, slot, lane, b, tile_id);
+  const TileBase tb(a, b);
+  const int tile_m = tile_id / a.tiles_n, tile_n = tile_id - tile_m * a.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  if (m0 >= tb.M) return;
+  const int wm = wave / WGN, wn = wave - wm * WGN;
+  const int S = map.S;
+  floatx16 acc[TM][TN];
+  const float* slab = a.ws + (size_t)tj * S * (size_t)(BM * BN) + (size_t)wave * (TM * TN * 16 * 64) + lane * 4;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float* q = slab + ((i * TN + j) * 4 + g) * 256;
+        float4 v = *reinterpret_cast<const float4*>(q);
+        for (int p = 1; p < S; ++p) {
+          const float4 w = *reinterpret_cast<const float4*>(q + (size_t)p * (BM * BN));
+          v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+        }
+        acc[i][j][4 * g] = v.x; acc[i][j][4 * g + 1] = v.y; acc[i][j][4 * g + 2] = v.z; acc[i][j][4 * g + 3] = v.w;
+      }
+  gemm_epilogue<TM, TN>(a, tb.C, tb.M, a.N, m0 + wm * TM * 32, n0 + wn * TN * 32, acc, park + wave * 32 * (TN * 32 + 4), lane);
 }
 
 template <int WGM, int WGN, int TM, int TN, bool TA, bool TB>
@@ -528,22 +769,20 @@ __global__ __launch_bounds__(256, 3) void k_gemm_f32_shortk(const GemmArgs a) {
   float* const Bs0 = lds + A_SZ;
 
   int b, tile_id;
-  if (!gemm_map_tile<BM>(a, b, tile_id)) return;
-  int M = a.M, K = a.K;
-  const float* A = a.A + (size_t)b * a.strideA;
-  const float* B = a.B + (size_t)b * a.strideB;
-  float* C = a.C + (size_t)b * a.strideC;
-  if (a.ragged == 1) {
-    const int g0 = a.gptr[b];
-    M = a.gptr[b + 1] - g0;
-    A += (size_t)g0 * a.lda;
-    C += (size_t)g0 * a.ldc;
-  } else if (a.ragged == 2) {
-    const int g0 = a.gptr[b];
-    K = a.gptr[b + 1] - g0;
-    A += (size_t)g0 * a.lda;
-    B += (size_t)g0 * a.ldb;
+  {
+    TileMap<BM> map;
+    int piece, S;
+    unsigned tj;
+    map.init(a, threadIdx.x & 63);      // (a.ws is never set for this kernel: every tile is computed whole)
+    if (!map.select(a, blockIdx.x, threadIdx.x & 63, b, tile_id, tj, piece, S)) return;
   }
+  b = __builtin_amdgcn_readfirstlane(b);
+  tile_id = __builtin_amdgcn_readfirstlane(tile_id);
+  const TileBase tb(a, b);
+  const int M = tb.M, K = tb.K;
+  const float* A = tb.A;
+  const float* B = tb.B;
+  float* C = tb.C;
   const int tile_m = tile_id / a.tiles_n, tile_n = tile_id - tile_m * a.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   if (m0 >= M) return;
@@ -615,27 +854,86 @@ __global__ __launch_bounds__(256, 3) void k_gemm_f32_shortk(const GemmArgs a) {
   gemm_epilogue<TM, TN>(a, C, M, N, m0 + wm * TM * 32, n0 + wn * TN * 32, acc, lds + wave * 32 * (TN * 32 + 4), lane);
 }
 
+// Whether every operand segment of the product qualifies for the unguarded 16-byte loaders of k_gemm_f32<.., FAST = true>:
+// 16-byte-aligned bases (also after the per-batch stride and the per-graph row offset), row strides that are multiples of 4
+// floats, and rows long enough to hold the 16-byte group that straddles the end of an extent that is not a multiple of 4 (its
+// surplus elements only reach output rows / columns that are never stored, or k positions that the loader zeroes).  The ragged
+// extent (M of ragged 1, K of ragged 2) is always the ROW index of the operands it applies to, never the contiguous one.
+static bool gemm_all_fast(const GemmArgs& a, int transA, int transB, int batch) {
+  auto up4 = [](int v) { return (v + 3) & ~3; };
+  auto seg = [&](const float* A, const float* B, int lda, int ldb, long long sA, long long sB, int K) {
+    if (lda % 4 != 0 || ldb % 4 != 0 || !aligned16(A) || !aligned16(B)) return false;
+    if (batch > 1 && (sA % 4 != 0 || sB % 4 != 0)) return false;
+    if (transA ? lda < up4(a.M) : lda < up4(K)) return false;      // (ragged 1: transA = 0; ragged 2: transA = 1, K is the row index)
+    if (transB ? ldb < up4(K) : ldb < up4(a.N)) return false;
+    return true;
+  };
+  if (!seg(a.A, a.B, a.lda, a.ldb, a.strideA, a.strideB, a.ragged == 2 ? 0 : a.K)) return false;
+  for (int i = 0; i < a.nx; ++i)
+    if (!seg(a.xA[i], a.xB[i], a.xlda[i], a.xldb[i], a.xsA[i], a.xsB[i], a.xK[i])) return false;
+  return true;
+}
+
+// Workgroups of k_gemm_f32 the chip holds at once: 2 per CU (LDS: 73.7 KB for the 128 x 128 tile; __launch_bounds__(256, 2))
+static const int kResident = 512;
+// slab workspace the tail split may use (floats): up to 1.5 * kResident pieces of one 128 x 128 tile
+extern "C" int64_t cgc_gemm_ws_floats(void) { return (int64_t)(kResident + kResident / 2) * 128 * 128; }
+
 template <int WGM, int WGN, int TM, int TN>
-static int launch_cfg(const GemmArgs& a0, int transA, int transB, int batch, int m_extent, bool short_k, hipStream_t stream) {
+static int launch_cfg(const GemmArgs& a0, int transA, int transB, int batch, int m_extent, int k_extent, bool short_k, float* ws,
+                      int64_t ws_floats, hipStream_t stream) {
   constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
   GemmArgs a = a0;
   a.tiles_n = ceil_div(a.N, BN);
   static const int map_mode = getenv("CGC_GEMM_MAP") ? atoi(getenv("CGC_GEMM_MAP")) : 3;
   a.map_mode = map_mode;
-  const long long tiles = (long long)ceil_div(m_extent, BM) * a.tiles_n;
-  if (tiles <= 0 || tiles > 0x7fffffffLL || batch > 65535) return CGC_EINVAL;
-  dim3 grid((unsigned)tiles, 1, (unsigned)batch), block(256);
+  const long long per_batch = (long long)ceil_div(m_extent, BM) * a.tiles_n;
+  const long long tiles = per_batch * batch;
+  if (per_batch <= 0 || tiles > 0x7ffffff0LL) return CGC_EINVAL;
+  a.per_batch = (int)per_batch;
+  a.nb = batch;
+  a.ws = nullptr;
+  a.resident = 0;
+  a.s_max = 1;
   if (transA && transB) return CGC_EINVAL;
+  // tail split: pipelined kernel only, long reductions only (a piece keeps >= 3 k-tiles), slabs must fit the workspace
+  static const int split_on = getenv("CGC_GEMM_SPLIT") ? atoi(getenv("CGC_GEMM_SPLIT")) : 1;
+  int extra = 0;
+  if (!short_k && ws != nullptr && split_on) {
+    long long kt = ceil_div(k_extent, BK);
+    for (int i = 0; i < a.nx; ++i) kt += ceil_div(a.xK[i], BK);
+    const int s_max = (int)(kt / 3 < 12 ? kt / 3 : 12);
+    const long long max_pieces = kResident + kResident / 2;            // L * S <= 1.5 R by construction (TileMap::init)
+    if (s_max >= 2 && max_pieces * BM * BN <= ws_floats) {
+      a.ws = ws;
+      a.resident = kResident;
+      a.s_max = s_max;
+      extra = (int)max_pieces;
+    }
+  }
+  dim3 grid((unsigned)(tiles + extra)), block(256);
+  static const int fast_on = getenv("CGC_GEMM_FAST") ? atoi(getenv("CGC_GEMM_FAST")) : 0;   // experiment (see k_gemm_f32): off
+  const bool fast = fast_on && gemm_all_fast(a, transA, transB, batch);
   if (short_k) {
     if (!transA && !transB) hipLaunchKernelGGL((k_gemm_f32_shortk<WGM, WGN, TM, TN, false, false>), grid, block, 0, stream, a);
     else if (!transA) hipLaunchKernelGGL((k_gemm_f32_shortk<WGM, WGN, TM, TN, false, true>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((k_gemm_f32_shortk<WGM, WGN, TM, TN, true, false>), grid, block, 0, stream, a);
+  } else if (fast) {
+    if (!transA && !transB) hipLaunchKernelGGL((k_gemm_f32<WGM, WGN, TM, TN, false, false, true>), grid, block, 0, stream, a);
+    else if (!transA) hipLaunchKernelGGL((k_gemm_f32<WGM, WGN, TM, TN, false, true, true>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((k_gemm_f32<WGM, WGN, TM, TN, true, false, true>), grid, block, 0, stream, a);
   } else {
-    if (!transA && !transB) hipLaunchKernelGGL((k_gemm_f32<WGM, WGN, TM, TN, false, false>), grid, block, 0, stream, a);
-    else if (!transA) hipLaunchKernelGGL((k_gemm_f32<WGM, WGN, TM, TN, false, true>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((k_gemm_f32<WGM, WGN, TM, TN, true, false>), grid, block, 0, stream, a);
+    if (!transA && !transB) hipLaunchKernelGGL((k_gemm_f32<WGM, WGN, TM, TN, false, false, false>), grid, block, 0, stream, a);
+    else if (!transA) hipLaunchKernelGGL((k_gemm_f32<WGM, WGN, TM, TN, false, true, false>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((k_gemm_f32<WGM, WGN, TM, TN, true, false, false>), grid, block, 0, stream, a);
   }
   CGC_RETURN_IF_LAUNCH_FAILED();
+  if (a.ws != nullptr) {
+    // at most min(T, R - 1) tail tiles; which ones (if any) is decided on the device exactly as in the kernel above
+    const long long lmax = tiles < kResident ? tiles : kResident - 1;
+    hipLaunchKernelGGL((k_gemm_fixup<WGM, WGN, TM, TN>), dim3((unsigned)lmax), block, 0, stream, a);
+    CGC_RETURN_IF_LAUNCH_FAILED();
+  }
   return 0;
 }
 
@@ -647,9 +945,13 @@ extern "C" int cgc_gemm_tuning(int cfg) {
   return old;
 }
 
-static int gemm_dispatch(GemmArgs& a, int transA, int transB, int batch, int max_ragged, hipStream_t stream) {
+static int gemm_dispatch(GemmArgs& a, int transA, int transB, int batch, int max_ragged, float* ws, int64_t ws_floats,
+                         hipStream_t stream) {
   const int M = a.M, N = a.N, K = a.K, ragged = a.ragged;
   if (batch <= 0 || N <= 0) return 0;
+  // the tail split is tuned for the 128 x 128 tile (512 resident workgroups); CGC_GEMM_SPLIT=2 lets every pipelined tile shape use it
+  static const int split_all = getenv("CGC_GEMM_SPLIT") ? atoi(getenv("CGC_GEMM_SPLIT")) >= 2 : 0;
+  float* const ws_any = split_all ? ws : nullptr;
   if (ragged == 1 && (transA || a.gptr == nullptr)) return CGC_EINVAL;
   if (ragged == 2 && (!transA || transB || a.gptr == nullptr || a.nx > 0)) return CGC_EINVAL;
   if (ragged < 0 || ragged > 2) return CGC_EINVAL;
@@ -668,32 +970,32 @@ static int gemm_dispatch(GemmArgs& a, int transA, int transB, int batch, int max
   if (force > 0) {
     const bool fsk = force >= 20 ? true : force >= 10 ? false : sk;
     switch (force % 10) {
-      case 1: return launch_cfg<2, 2, 2, 2>(a, transA, transB, batch, m_extent, fsk, stream);
-      case 2: return launch_cfg<4, 1, 1, 2>(a, transA, transB, batch, m_extent, fsk, stream);
-      case 3: return launch_cfg<1, 4, 2, 1>(a, transA, transB, batch, m_extent, fsk, stream);
-      case 4: return launch_cfg<2, 2, 1, 1>(a, transA, transB, batch, m_extent, fsk, stream);
-      case 5: return launch_cfg<4, 1, 1, 1>(a, transA, transB, batch, m_extent, fsk, stream);
-      case 6: return launch_cfg<1, 4, 1, 1>(a, transA, transB, batch, m_extent, fsk, stream);
+      case 1: return launch_cfg<2, 2, 2, 2>(a, transA, transB, batch, m_extent, k_extent, fsk, ws, ws_floats, stream);
+      case 2: return launch_cfg<4, 1, 1, 2>(a, transA, transB, batch, m_extent, k_extent, fsk, ws_any, ws_floats, stream);
+      case 3: return launch_cfg<1, 4, 2, 1>(a, transA, transB, batch, m_extent, k_extent, fsk, ws_any, ws_floats, stream);
+      case 4: return launch_cfg<2, 2, 1, 1>(a, transA, transB, batch, m_extent, k_extent, fsk, ws_any, ws_floats, stream);
+      case 5: return launch_cfg<4, 1, 1, 1>(a, transA, transB, batch, m_extent, k_extent, fsk, ws_any, ws_floats, stream);
+      case 6: return launch_cfg<1, 4, 1, 1>(a, transA, transB, batch, m_extent, k_extent, fsk, ws_any, ws_floats, stream);
       default: break;
     }
   }
-  if (N <= 32) return launch_cfg<4, 1, 1, 1>(a, transA, transB, batch, m_extent, sk, stream);          // 128 x 32
+  if (N <= 32) return launch_cfg<4, 1, 1, 1>(a, transA, transB, batch, m_extent, k_extent, sk, ws_any, ws_floats, stream);          // 128 x 32
   if (N <= 64) {
-    if (m_extent > 64 && fill < fill_min) return launch_cfg<2, 2, 1, 1>(a, transA, transB, batch, m_extent, sk, stream);   // 64 x 64
-    return launch_cfg<4, 1, 1, 2>(a, transA, transB, batch, m_extent, sk, stream);                                     // 128 x 64
+    if (m_extent > 64 && fill < fill_min) return launch_cfg<2, 2, 1, 1>(a, transA, transB, batch, m_extent, k_extent, sk, ws_any, ws_floats, stream);   // 64 x 64
+    return launch_cfg<4, 1, 1, 2>(a, transA, transB, batch, m_extent, k_extent, sk, ws_any, ws_floats, stream);                                     // 128 x 64
   }
-  if (m_extent <= 32) return launch_cfg<1, 4, 1, 1>(a, transA, transB, batch, m_extent, sk, stream);   // 32 x 128
-  if (m_extent <= 64) return launch_cfg<1, 4, 2, 1>(a, transA, transB, batch, m_extent, sk, stream);   // 64 x 128
+  if (m_extent <= 32) return launch_cfg<1, 4, 1, 1>(a, transA, transB, batch, m_extent, k_extent, sk, ws_any, ws_floats, stream);   // 32 x 128
+  if (m_extent <= 64) return launch_cfg<1, 4, 2, 1>(a, transA, transB, batch, m_extent, k_extent, sk, ws_any, ws_floats, stream);   // 64 x 128
   if (fill * ceil_div(N, 128) < fill_min) {   // too few 128x128 tiles to fill the chip (tools/gemm_cfg_sweep.py over the step's shapes)
     if (N <= 128) {                           // one column tile: long reductions stream A through 128x32 tiles (4 column tiles share the
       if (k_extent > 256 && m_extent > 128)   // A panel in L2; [32 x 1140 x 1140] x [1140 x 114]: 200 -> 155 us), short ones take 64x64
-        return launch_cfg<4, 1, 1, 1>(a, transA, transB, batch, m_extent, sk, stream);
-      return launch_cfg<2, 2, 1, 1>(a, transA, transB, batch, m_extent, sk, stream);
+        return launch_cfg<4, 1, 1, 1>(a, transA, transB, batch, m_extent, k_extent, sk, ws_any, ws_floats, stream);
+      return launch_cfg<2, 2, 1, 1>(a, transA, transB, batch, m_extent, k_extent, sk, ws_any, ws_floats, stream);
     }
-    if (transA) return launch_cfg<4, 1, 1, 2>(a, transA, transB, batch, m_extent, sk, stream);
-    return launch_cfg<1, 4, 2, 1>(a, transA, transB, batch, m_extent, sk, stream);
+    if (transA) return launch_cfg<4, 1, 1, 2>(a, transA, transB, batch, m_extent, k_extent, sk, ws_any, ws_floats, stream);
+    return launch_cfg<1, 4, 2, 1>(a, transA, transB, batch, m_extent, k_extent, sk, ws_any, ws_floats, stream);
   }
-  return launch_cfg<2, 2, 2, 2>(a, transA, transB, batch, m_extent, sk, stream);                        // 128 x 128
+  return launch_cfg<2, 2, 2, 2>(a, transA, transB, batch, m_extent, k_extent, sk, ws, ws_floats, stream);                        // 128 x 128
 }
 
 static void gemm_fill(GemmArgs& a, int M, int N, int K, float alpha, const float* A, int lda, const float* B, int ldb, float beta,
@@ -703,23 +1005,33 @@ static void gemm_fill(GemmArgs& a, int M, int N, int K, float alpha, const float
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
   a.strideA = strideA; a.strideB = strideB; a.strideC = strideC;
   a.alpha = alpha; a.beta = beta; a.ragged = ragged; a.tiles_n = 0;
+  a.per_batch = a.nb = 0; a.ws = nullptr; a.resident = 0; a.s_max = 1; a.map_mode = 0;
   a.nx = 0;
   for (int i = 0; i < 2; ++i) { a.xA[i] = a.xB[i] = nullptr; a.xlda[i] = a.xldb[i] = a.xK[i] = 0; a.xsA[i] = a.xsB[i] = 0; }
+}
+
+extern "C" int cgc_gemm_f32_ws(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda, const float* B,
+                               int ldb, float beta, float* C, int ldc, const float* bias, int batch, int64_t strideA, int64_t strideB,
+                               int64_t strideC, const int* gptr, int ragged, int max_ragged, float* ws, int64_t ws_floats,
+                               cgc_stream_t stream_) {
+  GemmArgs a;
+  gemm_fill(a, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, strideA, strideB, strideC, gptr, ragged);
+  return gemm_dispatch(a, transA, transB, batch, max_ragged, ws, ws_floats, as_stream(stream_));
 }
 
 extern "C" int cgc_gemm_f32(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda, const float* B, int ldb,
                             float beta, float* C, int ldc, const float* bias, int batch, int64_t strideA, int64_t strideB,
                             int64_t strideC, const int* gptr, int ragged, int max_ragged, cgc_stream_t stream_) {
-  GemmArgs a;
-  gemm_fill(a, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, strideA, strideB, strideC, gptr, ragged);
-  return gemm_dispatch(a, transA, transB, batch, max_ragged, as_stream(stream_));
+  return cgc_gemm_f32_ws(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, batch, strideA, strideB, strideC, gptr,
+                         ragged, max_ragged, nullptr, 0, stream_);
 }
 
-extern "C" int cgc_gemm_f32_cat(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda, const float* B,
-                                int ldb, float beta, float* C, int ldc, const float* bias, int batch, int64_t strideA,
-                                int64_t strideB, int64_t strideC, const int* gptr, int ragged, int max_ragged, int nx,
-                                const float* const* xA, const int* xlda, const int64_t* xstrideA, const float* const* xB,
-                                const int* xldb, const int64_t* xstrideB, const int* xK, cgc_stream_t stream_) {
+extern "C" int cgc_gemm_f32_cat_ws(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda, const float* B,
+                                   int ldb, float beta, float* C, int ldc, const float* bias, int batch, int64_t strideA,
+                                   int64_t strideB, int64_t strideC, const int* gptr, int ragged, int max_ragged, int nx,
+                                   const float* const* xA, const int* xlda, const int64_t* xstrideA, const float* const* xB,
+                                   const int* xldb, const int64_t* xstrideB, const int* xK, float* ws, int64_t ws_floats,
+                                   cgc_stream_t stream_) {
   if (nx < 0 || nx > 2) return CGC_EINVAL;
   GemmArgs a;
   gemm_fill(a, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, strideA, strideB, strideC, gptr, ragged);
@@ -731,7 +1043,16 @@ extern "C" int cgc_gemm_f32_cat(int transA, int transB, int M, int N, int K, flo
     ++kept;
   }
   a.nx = kept;
-  return gemm_dispatch(a, transA, transB, batch, max_ragged, as_stream(stream_));
+  return gemm_dispatch(a, transA, transB, batch, max_ragged, ws, ws_floats, as_stream(stream_));
+}
+
+extern "C" int cgc_gemm_f32_cat(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda, const float* B,
+                                int ldb, float beta, float* C, int ldc, const float* bias, int batch, int64_t strideA,
+                                int64_t strideB, int64_t strideC, const int* gptr, int ragged, int max_ragged, int nx,
+                                const float* const* xA, const int* xlda, const int64_t* xstrideA, const float* const* xB,
+                                const int* xldb, const int64_t* xstrideB, const int* xK, cgc_stream_t stream_) {
+  return cgc_gemm_f32_cat_ws(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, batch, strideA, strideB, strideC,
+                             gptr, ragged, max_ragged, nx, xA, xlda, xstrideA, xB, xldb, xstrideB, xK, nullptr, 0, stream_);
 }
 
 // ---- deterministic split-K combine

@@ -311,8 +311,22 @@ class LaunchTimer(object):
         return out
 
 
+class _NoWorkspace(object):
+    @staticmethod
+    def data_ptr():
+        return None
+
+    @staticmethod
+    def numel():
+        return 0
+
+
+_NO_WS = _NoWorkspace()
+
+
 class HipKernels(KernelSpec):
     timer = None   # set to a LaunchTimer by bench.py during the timed region
+    tail_split = True   # hand cgc_gemm_f32_ws its slab workspace (False: every output tile is computed whole; tests / A-B timing)
 
     def __init__(self):
         path = lib_path()
@@ -325,6 +339,7 @@ class HipKernels(KernelSpec):
         self.lib = ctypes.CDLL(path)
         from . import _abi
         _abi.declare(self.lib)
+        self._ws_cache = {}
 
     # -- helpers
     @staticmethod
@@ -435,6 +450,17 @@ class HipKernels(KernelSpec):
             self.timer.end('spmm_wide', t0, 8.0 * n * width)
 
     # -- dense contractions
+    def _gemm_ws(self, device, stream):
+        """The slab workspace of the GEMM's tail split (include/cgc_hip.h: cgc_gemm_f32_ws), one per (device, stream): products
+        queued on one stream run one after the other and may share it; two streams must not."""
+        if not self.tail_split:
+            return _NO_WS
+        key = (device.index, stream)
+        ws = self._ws_cache.get(key)
+        if ws is None:
+            ws = self._ws_cache[key] = torch.empty(int(self.lib.cgc_gemm_ws_floats()), dtype=torch.float32, device=device)
+        return ws
+
     def gemm(self, A, B, C, M, N, K, transA, transB, lda, ldb, ldc, alpha=1.0, beta=0.0, bias=None,
              batch=1, strideA=0, strideB=0, strideC=0, gptr=None, ragged=0, max_ragged=0, ragged_total=0, extra=()):
         self._dev(A, B, C, bias, gptr)
@@ -452,23 +478,25 @@ class HipKernels(KernelSpec):
                 else:
                     flops = 2.0 * M * N * kk * batch
                 t0 = self.timer.begin()
+        stream = self._stream()
+        ws = self._gemm_ws(C.device, stream)
         if extra:
             nx = len(extra)
             self._dev(*[e[0] for e in extra], *[e[1] for e in extra])
             PA, IA, LA = ctypes.c_void_p * nx, ctypes.c_int * nx, ctypes.c_int64 * nx
-            rc = self.lib.cgc_gemm_f32_cat(int(transA), int(transB), M, N, K, ctypes.c_float(alpha), _ptr(A), lda,
-                                           _ptr(B), ldb, ctypes.c_float(beta), _ptr(C), ldc, _ptr(bias), batch,
-                                           ctypes.c_int64(strideA), ctypes.c_int64(strideB), ctypes.c_int64(strideC),
-                                           _ptr(gptr), ragged, max_ragged, nx,
-                                           PA(*[e[0].data_ptr() for e in extra]), IA(*[e[2] for e in extra]),
-                                           LA(*[e[5] for e in extra]), PA(*[e[1].data_ptr() for e in extra]),
-                                           IA(*[e[3] for e in extra]), LA(*[e[6] for e in extra]),
-                                           IA(*[e[4] for e in extra]), self._stream())
+            rc = self.lib.cgc_gemm_f32_cat_ws(int(transA), int(transB), M, N, K, ctypes.c_float(alpha), _ptr(A), lda,
+                                              _ptr(B), ldb, ctypes.c_float(beta), _ptr(C), ldc, _ptr(bias), batch,
+                                              ctypes.c_int64(strideA), ctypes.c_int64(strideB), ctypes.c_int64(strideC),
+                                              _ptr(gptr), ragged, max_ragged, nx,
+                                              PA(*[e[0].data_ptr() for e in extra]), IA(*[e[2] for e in extra]),
+                                              LA(*[e[5] for e in extra]), PA(*[e[1].data_ptr() for e in extra]),
+                                              IA(*[e[3] for e in extra]), LA(*[e[6] for e in extra]),
+                                              IA(*[e[4] for e in extra]), ws.data_ptr(), ws.numel(), stream)
         else:
-            rc = self.lib.cgc_gemm_f32(int(transA), int(transB), M, N, K, ctypes.c_float(alpha), _ptr(A), lda,
-                                       _ptr(B), ldb, ctypes.c_float(beta), _ptr(C), ldc, _ptr(bias), batch,
-                                       ctypes.c_int64(strideA), ctypes.c_int64(strideB), ctypes.c_int64(strideC),
-                                       _ptr(gptr), ragged, max_ragged, self._stream())
+            rc = self.lib.cgc_gemm_f32_ws(int(transA), int(transB), M, N, K, ctypes.c_float(alpha), _ptr(A), lda,
+                                          _ptr(B), ldb, ctypes.c_float(beta), _ptr(C), ldc, _ptr(bias), batch,
+                                          ctypes.c_int64(strideA), ctypes.c_int64(strideB), ctypes.c_int64(strideC),
+                                          _ptr(gptr), ragged, max_ragged, ws.data_ptr(), ws.numel(), stream)
         self._chk(rc, 'cgc_gemm_f32')
         if t0 is not None:
             self.timer.end('gemm_128x128', t0, flops)

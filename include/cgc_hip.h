@@ -138,6 +138,25 @@ int cgc_gemm_f32_cat(int transA, int transB, int M, int N, int K, float alpha, c
                      int64_t strideA, int64_t strideB, int64_t strideC, const int* gptr, int ragged, int max_ragged,
                      int nx, const float* const* xA, const int* xlda, const int64_t* xstrideA,
                      const float* const* xB, const int* xldb, const int64_t* xstrideB, const int* xK, cgc_stream_t stream);
+/* The same two products with a SLAB WORKSPACE for the tail split of the 128 x 128 pipelined kernel (round 3): T output tiles on the
+ * 512 workgroups the chip holds run in ceil(T / 512) rounds, and the last round lasts as long as a full one however few tiles it
+ * holds (4140 tiles = 8.09 -> 9 rounds for the step's big products at 32 graphs, 522 tiles = 1.02 -> 2 rounds at 4 graphs per GPU).
+ * With ws != NULL the T mod 512 tiles of the last round (all tiles when T < 512) are cut along K into up to 12 pieces each, every
+ * piece parks its raw fp32 accumulators in a slab of ws, and a second kernel adds a tile's slabs IN PIECE ORDER and applies
+ * alpha / beta / bias: deterministic (no atomics, no arrival order), no flags, no spinning.  ws: ws_floats >= cgc_gemm_ws_floats()
+ * floats, contents irrelevant before and after; products on one stream may share it.  ws = NULL (or too small, or a product the
+ * split does not apply to: short reductions, other tile shapes) behaves exactly as the plain entry points. */
+int64_t cgc_gemm_ws_floats(void);
+int cgc_gemm_f32_ws(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
+                    const float* B, int ldb, float beta, float* C, int ldc, const float* bias, int batch,
+                    int64_t strideA, int64_t strideB, int64_t strideC, const int* gptr, int ragged, int max_ragged,
+                    float* ws, int64_t ws_floats, cgc_stream_t stream);
+int cgc_gemm_f32_cat_ws(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
+                        const float* B, int ldb, float beta, float* C, int ldc, const float* bias, int batch,
+                        int64_t strideA, int64_t strideB, int64_t strideC, const int* gptr, int ragged, int max_ragged,
+                        int nx, const float* const* xA, const int* xlda, const int64_t* xstrideA,
+                        const float* const* xB, const int* xldb, const int64_t* xstrideB, const int* xK,
+                        float* ws, int64_t ws_floats, cgc_stream_t stream);
 /* Tuning hook for experiments (tools/gemm_cfg_sweep.py): cfg 1..6 forces the tile shape 128x128, 128x64, 64x128, 64x64, 128x32,
  * 32x128 for every following product of this process, +10 the pipelined kernel, +20 the short-K kernel; 0 restores the automatic
  * selection.  Returns the previous value.  Results do not depend on it (same arithmetic per output element up to tile-edge order). */

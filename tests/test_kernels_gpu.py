@@ -366,6 +366,87 @@ def test_gemm_extra_k_segments():
     close(want, manual, 2e-5, 'twin vs explicit formula')
 
 
+TAIL_CASES = [
+    # (M or rows/graph list, N, K, tA, tB, batch, ragged)  -- with the 128 x 128 pipelined kernel forced (cgc_gemm_tuning(11))
+    (1000, 700, 500, False, False, 1, 0),        # 48 tiles < 512: every tile is a tail tile, 5 pieces
+    (1000, 700, 500, False, True, 1, 0),
+    (900, 1140, 1000, True, False, 1, 0),
+    (3840, 2304, 200, False, True, 1, 0),        # 540 tiles: 512 whole + 28 tail tiles in 2 pieces
+    (700, 600, 333, False, False, 7, 0),         # strided batch, 210 tiles, K not a multiple of the k-tile
+    ([300, 0, 513, 128, 77, 900, 250, 640], 520, 400, False, False, 8, 1),   # ragged M, compact list (batch % 8 == 0)
+    ([300, 0, 513, 128, 77], 520, 400, False, True, 5, 1),                    # ragged M, plain cut (empty tiles in the tail)
+    ([300, 0, 513, 128, 77, 900, 250, 640], 520, 0, True, False, 8, 2),      # ragged K, serpentine dealing
+    ([300, 0, 513], 520, 0, True, False, 3, 2),                               # ragged K, plain cut; one empty reduction
+]
+
+
+@pytest.mark.parametrize('rows,N,K,tA,tB,batch,ragged', TAIL_CASES)
+def test_gemm_tail_split(rows, N, K, tA, tB, batch, ragged):
+    """The tail split of the 128 x 128 kernel (include/cgc_hip.h: cgc_gemm_f32_ws): tiles of the last partial round cut along K
+    into pieces + slab fix-up.  Against fp64, against the unsplit launch (same arithmetic per element up to the order of the
+    K pieces), and bitwise repeatable; alpha / beta / bias / an extra K segment go through the fix-up's epilogue."""
+    k = hip()
+    old = k.lib.cgc_gemm_tuning(11)
+    try:
+        if ragged == 0:
+            M = rows
+            A = rnd(batch, *((K, M) if tA else (M, K)), seed=1)
+            B = rnd(batch, *((N, K) if tB else (K, N)), seed=2)
+            want = torch.bmm(A.double().transpose(1, 2) if tA else A.double(), B.double().transpose(1, 2) if tB else B.double())
+            C0 = rnd(batch, M, N, seed=3)
+            bias = rnd(N, seed=4)
+            want = 0.5 * want + 2.0 * C0.double() + bias.double()
+            gA, gB = g(A), g(B)
+            lda, ldb = A.shape[2], B.shape[2]
+            args = (M, N, K, tA, tB, lda, ldb, N, 0.5, 2.0, g(bias), batch, A.shape[1] * lda, B.shape[1] * ldb, M * N)
+            outs = []
+            for split in (True, True, False):
+                k.tail_split = split
+                got = g(C0.clone())
+                k.gemm(gA, gB, got, *args)
+                outs.append(got.cpu())
+        else:
+            counts = rows
+            n, nmax = sum(counts), max(counts)
+            gptr = torch.tensor(np.cumsum([0] + counts), dtype=torch.int32)
+            C = 450
+            if ragged == 1:          # Y_b = S_b op(G_b) + X_b op(H_b) (extra K segment), rows of graph b
+                S, X = rnd(n, K, seed=1), rnd(n, 60, seed=5)
+                G = rnd(batch, *((N, K) if tB else (K, N)), seed=2)
+                H = rnd(batch, *((N, 60) if tB else (60, N)), seed=6)
+                want = torch.cat([S[gptr[b]:gptr[b + 1]].double() @ (G[b].double().t() if tB else G[b].double()) +
+                                  X[gptr[b]:gptr[b + 1]].double() @ (H[b].double().t() if tB else H[b].double())
+                                  for b in range(batch)])
+                C0 = rnd(n, N, seed=3)
+                want = want + C0.double()
+                gS, gG, gX, gH, gp = g(S), g(G), g(X), g(H), g(gptr)
+                outs = []
+                for split in (True, True, False):
+                    k.tail_split = split
+                    got = g(C0.clone())
+                    k.gemm(gS, gG, got, 0, N, K, False, tB, K, G.shape[2], N, 1.0, 1.0, None, batch, 0, G.shape[1] * G.shape[2], 0,
+                           gp, 1, nmax, n, extra=[(gX, gH, 60, H.shape[2], 60, 0, H.shape[1] * H.shape[2])])
+                    outs.append(got.cpu())
+            else:                    # out[b] = S_b^T X_b, reduction over the rows of graph b
+                S, X = rnd(n, C, seed=1), rnd(n, N, seed=2)
+                want = torch.stack([S[gptr[b]:gptr[b + 1]].double().t() @ X[gptr[b]:gptr[b + 1]].double() for b in range(batch)])
+                gS, gX, gp = g(S), g(X), g(gptr)
+                outs = []
+                for split in (True, True, False):
+                    k.tail_split = split
+                    got = torch.full((batch, C, N), 7.0, device=DEV)
+                    k.gemm(gS, gX, got, C, N, 0, True, False, C, N, N, 1.0, 0.0, None, batch, 0, 0, C * N, gp, 2, nmax, n)
+                    outs.append(got.cpu())
+    finally:
+        k.tail_split = True
+        k.lib.cgc_gemm_tuning(old)
+    assert torch.equal(outs[0], outs[1])                                   # fixed summation order: bitwise repeatable
+    scale = float(want.abs().max())
+    for o, what in zip((outs[0], outs[2]), ('split', 'whole')):
+        assert float((o.double() - want.reshape(o.shape)).abs().max()) < 1e-5 * scale, what
+    assert float((outs[0].double() - outs[2].double()).abs().max()) < 1e-5 * scale
+
+
 def test_gemm_strided_batch_and_splitk_reduce():
     A, B = rnd(5, 70, 90, seed=1), rnd(5, 90, 40, seed=2)
     want, got = torch.zeros(5, 70, 40), torch.zeros(5, 70, 40, device=DEV)
