@@ -57,6 +57,15 @@ PROTOTYPES = {
     'cgc_dense_renorm_bwd': [P, P, I, I, F, P, P],
     'cgc_adj_prep_fwd': [P, I, I, F, P, P, P, P, P],
     'cgc_adj_prep_bwd': [P, P, P, P, P, P, I, I, F, P, P],
+    'cgc_cat_cols': [P, I, I, I, P, P, P, I, P],
+    'cgc_transpose': [P, I, I, I, P, I, P],
+    # step sequencer (csrc/exec.hip; the struct arguments are ctypes Structures of native.py passed by reference)
+    'cgc_level_supported': [P],
+    'cgc_level_saved_floats': [P],
+    'cgc_level_scratch_floats': [P],
+    'cgc_level_grad_layout_of': [P, P],
+    'cgc_level_fwd': [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P],
+    'cgc_level_bwd': [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P],
 }
 
 
@@ -65,4 +74,4 @@ def declare(lib):
     for name, argtypes in PROTOTYPES.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
-        fn.restype = C.c_int64 if name.endswith(('_ws_ints', '_ws_floats', '_offset', '_grad_floats')) else C.c_int
+        fn.restype = C.c_int64 if name.endswith(('_ws_ints', '_ws_floats', '_offset', '_grad_floats', '_saved_floats', '_scratch_floats')) else C.c_int

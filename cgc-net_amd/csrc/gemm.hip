@@ -41,6 +41,7 @@ struct GemmArgs {
   // tail split (see TileMap): slabs of raw accumulators for the pieces of the tail tiles; nullptr = every tile is computed whole
   float* ws;
   int resident;   // workgroups the chip holds at once = the quantum of a "round"
+  int chunk;      // ragged 3: rows per part
   int s_max;      // most pieces a tail tile is cut into
   // optional extra K segments: C += alpha * A_x[s] * B_x[s] (same op() orientation, M, N as the main pair), i.e. the
   // product of the column-concatenated [A | A_x0 | A_x1] with the row-concatenated [B ; B_x0 ; B_x1] without ever
@@ -376,6 +377,16 @@ struct TileBase {
       K = a.gptr[b + 1] - g0;
       A += (size_t)g0 * a.lda;
       B += (size_t)g0 * a.ldb;
+    } else if (a.ragged == 3) {
+      // uniform row chunks (split-K without an offset array): item b = (outer, part); every outer item reduces over a.K rows, cut
+      // into parts of a.chunk rows; A (stored [K,M]) and B (stored [K,N]) are the flattened [outer * K, .] row blocks
+      const int parts = (a.K + a.chunk - 1) / a.chunk;
+      const int outer = b / parts, part = b - outer * parts;
+      const long long g0 = (long long)outer * a.K + (long long)part * a.chunk;
+      const int left = a.K - part * a.chunk;
+      K = left < a.chunk ? left : a.chunk;
+      A = a.A + (size_t)g0 * a.lda;
+      B = a.B + (size_t)g0 * a.ldb;
     }
   }
 };
@@ -855,7 +866,7 @@ static bool gemm_all_fast(const GemmArgs& a, int transA, int transB, int batch) 
     if (transB ? ldb < up4(K) : ldb < up4(a.N)) return false;
     return true;
   };
-  if (!seg(a.A, a.B, a.lda, a.ldb, a.strideA, a.strideB, a.ragged == 2 ? 0 : a.K)) return false;
+  if (!seg(a.A, a.B, a.lda, a.ldb, a.strideA, a.strideB, a.ragged >= 2 ? 0 : a.K)) return false;
   for (int i = 0; i < a.nx; ++i)
     if (!seg(a.xA[i], a.xB[i], a.xlda[i], a.xldb[i], a.xsA[i], a.xsB[i], a.xK[i])) return false;
   return true;
@@ -937,19 +948,21 @@ static int gemm_dispatch(GemmArgs& a, int transA, int transB, int batch, int max
   const int M = a.M, N = a.N, K = a.K, ragged = a.ragged;
   if (batch <= 0 || N <= 0) return 0;
 #ifdef CGC_GEMM_ONLY_128   // compile-time experiments on the dominant kernel alone (not part of the build)
-  return launch_cfg<2, 2, 2, 2>(a, transA, transB, batch, ragged == 1 ? max_ragged : M, ragged == 2 ? max_ragged : K, false, ws, ws_floats, stream);
+  return launch_cfg<2, 2, 2, 2>(a, transA, transB, batch, ragged == 1 ? max_ragged : M, ragged >= 2 ? max_ragged : K, false, ws, ws_floats, stream);
 #endif
   // the tail split is tuned for the 128 x 128 tile (512 resident workgroups); CGC_GEMM_SPLIT=2 lets every pipelined tile shape use it
   static const int split_all = getenv("CGC_GEMM_SPLIT") ? atoi(getenv("CGC_GEMM_SPLIT")) >= 2 : 0;
   float* const ws_any = split_all ? ws : nullptr;
   if (ragged == 1 && (transA || a.gptr == nullptr)) return CGC_EINVAL;
   if (ragged == 2 && (!transA || transB || a.gptr == nullptr || a.nx > 0)) return CGC_EINVAL;
-  if (ragged < 0 || ragged > 2) return CGC_EINVAL;
+  if (ragged == 3 && (!transA || transB || a.nx > 0 || max_ragged <= 0 || K <= 0 || batch % ceil_div(K, max_ragged) != 0)) return CGC_EINVAL;
+  if (ragged < 0 || ragged > 3) return CGC_EINVAL;
+  a.chunk = ragged == 3 ? max_ragged : 0;
   const int m_extent = ragged == 1 ? max_ragged : M;
   if (m_extent <= 0) return 0;
   // tile shape by output aspect: the hot contractions are (>=1140) x (>=1140); the skinny ones are K- or output-bound.
   // `fill` = workgroups a 128-row tiling would launch; below ~448 (256 CUs x 2 resident) the tile is halved in M.
-  const int k_extent = ragged == 2 ? max_ragged : K;
+  const int k_extent = ragged >= 2 ? max_ragged : K;
   static const int shortk_max = getenv("CGC_GEMM_SHORTK") ? atoi(getenv("CGC_GEMM_SHORTK")) : 160;
   static const int fill_min = getenv("CGC_GEMM_FILL") ? atoi(getenv("CGC_GEMM_FILL")) : 448;
   const bool sk = k_extent <= shortk_max && a.nx == 0;
@@ -995,7 +1008,7 @@ static void gemm_fill(GemmArgs& a, int M, int N, int K, float alpha, const float
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
   a.strideA = strideA; a.strideB = strideB; a.strideC = strideC;
   a.alpha = alpha; a.beta = beta; a.ragged = ragged; a.tiles_n = 0;
-  a.per_batch = a.nb = 0; a.ws = nullptr; a.resident = 0; a.s_max = 1; a.map_mode = 0;
+  a.per_batch = a.nb = 0; a.ws = nullptr; a.resident = 0; a.s_max = 1; a.map_mode = 0; a.chunk = 0;
   a.nx = 0;
   for (int i = 0; i < 2; ++i) { a.xA[i] = a.xB[i] = nullptr; a.xlda[i] = a.xldb[i] = a.xK[i] = 0; a.xsA[i] = a.xsB[i] = 0; }
 }

@@ -469,12 +469,12 @@ class HipKernels(KernelSpec):
             # time exactly the launches that gemm_dispatch() (csrc/gemm.hip) sends to the 128x128 pipelined kernel
             # k_gemm_f32<2,2,2,2,*>: N > 64, more than 64 rows, enough tiles to fill the chip, reduction longer than 160
             m_ext = max_ragged if ragged == 1 else M
-            k_ext = max_ragged if ragged == 2 else K
+            k_ext = max_ragged if ragged >= 2 else K
             fill = -(-m_ext // 128) * batch
             if N > 64 and m_ext > 64 and fill * (-(-N // 128)) >= 448 and (k_ext > 160 or extra):
                 kk = K + sum(e[4] for e in extra)
                 if ragged:   # ragged extents sum to ragged_total rows
-                    flops = 2.0 * (M if ragged == 2 else kk) * N * ragged_total
+                    flops = 2.0 * (M if ragged >= 2 else kk) * N * ragged_total
                 else:
                     flops = 2.0 * M * N * kk * batch
                 t0 = self.timer.begin()

@@ -1,0 +1,267 @@
+"""Python face of the step sequencer (csrc/exec.hip; include/cgc_hip.h: cgc_level_fwd / cgc_level_bwd).
+
+One ``torch.autograd.Function`` per LEVEL of ``SoftPoolingGcnEncoder.forward`` (model/network.py:258-268, :270-278, :279-285)
+instead of one per operator: Python issues 3 + 3 library calls per training step where the per-operator path (ops.py) issues
+~330, the schedule inside a level is C++.  The arithmetic is the per-operator path's, kernel for kernel (tests compare the two
+bit for bit); what autograd sees is (readout, pooled features, pooled adjacency) per level and one flat gradient buffer whose
+slices are the parameters' gradients.
+
+Scope (``supported``): DenseSAGEConv blocks in training mode (or without BatchNorm), fixed BatchNorm momentum, DenseJK on the
+compiled channel counts, input features without gradient.  Everything else runs on the per-operator path.
+"""
+import ctypes as C
+
+import torch
+from torch.autograd import Function
+
+from . import kernels
+from .graph import uniform_ptr
+from .kernels import ACT_CODES
+
+P, I, F_, D_, L = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_int64
+
+
+class LevelDesc(C.Structure):
+    _fields_ = [('level', I), ('B', I), ('n', I), ('rows_per_graph', I), ('nmax', I), ('npad', I), ('fin', I), ('H', I), ('E', I),
+                ('AH', I), ('C', I), ('has_bias', I), ('has_bn', I), ('act', I), ('jk', I), ('renorm', I), ('renorm_p', F_),
+                ('bn_eps', F_ * 6), ('bn_momentum', F_ * 6), ('count', D_)]
+
+
+class BlockParams(C.Structure):
+    _fields_ = [('W', P * 3), ('b', P * 3), ('gamma', P * 3), ('beta', P * 3), ('running_mean', P * 3), ('running_var', P * 3),
+                ('num_batches_tracked', P * 3), ('lin_W', P), ('lin_b', P)]
+
+
+class JkParams(C.Structure):
+    _fields_ = [('lstm', P * 8), ('w_att', P), ('b_att', P)]
+
+
+class Graph(C.Structure):
+    _fields_ = [('rowptr', P), ('col', P), ('t_rowptr', P), ('t_col', P), ('val', P), ('t_val', P), ('inv_d', P), ('gorder', P)]
+
+
+class GradLayout(C.Structure):
+    _fields_ = [('W', L * 6), ('b', L * 6), ('bn_weight', L * 6), ('bn_bias', L * 6), ('lin_W', L), ('lin_b', L), ('jk', L),
+                ('total', L)]
+
+
+def _lib():
+    return kernels.get().lib       # prototypes: _abi.py
+
+
+def _p(t):
+    return t.data_ptr() if t is not None else None
+
+
+# ---- which tensors of a module go where (fixed order: the Function's inputs, the gradient slices) --------------------------
+def _block_tensors(blk):
+    """[W1, b1, W2, b2, W3, b3, bn1.weight, bn1.bias, .., bn3.bias, lin.weight, lin.bias] (None where the module has none)."""
+    out = []
+    for k in (1, 2, 3):
+        conv = getattr(blk, 'gcn%d' % k)
+        out += [conv.weight, conv.bias]
+    for k in (1, 2, 3):
+        bn = getattr(blk, 'bn%d' % k) if blk.use_bn else None
+        out += [bn.weight if bn is not None else None, bn.bias if bn is not None else None]
+    lin = blk.lin
+    out += [lin.weight if lin is not None else None, lin.bias if lin is not None else None]
+    return out
+
+
+def _jk_tensors(jk):
+    p = jk.lstm
+    return [p.weight_ih_l0, p.weight_hh_l0, p.bias_ih_l0, p.bias_hh_l0, p.weight_ih_l0_reverse, p.weight_hh_l0_reverse,
+            p.bias_ih_l0_reverse, p.bias_hh_l0_reverse, jk.att.weight, jk.att.bias]
+
+
+def _block_params(blk):
+    s = BlockParams()
+    if blk is None:
+        return s
+    for k in range(3):
+        conv = getattr(blk, 'gcn%d' % (k + 1))
+        s.W[k], s.b[k] = _p(conv.weight), _p(conv.bias)
+        if blk.use_bn:
+            bn = getattr(blk, 'bn%d' % (k + 1))
+            s.gamma[k], s.beta[k] = _p(bn.weight), _p(bn.bias)
+            track = bn.track_running_stats and bn.running_mean is not None
+            s.running_mean[k] = _p(bn.running_mean) if track else None
+            s.running_var[k] = _p(bn.running_var) if track else None
+            s.num_batches_tracked[k] = _p(bn.num_batches_tracked) if track else None
+    if blk.lin is not None:
+        s.lin_W, s.lin_b = _p(blk.lin.weight), _p(blk.lin.bias)
+    return s
+
+
+def _jk_params(jk):
+    s = JkParams()
+    if jk is None:
+        return s
+    t = _jk_tensors(jk)
+    for i in range(8):
+        s.lstm[i] = _p(t[i])
+    s.w_att, s.b_att = _p(t[8]), _p(t[9])
+    return s
+
+
+def _f32ok(*ts):
+    return all(t is None or (t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda) for t in ts)
+
+
+def describe(enc, level, emb, pool, jk, B, n, rows_per_graph, nmax, npad, fin, count):
+    """LevelDesc for one level, or None when the sequencer does not cover the configuration (the caller then takes the
+    per-operator path)."""
+    blocks = [emb] + ([pool] if pool is not None else [])
+    for blk in blocks:
+        if not blk.mean_aggregation or blk.add_loop:
+            return None
+        for k in (1, 2, 3):
+            conv = getattr(blk, 'gcn%d' % k)
+            if not conv.normalize or (conv.bias is None) != (emb.gcn1.bias is None):
+                return None
+            if blk.use_bn:
+                bn = getattr(blk, 'bn%d' % k)
+                if bn.momentum is None or not bn.affine or not blk.training:
+                    return None
+        if blk.use_bn != emb.use_bn or blk.activation != emb.activation:
+            return None
+        if not _f32ok(*_block_tensors(blk)):
+            return None
+    if jk is not None and (jk.mode != 'lstm' or not _f32ok(*_jk_tensors(jk))):
+        return None
+    if pool is not None and (pool.lin is None or pool.gcn1.out_channels != pool.gcn2.out_channels):
+        return None
+    if emb.lin is not None or emb.gcn1.out_channels != emb.gcn2.out_channels:
+        return None
+    d = LevelDesc()
+    d.level, d.B, d.n, d.rows_per_graph, d.nmax, d.npad, d.fin = level, B, n, rows_per_graph, nmax, npad, fin
+    d.H, d.E = emb.gcn1.out_channels, emb.gcn3.out_channels
+    d.AH, d.C = (pool.gcn1.out_channels, pool.gcn3.out_channels) if pool is not None else (0, 0)
+    d.has_bias, d.has_bn = int(emb.gcn1.bias is not None), int(emb.use_bn)
+    d.act, d.jk = ACT_CODES[emb.activation], int(jk is not None)
+    d.renorm, d.renorm_p = int(enc.norm_adj), float(RENORM_P)
+    for b_i, blk in enumerate(blocks):
+        if blk.use_bn:
+            for k in range(3):
+                bn = getattr(blk, 'bn%d' % (k + 1))
+                d.bn_eps[3 * b_i + k], d.bn_momentum[3 * b_i + k] = bn.eps, bn.momentum
+    d.count = float(count)
+    if emb.gcn1.in_channels != fin or (pool is not None and pool.gcn1.in_channels != fin):
+        return None
+    if not _lib().cgc_level_supported(C.byref(d)):
+        return None
+    return d
+
+
+RENORM_P = 0.4      # model/network.py:260,271,280
+
+
+class _Level(Function):
+    """(readout, x_out, A_out) = one level; ``cfg`` carries the non-tensor arguments."""
+
+    @staticmethod
+    def forward(ctx, cfg, x_in, A_in, *params):
+        lib = _lib()
+        d, emb, pool, jk, g, gptr = cfg['desc'], cfg['emb'], cfg['pool'], cfg['jk'], cfg['graph'], cfg['gptr']
+        dev = x_in.device
+        kernels.get()._dev(x_in, A_in, gptr)
+        stream = kernels.get()._stream()
+        saved = torch.empty(int(lib.cgc_level_saved_floats(C.byref(d))), dtype=torch.float32, device=dev)
+        scratch = torch.empty(int(lib.cgc_level_scratch_floats(C.byref(d))), dtype=torch.float32, device=dev)
+        D = d.H if d.jk else 2 * d.H + d.E
+        readout = torch.empty(d.B, D, dtype=torch.float32, device=dev)
+        x_out = torch.empty(d.B, d.C, D, dtype=torch.float32, device=dev) if d.C else None
+        A_out = torch.empty(d.B, d.C, d.C, dtype=torch.float32, device=dev) if d.C else None
+        pe, pp, pj = _block_params(emb), _block_params(pool), _jk_params(jk)
+        gs = Graph()
+        if g is not None:
+            gs.rowptr, gs.col, gs.t_rowptr, gs.t_col = _p(g.rowptr), _p(g.col), _p(g.t_rowptr), _p(g.t_col)
+            gs.val, gs.t_val, gs.inv_d, gs.gorder = _p(g.val), _p(g.t_val), _p(g.inv_d), _p(g.gorder)
+        s_ptr, s_ld = P(), I()
+        rc = lib.cgc_level_fwd(C.byref(d), C.byref(pe), C.byref(pp), C.byref(pj), C.byref(gs), _p(gptr), _p(x_in), _p(A_in), _p(saved),
+                               _p(scratch), _p(readout), _p(x_out), _p(A_out), C.byref(s_ptr), C.byref(s_ld), stream)
+        if rc != 0:
+            raise RuntimeError('cgc_level_fwd failed with code %d' % rc)
+        if cfg.get('assign') is not None and d.C:
+            off = (s_ptr.value - saved.data_ptr()) // 4
+            cfg['assign'].append(torch.as_strided(saved, (d.n, d.C), (s_ld.value, 1), off).detach().clone())
+        ctx.cfg, ctx.structs = cfg, (pe, pp, pj, gs)
+        ctx.save_for_backward(x_in, A_in, saved, *[p for p in params if p is not None])
+        ctx.mask = [p is not None for p in params]
+        ctx.shapes = [tuple(p.shape) if p is not None else None for p in params]
+        if d.C:
+            return readout, x_out, A_out
+        return readout
+
+    @staticmethod
+    def backward(ctx, d_readout, d_x_out=None, d_A_out=None):
+        lib = _lib()
+        cfg = ctx.cfg
+        d, g, gptr = cfg['desc'], cfg['graph'], cfg['gptr']
+        x_in, A_in, saved = ctx.saved_tensors[:3]
+        pe, pp, pj, gs = ctx.structs
+        dev = saved.device
+        stream = kernels.get()._stream()
+        lay = GradLayout()
+        lib.cgc_level_grad_layout_of(C.byref(d), C.byref(lay))
+        grads = torch.empty(int(lay.total), dtype=torch.float32, device=dev)
+        scratch = torch.empty(int(lib.cgc_level_scratch_floats(C.byref(d))), dtype=torch.float32, device=dev)
+        D = d.H if d.jk else 2 * d.H + d.E
+        d_readout = d_readout.contiguous().float()
+        if d.C:
+            d_x_out = torch.zeros(d.B, d.C, D, device=dev) if d_x_out is None else d_x_out.contiguous().float()
+            d_A_out = torch.zeros(d.B, d.C, d.C, device=dev) if d_A_out is None else d_A_out.contiguous().float()
+        dense = d.level >= 2
+        d_x_in = torch.empty_like(x_in) if dense else None
+        d_A_in = torch.empty_like(A_in) if dense else None
+        rc = lib.cgc_level_bwd(C.byref(d), C.byref(pe), C.byref(pp), C.byref(pj), C.byref(gs), _p(gptr), _p(x_in), _p(A_in), _p(saved),
+                               _p(scratch), _p(d_readout), _p(d_x_out), _p(d_A_out), _p(grads), _p(d_x_in), _p(d_A_in), stream)
+        if rc != 0:
+            raise RuntimeError('cgc_level_bwd failed with code %d' % rc)
+        out = []
+        offs = _param_offsets(d, lay)
+        for present, shape, off in zip(ctx.mask, ctx.shapes, offs):
+            if not present or off < 0:
+                out.append(None)
+                continue
+            k = 1
+            for s_ in shape:
+                k *= s_
+            out.append(grads[off:off + k].view(shape))
+        return (None, d_x_in, d_A_in) + tuple(out)
+
+
+def _param_offsets(d, lay):
+    """Gradient-buffer offsets in the order of the Function's parameter inputs (see level())."""
+    offs = []
+    nblk = 2 if d.C else 1
+    for b_i in range(nblk):
+        for k in range(3):
+            offs += [lay.W[3 * b_i + k], lay.b[3 * b_i + k]]
+        for k in range(3):
+            offs += [lay.bn_weight[3 * b_i + k], lay.bn_bias[3 * b_i + k]]
+        offs += ([lay.lin_W, lay.lin_b] if b_i == 1 else [-1, -1])
+    if d.jk:
+        H = d.H
+        Hh = 3 * H // 2
+        o = lay.jk
+        for _ in range(2):
+            for size in (4 * Hh * H, 4 * Hh * Hh, 4 * Hh, 4 * Hh):
+                offs.append(o)
+                o += size
+        offs += [o, o + 2 * Hh]
+    return offs
+
+
+def level(enc, desc, emb, pool, jk, g, gptr, x_in, A_in, assign=None):
+    """Run one level through the sequencer.  Returns (readout, x_out, A_out) (x_out / A_out None at the last level)."""
+    cfg = dict(desc=desc, emb=emb, pool=pool, jk=jk, graph=g, gptr=gptr, assign=assign)
+    params = _block_tensors(emb) + (_block_tensors(pool) if pool is not None else []) + (_jk_tensors(jk) if jk is not None else [])
+    out = _Level.apply(cfg, x_in, A_in, *params)
+    if desc.C:
+        return out
+    return out, None, None
+
+
+def dense_gptr(B, Cn, device):
+    return uniform_ptr(B, Cn, device)

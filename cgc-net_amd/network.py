@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
+from . import native, ops
 from .graph import BatchGraph, uniform_ptr
 
 EPS = 1e-15
@@ -322,6 +322,9 @@ class SoftPoolingGcnEncoder(nn.Module):
         self.pred_model = self.build_readout_module(input_dim * 3, pred_hidden_dims, label_dim, activation)
         self.last_graph = None
         self._graphed = None          # see enable_graph_capture()
+        # levels run through the step sequencer (native.py / csrc/exec.hip: one library call per level and direction) whenever it
+        # covers the configuration; False (or CGC_NATIVE=0): always the per-operator path (ops.py), one autograd node per operator
+        self.native = os.environ.get('CGC_NATIVE', '1') != '0'
 
     def build_readout_module(self, pred_input_dim, pred_hidden_dims, label_dim, activation):
         if len(pred_hidden_dims) == 0:
@@ -372,12 +375,42 @@ class SoftPoolingGcnEncoder(nn.Module):
         return flat
 
     # -- stages --------------------------------------------------------------------------------
+    def _use_native(self, x):
+        return (self.native and self.training and torch.is_grad_enabled() and self._graphed is None and x.is_cuda
+                and x.dtype == torch.float32 and not x.requires_grad)
+
+    def _native_level(self, level, x, adj, g=None):
+        """One level through the sequencer; None when it does not cover this configuration."""
+        emb = getattr(self, 'GCN_embed_%d' % level)
+        pool = getattr(self, 'GCN_pool_%d' % level) if level < 3 else None
+        jk = getattr(self, 'jk%d' % level) if self.jk else None
+        if level == 1:
+            desc = native.describe(self, 1, emb, pool, jk, g.B, g.n, 0, g.nmax, g.npad, x.shape[1], g.padded_rows)
+            gptr = g.gptr
+        else:
+            B, Cn, fin = x.shape
+            desc = native.describe(self, level, emb, pool, jk, B, B * Cn, Cn, 0, 0, fin, B * Cn)
+            gptr = uniform_ptr(B, Cn, x.device)
+            x, adj = ops._f32c(x).view(B * Cn, fin), ops._f32c(adj)
+        if desc is None:
+            return None
+        assign = [] if (self.collect_assign and pool is not None) else None
+        out = native.level(self, desc, emb, pool, jk, g, gptr, x.contiguous(), adj, assign)
+        if assign:
+            s = assign[0]
+            self.assign_matrix.append(self._pad_assign(s, g) if level == 1 else s.view(desc.B, desc.rows_per_graph, -1))
+        return out
+
     def _level1(self, data):
         g = BatchGraph.from_batch(data, RENORM_P if self.norm_adj else None)
         if _VALIDATE_INPUTS:
             g.validate()
         self.last_graph = g
         x = data.x
+        if self._use_native(x):
+            out = self._native_level(1, x, None, g)
+            if out is not None:
+                return out
         emb_blk, pool_blk = self.GCN_embed_1, self.GCN_pool_1
         agg0 = ops.aggregate(x, g, emb_blk.mean_aggregation)     # shared by both blocks' first conv
         outs_p = None
@@ -406,6 +439,10 @@ class SoftPoolingGcnEncoder(nn.Module):
 
     def _dense_level(self, level, x, adj):
         B, C, _ = x.shape
+        if self._use_native(x.detach()):
+            out = self._native_level(level, x, adj)
+            if out is not None:
+                return out
         emb_blk = getattr(self, 'GCN_embed_%d' % level)
         if emb_blk.mean_aggregation:       # re-normalisation + clamped row normalisation: one fused pass each way
             adj, a = ops.adj_prep(adj, RENORM_P if self.norm_adj else None)

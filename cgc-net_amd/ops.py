@@ -8,8 +8,6 @@ Reference arithmetic being re-expressed:
   segment_max                           max readout incl. zero padding rows           (A9; model/network.py:264)
   rownorm_clamp, renorm_dense           clamp(min=1) mean divisor, _re_norm_adj at levels 2-3 (A4, A6)
 """
-import collections
-
 import torch
 from torch.autograd import Function
 
@@ -87,29 +85,12 @@ def _rows_ld(t):
 # ----------------------------------------------------------------------------------------------
 # split-K helper for the tall-skinny "weight gradient" contractions  out[Fa,Fb] = A[n,Fa]^T B[n,Fb]
 # ----------------------------------------------------------------------------------------------
-_SPLIT_CACHE = collections.OrderedDict()      # (n, parts, device) -> (ptr, chunk); bounded: n is a batch's node count
-_SPLIT_ARANGE = {}
-
-
-def _split_ptr(n, parts, device):
-    """Row split points [0, chunk, 2 chunk, .., n] as an int32 device tensor.  Built ON the device (two tiny launches on a
-    miss): a torch.tensor(list, device=...) here would be a blocking host-to-device copy in the middle of backward, once per
-    distinct node count -- i.e. every step of a real epoch."""
-    key = (n, parts, str(device))
-    hit = _SPLIT_CACHE.get(key)
-    if hit is not None:
-        _SPLIT_CACHE.move_to_end(key)
-        return hit
+def _split_chunk(n, parts):
+    """Rows per slice when n rows are cut into `parts` slices: a multiple of the GEMM's k-tile (32).  The slices are addressed by
+    cgc_gemm_f32's ``ragged = 3`` mode (uniform row chunks): no offset tensor -- round 2 kept device tensors of split points in a
+    bounded cache, which a captured hipGraph could outlive."""
     chunk = -(-n // parts)
-    chunk = -(-chunk // 32) * 32
-    ar = _SPLIT_ARANGE.get((parts, str(device)))
-    if ar is None:
-        ar = _SPLIT_ARANGE[(parts, str(device))] = torch.arange(parts + 1, dtype=torch.int32, device=device)
-    ptr = (ar * chunk).clamp_(max=n)
-    _SPLIT_CACHE[key] = (ptr, chunk)
-    if len(_SPLIT_CACHE) > 64:
-        _SPLIT_CACHE.popitem(last=False)
-    return ptr, chunk
+    return -(-chunk // 32) * 32
 
 
 _RESIDENT_BLOCKS = 512      # 256 CUs x 2 workgroups (the GEMM's ~70 KB of LDS admits two per CU)
@@ -144,10 +125,11 @@ def gemm_tn_rows(A, lda, Fa, B, ldb, Fb, n, out, ldc=None, beta=0.0):
         # (strided destinations take the direct path; they only occur for small slices)
         K().gemm(A, B, out, Fa, Fb, n, True, False, lda, ldb, ldc, 1.0, beta)
         return
-    ptr, chunk = _split_ptr(n, parts, A.device)
+    chunk = _split_chunk(n, parts)
+    parts = -(-n // chunk)                                   # (slices that the rounding left empty are dropped)
     ws = torch.empty(parts, Fa * Fb, dtype=torch.float32, device=A.device)
-    K().gemm(A, B, ws, Fa, Fb, 0, True, False, lda, ldb, Fb, 1.0, 0.0, None,
-             parts, 0, 0, Fa * Fb, ptr, 2, chunk, n)
+    K().gemm(A, B, ws, Fa, Fb, n, True, False, lda, ldb, Fb, 1.0, 0.0, None,
+             parts, 0, 0, Fa * Fb, None, 3, chunk, n)
     K().reduce_batch_sum(ws, out, parts, Fa * Fb, beta)
 
 
@@ -700,19 +682,6 @@ def diff_pool_sparse(embed, s, g):
 # ----------------------------------------------------------------------------------------------
 # strided-batched dense matmul C_b = op(A_b) op(B_b)  (levels 2-3: A~ x, S^T X, A S, S^T (A S))
 # ----------------------------------------------------------------------------------------------
-_BSPLIT_CACHE = {}
-
-
-def _bsplit_ptr(batch, Kd, parts, device):
-    """Row split points of a [batch*Kd, .] flattening: every batch's Kd rows are cut into `parts` slices."""
-    key = (batch, Kd, parts, str(device))
-    if key not in _BSPLIT_CACHE:
-        step = -(-(-(-Kd // parts)) // 32) * 32
-        ptr = [b * Kd + min(p * step, Kd) for b in range(batch) for p in range(parts)] + [batch * Kd]
-        _BSPLIT_CACHE[key] = (torch.tensor(ptr, dtype=torch.int32, device=device), step)
-    return _BSPLIT_CACHE[key]
-
-
 def _bgemm(A, B, C, tA, tB, beta=0.0):
     """A, B, C: [batch, r, c] tensors with contiguous (possibly padded) rows, see _b3; computes C = op(A) op(B) (+ beta C)."""
     batch = C.shape[0]
@@ -723,10 +692,11 @@ def _bgemm(A, B, C, tA, tB, beta=0.0):
         # small outputs reduced over a long axis (S2^T P2, S2^T X at level 2): too few tiles to fill the chip -> cut every
         # batch's reduction into slices (ragged-K over the flattened rows), combine deterministically
         parts = max(2, min(Kd // 128, -(-384 // (batch * (2 if N > 64 else 1)))))
-        ptr, step = _bsplit_ptr(batch, Kd, parts, A.device)
+        step = _split_chunk(Kd, parts)
+        parts = -(-Kd // step)
         ws = torch.empty(batch * parts, M * N, dtype=torch.float32, device=A.device)
-        K().gemm(A, B, ws, M, N, 0, True, False, lda, ldb, N, 1.0, 0.0, None, batch * parts, 0, 0, M * N,
-                 ptr, 2, step, batch * Kd)
+        K().gemm(A, B, ws, M, N, Kd, True, False, lda, ldb, N, 1.0, 0.0, None, batch * parts, 0, 0, M * N,
+                 None, 3, step, batch * Kd)
         K().reduce_batched(ws, C, batch, parts, M * N, beta)
         return
     K().gemm(A, B, C, M, N, Kd, tA, tB, lda, ldb, ldc, 1.0, beta, None, batch, A.stride(0), B.stride(0), C.stride(0))

@@ -122,7 +122,11 @@ int cgc_spmm_graphs_ordered(const int* rowptr, const int* col, const int* perm, 
  * C_b = alpha*op(A_b)*op(B_b) + beta*C_b (+ bias[N]);  op(A): M x K (transA: stored [K,M]); op(B): K x N (transB: stored [N,K]).
  * Operand b starts at base + b*stride.  ragged=1: M_b = gptr[b+1]-gptr[b]; A (transA must be 0) and C advance gptr[b] rows.
  * ragged=2: K_b = gptr[b+1]-gptr[b]; A (transA must be 1) and B (transB must be 0) advance gptr[b] rows.
- * max_ragged >= max_b of the ragged extent (sizes the grid). */
+ * max_ragged >= max_b of the ragged extent (sizes the grid).
+ * ragged=3 (uniform row chunks: split-K without an offset array): batch = outer * parts items, parts = ceil(K / max_ragged); item
+ * (o, p) reduces over rows [o*K + p*max_ragged, o*K + min((p+1)*max_ragged, K)) of A (transA = 1) and B (transB = 0), the
+ * flattened [outer*K, .] row blocks (strideA / strideB ignored), and writes C + (o*parts + p)*strideC: partial products for
+ * cgc_reduce_batch_sum / cgc_reduce_batched. */
 int cgc_gemm_f32(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
                  const float* B, int ldb, float beta, float* C, int ldc, const float* bias, int batch,
                  int64_t strideA, int64_t strideB, int64_t strideC, const int* gptr, int ragged, int max_ragged,
@@ -276,6 +280,87 @@ int cgc_adj_prep_fwd(const float* A, int R, int C, float p, float* At, float* An
  * dAt = invd*(gAn - ge1*<gAn,An>_row) + gAt, dA = backward of the re-normalisation at dAt (dA = dAt when p < 0). */
 int cgc_adj_prep_bwd(const float* A, const float* An, const float* invd, const float* ge1, const float* gAn, const float* gAt,
                      int R, int C, float p, float* dA, cgc_stream_t stream);
+
+/* ---- small layout helpers of the step sequencer (also usable on their own) */
+/* dst[r, off_i : off_i + width_i] (=, or += when accumulate != 0) src_i[r, 0:width_i], off_i = width_0 + .. + width_{i-1}: the column
+ * concatenation torch.cat(srcs, dim=1) (model/network.py:118) / its gradient scatter, for up to 4 sources with their own row strides. */
+int cgc_cat_cols(float* dst, int ldd, int rows, int nsrc, const float* const* srcs, const int* lds, const int* widths,
+                 int accumulate, cgc_stream_t stream);
+/* dst [cols, rows] (row stride ldd) = src [rows, cols] (row stride lds) transposed */
+int cgc_transpose(const float* src, int lds, int rows, int cols, float* dst, int ldd, cgc_stream_t stream);
+
+/* ==== Step sequencer (round 3): one level of SoftPoolingGcnEncoder.forward (model/network.py:258-268 | :270-278 | :279-285) and
+ * its backward as ONE call each.  A level = optional adjacency preparation (levels 2-3) -> the embedding block and (levels 1-2)
+ * the assignment block run layer by layer in lockstep (GNN_Module.forward, model/network.py:109-125) -> DenseJK -> max readout ->
+ * Linear over cat + softmax -> _diff_pool.  The call enqueues the same kernels, in the same order, that the per-operator entry
+ * points above would be asked for one by one by a Python autograd graph (328 launches per step) -- without Python, without
+ * autograd nodes, without per-launch allocations: activations live in two caller-provided arenas.  Stateless like everything
+ * else here: no allocation, no synchronisation, safe for concurrent callers with distinct arenas.
+ * Scope: DenseSAGEConv blocks (normalize, add_loop = False), training mode (BatchNorm batch statistics) or no BatchNorm, fixed
+ * momentum; anything else stays on the per-operator path.                                                                     */
+typedef struct {
+  int level;              /* 1: flat rows + CSR; 2, 3: dense [B, C, .] tensors */
+  int B;                  /* graphs */
+  int n;                  /* rows: total nodes (level 1) or B * rows_per_graph */
+  int rows_per_graph;     /* levels 2-3: clusters of the previous level; level 1: 0 */
+  int nmax, npad;         /* level 1: largest graph; rows per graph of the reference's dense layout (readout vs zero padding) */
+  int fin;                /* input features */
+  int H, E;               /* embedding block: hidden width, last-layer width */
+  int AH, C;              /* assignment block: hidden width, clusters; C = 0: no assignment block (level 3) */
+  int has_bias, has_bn, act, jk, renorm;   /* jk: DenseJK over the embedding block's three outputs (needs H == E) */
+  float renorm_p;
+  float bn_eps[6], bn_momentum[6];         /* embedding block layers 0..2, assignment block layers 3..5 */
+  double count;           /* rows BatchNorm statistics are taken over: B * npad (level 1, padding included), n otherwise */
+} cgc_level_desc;
+
+typedef struct {          /* one GNN_Module's parameters (DEVICE pointers; unused ones NULL) */
+  const float* W[3];      /* DenseSAGEConv.weight [in, out] */
+  const float* b[3];
+  const float* gamma[3];
+  const float* beta[3];
+  float* running_mean[3];
+  float* running_var[3];
+  int64_t* num_batches_tracked[3];
+  const float* lin_W;     /* nn.Linear(2 AH + C, C).weight [C, 2 AH + C] (assignment block only) */
+  const float* lin_b;
+} cgc_block_params;
+
+typedef struct {
+  const float* lstm[8];   /* as cgc_jk_lstm_fwd */
+  const float* w_att;
+  const float* b_att;
+} cgc_jk_params;
+
+typedef struct {          /* level 1: what graph.BatchGraph holds */
+  const int* rowptr; const int* col; const int* t_rowptr; const int* t_col;
+  const float* val; const float* t_val;   /* NULL without _re_norm_adj */
+  const float* inv_d;
+  const int* gorder;      /* NULL or the visiting sequence of cgc_spmm_graphs_ordered */
+} cgc_graph;
+
+typedef struct {          /* element offsets into the gradient buffer of cgc_level_bwd; -1 = absent */
+  int64_t W[6], b[6], bn_weight[6], bn_bias[6];   /* layers 0..2 embedding block, 3..5 assignment block */
+  int64_t lin_W, lin_b;
+  int64_t jk;             /* cgc_jk_param_grad_floats(H) floats in parameter order */
+  int64_t total;
+} cgc_level_grad_layout;
+
+int cgc_level_supported(const cgc_level_desc* d);                      /* 1 if the sequencer covers this configuration */
+int64_t cgc_level_saved_floats(const cgc_level_desc* d);               /* arena kept from cgc_level_fwd to cgc_level_bwd */
+int64_t cgc_level_scratch_floats(const cgc_level_desc* d);             /* arena either call may overwrite */
+int cgc_level_grad_layout_of(const cgc_level_desc* d, cgc_level_grad_layout* out);
+/* x_in [n, fin]; A_in [B, C, C] (levels 2-3; NULL at level 1); gptr [B+1] first row of every graph.
+ * Out: readout [B, D] (D = H with jk, else 2H + E); x_out [B, C, D] and A_out [B, C, C] (levels 1-2); assign_out (optional, may be
+ * NULL): receives the address of the assignment matrix S [n, C] inside `saved` and *assign_ld its row stride. */
+int cgc_level_fwd(const cgc_level_desc* d, const cgc_block_params* emb, const cgc_block_params* pool, const cgc_jk_params* jk,
+                  const cgc_graph* g, const int* gptr, const float* x_in, const float* A_in, float* saved, float* scratch,
+                  float* readout, float* x_out, float* A_out, const float** assign_out, int* assign_ld, cgc_stream_t stream);
+/* d_readout [B, D]; d_x_out / d_A_out: gradients of x_out / A_out (NULL at level 3).  Out: grads (cgc_level_grad_layout_of),
+ * d_x_in [n, fin] and d_A_in [B, C, C] (levels 2-3; NULL at level 1: the input features carry no gradient). */
+int cgc_level_bwd(const cgc_level_desc* d, const cgc_block_params* emb, const cgc_block_params* pool, const cgc_jk_params* jk,
+                  const cgc_graph* g, const int* gptr, const float* x_in, const float* A_in, const float* saved, float* scratch,
+                  const float* d_readout, const float* d_x_out, const float* d_A_out, float* grads, float* d_x_in, float* d_A_in,
+                  cgc_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -190,6 +190,13 @@ class TorchKernels(KernelSpec):
                 assert k <= max_ragged
                 oa += g[b] * lda
                 ob += g[b] * ldb
+            elif ragged == 3:        # uniform row chunks of max_ragged rows; K = rows per outer item (include/cgc_hip.h)
+                assert transA and not transB and not extra
+                parts = -(-K // max_ragged)
+                outer, part = divmod(b, parts)
+                g0 = outer * K + part * max_ragged
+                k = min(max_ragged, K - part * max_ragged)
+                oa, ob = g0 * lda, g0 * ldb
             a = _mat(A, k, m, lda, oa).t() if transA else _mat(A, m, k, lda, oa)
             bm = _mat(B, N, k, ldb, ob).t() if transB else _mat(B, k, N, ldb, ob)
             c = _mat(C, m, N, ldc, oc)

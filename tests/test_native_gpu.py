@@ -1,0 +1,122 @@
+"""GPU: the step sequencer (cgc_level_fwd / cgc_level_bwd, csrc/exec.hip, native.py) against the per-operator path (ops.py).
+
+Both enqueue the same kernels on the same operands, so logits, loss, assignment matrices, every parameter gradient and the
+BatchNorm buffers must agree BIT FOR BIT wherever the two schedules are the same arithmetic (the shipped widths); elsewhere to
+rounding.  The per-operator path is itself held to the oracle / the reference fixtures by test_model_gpu.py."""
+import pytest
+import torch
+
+import cgc_net_amd  # noqa: F401
+from cgc_net_amd import network
+from cgc_net_amd.data import Batch, SyntheticCellGraphs
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _pair(args, kw, seed=5):
+    torch.manual_seed(seed)
+    a = network.SoftPoolingGcnEncoder(*args, **kw).to(DEV)
+    b = network.SoftPoolingGcnEncoder(*args, **kw).to(DEV)
+    b.load_state_dict(a.state_dict())
+    a.native, b.native = True, False
+    return a.train(), b.train()
+
+
+def _used_native(model, batch):
+    calls = []
+    orig = network.native.level
+
+    def spy(*a, **k):
+        calls.append(1)
+        return orig(*a, **k)
+    network.native.level = spy
+    try:
+        out = model(batch)
+    finally:
+        network.native.level = orig
+    return out, len(calls)
+
+
+CASES = [
+    ('plain_c60', (600, 16, 20, 20, True, True, 20, 3, 0.1, [50]), dict(), 6, 300),
+    ('shipped_c60', (600, 16, 20, 20, True, True, 20, 3, 0.1, [50]), dict(norm_adj=True, jk=True), 6, 300),
+    ('shipped_leaky_c60', (600, 16, 20, 20, True, True, 20, 3, 0.1, [50]), dict(norm_adj=True, jk=True, activation='leakyrelu'), 5, 300),
+    ('nobn_elu', (600, 16, 20, 20, True, False, 20, 3, 0.1, [50]), dict(norm_adj=True, activation='elu'), 4, 200),
+    ('shipped_c1140_b3', (11404, 16, 20, 20, True, True, 20, 3, 0.1, [50]), dict(norm_adj=True, jk=True), 3, 1800),
+    ('plain_c1140_b2', (11404, 16, 20, 20, True, True, 20, 3, 0.1, [50]), dict(), 2, 1500),
+    ('wide_features', (1600, 64, 20, 20, True, True, 20, 3, 0.1, [50]), dict(norm_adj=True, jk=True), 3, 500),
+    ('hidden16', (800, 16, 16, 16, True, True, 16, 3, 0.1, [50]), dict(norm_adj=True, jk=True), 4, 300),
+]
+
+
+@pytest.mark.parametrize('name,args,flags,B,nodes', CASES, ids=[c[0] for c in CASES])
+def test_sequencer_equals_per_operator_path(name, args, flags, B, nodes):
+    ds = SyntheticCellGraphs(2 * B, nodes, num_features=args[1], base_seed=11)
+    batches = [Batch.from_data_list([ds[i] for i in range(lo, lo + B)]).to(DEV) for lo in (0, B)]
+    kw = dict(concat=True, load_data_sparse=True, drop_out=0., collect_assign=True)
+    kw.update(flags)
+    nat, ref = _pair(args, kw)
+    opts = [torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=1e-4) for m in (nat, ref)]
+    worst = 0.0
+    for step in range(3):
+        b = batches[step % 2]
+        (ln, lossn), ncalls = _used_native(nat, b)
+        assert ncalls == 3, 'the sequencer did not take all three levels'
+        (lr, lossr), rcalls = _used_native(ref, b)
+        assert rcalls == 0
+        for o, m in zip(opts, (nat, ref)):
+            o.zero_grad()
+        lossn.backward()
+        lossr.backward()
+        pairs = [('logits', ln, lr), ('loss', lossn, lossr)]
+        pairs += [('assign%d' % i, a, c) for i, (a, c) in enumerate(zip(nat.assign_matrix, ref.assign_matrix))]
+        gr = dict(ref.named_parameters())
+        for k, p in nat.named_parameters():
+            assert p.grad is not None and gr[k].grad is not None, k
+            pairs.append(('grad ' + k, p.grad, gr[k].grad))
+        br = dict(ref.named_buffers())
+        pairs += [('buffer ' + k, v, br[k]) for k, v in nat.named_buffers()]
+        for what, x, y in pairs:
+            assert x.shape == y.shape, what
+            if x.dtype.is_floating_point:
+                assert torch.isfinite(x).all(), what
+                err = float((x.double() - y.double()).abs().max() / (y.double().abs().max() + 1e-30)) if x.numel() else 0.0
+                worst = max(worst, err)
+                assert err < 2e-6, (step, what, err)
+            else:
+                assert torch.equal(x, y), what
+        for o in opts:
+            o.step()
+    print('%s: worst relative difference sequencer vs per-operator path %.3g' % (name, worst))
+
+
+def test_sequencer_bitwise_on_the_shipped_configuration():
+    """Same kernels, same operands, same order: bit-for-bit equal at the shipped widths (H = 20)."""
+    ds = SyntheticCellGraphs(4, 600, num_features=16, base_seed=3)
+    b = Batch.from_data_list([ds[i] for i in range(4)]).to(DEV)
+    nat, ref = _pair((11404, 16, 20, 20, True, True, 20, 3, 0.1, [50]), dict(concat=True, load_data_sparse=True, norm_adj=True, jk=True))
+    ln, lossn = nat(b)
+    lr, lossr = ref(b)
+    lossn.backward()
+    lossr.backward()
+    assert torch.equal(ln, lr) and torch.equal(lossn, lossr)
+    gr = dict(ref.named_parameters())
+    diff = [k for k, p in nat.named_parameters() if not torch.equal(p.grad, gr[k].grad)]
+    assert not diff, diff
+
+
+def test_sequencer_falls_back_outside_its_scope():
+    """Eval mode, GIN blocks and inputs that require a gradient stay on the per-operator path."""
+    ds = SyntheticCellGraphs(3, 200, num_features=16, base_seed=1)
+    b = Batch.from_data_list([ds[i] for i in range(3)]).to(DEV)
+    m = network.SoftPoolingGcnEncoder(400, 16, 20, 20, True, True, 20, 3, 0.1, [50], concat=True, load_data_sparse=True).to(DEV)
+    m.eval()
+    with torch.no_grad():
+        _, calls = _used_native(m, b)
+    assert calls == 0
+    g = network.SoftPoolingGcnEncoder(400, 16, 20, 20, True, True, 20, 3, 0.1, [50], concat=True, load_data_sparse=True,
+                                      gcn_name='GIN').to(DEV).train()
+    (_, loss), calls = _used_native(g, b)
+    assert calls == 0
+    loss.backward()
