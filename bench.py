@@ -73,6 +73,20 @@ def parse():
     return p.parse_args()
 
 
+def source_hash():
+    """sha256 over the kernel sources (cgc-net_amd/csrc/*.hip|*.hpp|Makefile, include/*.h): what the committed counter summaries
+    under profiles/ are stamped with, so that a number measured on other code is never quoted for this one."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, 'cgc-net_amd', 'csrc', '*.hip')) + glob.glob(os.path.join(ROOT, 'cgc-net_amd', 'csrc', '*.hpp'))
+                   + glob.glob(os.path.join(ROOT, 'include', '*.h')) + [os.path.join(ROOT, 'cgc-net_amd', 'csrc', 'Makefile')])
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, 'rb').read())
+    return h.hexdigest()
+
+
 def make_model(args, module):
     kw = dict(concat=True, gcn_name='SAGE', load_data_sparse=True)
     if args.flags == 'shipped':
@@ -216,13 +230,16 @@ def main():
 
     for i in range(args.warmup):
         step(batches[i % len(batches)])
-    K = kernels.get()
-    timer = None if args.no_kernel_timing else kernels.LaunchTimer()
+    kernels.get()
+    # HIP events around every launch of the dominant GEMM and of the wide SpMM (the library's measurement hook: recorded on the
+    # launch stream, also for launches issued by the step sequencer)
+    timer = None if args.no_kernel_timing else kernels.LaunchTimer(64 * args.steps + 64)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    K.timer = timer
+    if timer is not None:
+        timer.start()
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(batches[i % len(batches)])
@@ -231,7 +248,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    K.timer = None
+    if timer is not None:
+        timer.stop()
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -253,53 +271,77 @@ def main():
                                       args.maxn, c1, int(c1 * 0.1), args.flags),
                        'global_batch': args.batch * (1 if strong else world), 'nodes_per_batch': round(nodes),
                        'parallelism': 'dp%d' % world, 'includes': 'CSR build + fwd + loss + bwd + grad all-reduce + Adam',
-                       'hipgraph_dense_levels': bool(args.graph), 'node_order': 'grid cells' if args.spatial else 'draw order', 'fused_adam': not args.plain_adam},
+                       'step_sequencer': bool(getattr(model, 'native', False)) and not args.graph, 'hipgraph_dense_levels': bool(args.graph), 'node_order': 'grid cells' if args.spatial else 'draw order', 'fused_adam': not args.plain_adam},
         }
         if timer is not None:
-            s = timer.summary()
-            if 'gemm_128x128' in s:
-                g = s['gemm_128x128']
-                tf = g['rate'] / 1e12
-                out['roofline'] = {'kernel': 'k_gemm_f32<2,2,2,2,*> (fp32 MFMA 32x32x2, 128x128x32 tile; all launches of its NN/NT/TN instantiations)', 'bound': 'mfma',
+            recs = timer.records()
+            per_step = len(recs) // args.steps if args.steps and len(recs) % max(args.steps, 1) == 0 else 0
+            shipped = args.flags == 'shipped'
+            g_ms = g_fl = s_ms = s_by = 0.0
+            g_n = s_n = 0
+            for i, (tag, dims, ms) in enumerate(recs):
+                if not per_step:
+                    break
+                bi = (i // per_step) % len(cpu_batches)             # the batch this launch worked on
+                nb_nodes, nb_edges = cpu_batches[bi].x.shape[0], cpu_batches[bi].edge_index.shape[1]
+                if tag == 'gemm_128x128':
+                    g_ms += ms
+                    g_fl += kernels.LaunchTimer.gemm_flops(dims, nb_nodes)
+                    g_n += 1
+                elif tag == 'spmm_wide':
+                    n_, width = dims[0], dims[1]
+                    # algorithmic bytes: 8 n W (read X once, write Y once) + 4(n+1) + 4 nnz (+ 4 nnz weights; the re-normalised
+                    # adjacency also holds every diagonal entry)
+                    nnz = nb_edges + (nb_nodes if shipped else 0)
+                    s_ms += ms
+                    s_by += 8.0 * n_ * width + 4.0 * (n_ + 1) + (8.0 if dims[3] else 4.0) * nnz
+                    s_n += 1
+            if g_n:
+                tf = g_fl / (g_ms * 1e-3) / 1e12
+                out['roofline'] = {'kernel': 'k_gemm_f32<2,2,2,2,*> (fp32 MFMA 32x32x2, 128x128x32 tile; all launches of its NN/NT/TN instantiations, '
+                                             'tail fix-up kernel included)', 'bound': 'mfma',
                                    'achieved': round(tf, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                                    'frac': round(tf / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': None,
-                                   'launches_per_step': g['launches'] / args.steps, 'avg_launch_ms': round(g['avg_ms'], 4),
-                                   'gflop_per_launch': round(g['work_per_launch'] / 1e9, 3),
-                                   'ms_per_step': round(g['total_ms'] / args.steps, 3)}
-            if 'spmm_wide' in s:
-                g = s['spmm_wide']
-                # algorithmic bytes per launch: 8 n W (read X once, write Y once) + 4(n+1) + 4 nnz (+ 4 nnz weights)
-                idx = 4.0 * (nodes + 1) + (8.0 if args.flags == 'shipped' else 4.0) * (edges + (nodes if args.flags == 'shipped' else 0))
-                bytes_per_launch = g['work_per_launch'] + idx
-                gbs = bytes_per_launch / (g['avg_ms'] * 1e-3) / 1e9
+                                   'launches_per_step': g_n / args.steps, 'avg_launch_ms': round(g_ms / g_n, 4),
+                                   'gflop_per_launch': round(g_fl / g_n / 1e9, 3),
+                                   'ms_per_step': round(g_ms / args.steps, 3)}
+            if s_n:
+                gbs = s_by / (s_ms * 1e-3) / 1e9
                 out['roofline_aggregation'] = {'kernel': 'k_spmm_wide<9,*> (A*S and its transpose, width %d)' % c1, 'bound': 'hbm',
                                                'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                                'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': None,
-                                               'launches_per_step': g['launches'] / args.steps,
-                                               'avg_launch_ms': round(g['avg_ms'], 4),
-                                               'mb_per_launch': round(bytes_per_launch / 1e6, 2)}
-        # HBM traffic per launch and counter-derived matrix-core utilisation from the committed PMC passes of this same command
-        # (profiles/make_traffic_json.py, profiles/make_counters_json.py); null if absent or another configuration is run
+                                               'launches_per_step': s_n / args.steps,
+                                               'avg_launch_ms': round(s_ms / s_n, 4),
+                                               'mb_per_launch': round(s_by / s_n / 1e6, 2)}
+            timer.close()
+        # HBM traffic per launch and counter-derived matrix-core utilisation: from the committed PMC passes of this same command
+        # (profiles/make_traffic_json.py, profiles/make_counters_json.py) -- ONLY when they were taken on exactly this kernel source
+        # (sha256 over csrc/ + include/, stamped into the json); otherwise null + "stale"
         if args.flags == 'shipped' and args.maxn == 11404 and args.batch == 32 and args.nodes == 1800:
-            try:
-                tr = json.load(open(os.path.join(ROOT, 'profiles', 'r02_traffic.json')))
-                if 'roofline' in out and 'gemm_128x128' in tr:
-                    out['roofline']['traffic'] = round(tr['gemm_128x128']['hbm_bytes_per_launch'])
-                    out['roofline']['traffic_source'] = 'profiles/r02_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes/launch)'
-                if 'roofline_aggregation' in out and 'spmm_wide' in tr:
-                    out['roofline_aggregation']['traffic'] = round(tr['spmm_wide']['hbm_bytes_per_launch'])
-                    out['roofline_aggregation']['traffic_source'] = 'profiles/r02_traffic.json'
-            except (OSError, ValueError, KeyError):
-                pass
-            try:
-                cn = json.load(open(os.path.join(ROOT, 'profiles', 'r02_counters.json')))
-                if 'roofline' in out and cn.get('gemm_128x128', {}).get('mfma_busy') is not None:
-                    out['roofline']['mfma_busy_counter'] = cn['gemm_128x128']['mfma_busy']
-                    out['roofline']['mfma_busy_source'] = ('profiles/r02_counters.json: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x '
-                                                           'GRBM_GUI_ACTIVE/8) of this command under rocprofv3 --pmc (clock-independent; '
-                                                           'frac = mfma_busy x sustained clock / 2.4 GHz)')
-            except (OSError, ValueError, KeyError):
-                pass
+            src = source_hash()
+            for key, fname in (('traffic', 'r03_traffic.json'), ('counters', 'r03_counters.json')):
+                try:
+                    js = json.load(open(os.path.join(ROOT, 'profiles', fname)))
+                except (OSError, ValueError):
+                    continue
+                fresh = js.get('source_sha256') == src
+                for obj, tag in (('roofline', 'gemm_128x128'), ('roofline_aggregation', 'spmm_wide')):
+                    if obj not in out or tag not in js:
+                        continue
+                    if key == 'traffic':
+                        if fresh:
+                            out[obj]['traffic'] = round(js[tag]['hbm_bytes_per_launch'])
+                            out[obj]['traffic_source'] = 'profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes/launch; same kernel source)' % fname
+                        else:
+                            out[obj]['traffic_stale'] = True
+                    elif tag == 'gemm_128x128' and js[tag].get('mfma_busy') is not None:
+                        if fresh:
+                            out[obj]['mfma_busy_counter'] = js[tag]['mfma_busy']
+                            out[obj]['mfma_busy_source'] = ('profiles/%s: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE/8) of this '
+                                                            'command under rocprofv3 --pmc, same kernel source (clock-independent; frac = '
+                                                            'mfma_busy x sustained clock / 2.4 GHz)' % fname)
+                        else:
+                            out[obj]['mfma_busy_stale'] = True
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args, cpu_batches)
         print(json.dumps(out), flush=True)

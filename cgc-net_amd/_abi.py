@@ -57,6 +57,11 @@ PROTOTYPES = {
     'cgc_dense_renorm_bwd': [P, P, I, I, F, P, P],
     'cgc_adj_prep_fwd': [P, I, I, F, P, P, P, P, P],
     'cgc_adj_prep_bwd': [P, P, P, P, P, P, I, I, F, P, P],
+    'cgc_timing_create': [I],
+    'cgc_timing_attach': [P],
+    'cgc_timing_count': [P],
+    'cgc_timing_read': [P, I, P, P],
+    'cgc_timing_destroy': [P],
     'cgc_cat_cols': [P, I, I, I, P, P, P, I, P],
     'cgc_transpose': [P, I, I, I, P, I, P],
     # step sequencer (csrc/exec.hip; the struct arguments are ctypes Structures of native.py passed by reference)
@@ -74,4 +79,7 @@ def declare(lib):
     for name, argtypes in PROTOTYPES.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
+        if name == 'cgc_timing_create':
+            fn.restype = P          # a handle, not a status
+            continue
         fn.restype = C.c_int64 if name.endswith(('_ws_ints', '_ws_floats', '_offset', '_grad_floats', '_saved_floats', '_scratch_floats')) else C.c_int

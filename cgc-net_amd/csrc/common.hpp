@@ -14,6 +14,12 @@
     if (e__ != hipSuccess) return (int)e__;             \
   } while (0)
 
+// measurement hook (timing.hip): index of the record or -1 when no observer is attached
+#define CGC_TAG_GEMM_128 1
+#define CGC_TAG_SPMM_WIDE 2
+int cgc_timing_begin(int tag, int d0, int d1, int d2, int d3, int d4, int d5, int d6, hipStream_t stream);
+void cgc_timing_end(int idx, hipStream_t stream);
+
 static inline hipStream_t as_stream(cgc_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }

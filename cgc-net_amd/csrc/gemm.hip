@@ -924,6 +924,11 @@ static int launch_cfg(const GemmArgs& a0, int transA, int transB, int batch, int
     }
   }
   dim3 grid((unsigned)(tiles + extra)), block(256);
+  int xk = 0;
+  for (int i = 0; i < a.nx; ++i) xk += a.xK[i];
+  const int trec = (BM == 128 && BN == 128 && !short_k)
+                       ? cgc_timing_begin(CGC_TAG_GEMM_128, a.M, a.N, a.K, batch, a.ragged, a.ragged ? (a.ragged == 1 ? m_extent : k_extent) : 0, xk, stream)
+                       : -1;
   static const int fast_on = getenv("CGC_GEMM_FAST") ? atoi(getenv("CGC_GEMM_FAST")) : 1;   // CGC_GEMM_FAST=0: A-B timing against the guarded kernel
   const bool fast = fast_on && gemm_all_fast(a, transA, transB, batch);
   if (short_k) {
@@ -946,6 +951,7 @@ static int launch_cfg(const GemmArgs& a0, int transA, int transB, int batch, int
     hipLaunchKernelGGL((k_gemm_fixup<WGM, WGN, TM, TN>), dim3((unsigned)(lmax * 4 * TM * TN)), dim3(64), 0, stream, a);
     CGC_RETURN_IF_LAUNCH_FAILED();
   }
+  cgc_timing_end(trec, stream);
   return 0;
 }
 

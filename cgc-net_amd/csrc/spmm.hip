@@ -425,5 +425,8 @@ extern "C" int cgc_spmm_graphs_ordered(const int* rowptr, const int* col, const 
     if ((size_t)nmax * 4 * 4 <= budget) return k_thr >= 1024 ? launch_slab<4, 1024>(SLAB_ARGS) : launch_slab<4, 512>(SLAB_ARGS);
 #undef SLAB_ARGS
   }
-  return launch_gather(rowptr, col, perm, val, pre, post, x, out, n, width, ld, gptr, B, nmax, visit, as_stream(stream), gorder);
+  const int trec = width > 64 ? cgc_timing_begin(CGC_TAG_SPMM_WIDE, n, width, ld, val != nullptr, 0, 0, 0, as_stream(stream)) : -1;
+  const int rc = launch_gather(rowptr, col, perm, val, pre, post, x, out, n, width, ld, gptr, B, nmax, visit, as_stream(stream), gorder);
+  cgc_timing_end(trec, as_stream(stream));
+  return rc;
 }

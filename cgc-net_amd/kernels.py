@@ -283,32 +283,60 @@ def _ptr(t):
 
 
 class LaunchTimer(object):
-    """Optional HIP-event timing of selected launches (bench.py): events are recorded on the stream the
-    kernels are launched on (torch's current stream) and read back after the timed region."""
+    """HIP-event timing of every launch of the dominant 128 x 128 GEMM and of the wide SpMM between ``start()`` and ``stop()``
+    (the library's measurement hook, csrc/timing.hip: events on the stream of the launch, whoever issues it -- the per-operator
+    path or the step sequencer).  ``records()`` after a synchronize: list of (tag, dims, ms)."""
+    TAGS = {1: 'gemm_128x128', 2: 'spmm_wide'}
 
-    def __init__(self):
-        self.records = {}       # tag -> list of (start_event, end_event, work) ; work = flops or bytes of the launch
+    def __init__(self, capacity=8192):
+        self.lib = get().lib
+        self.h = self.lib.cgc_timing_create(int(capacity))
+        if not self.h:
+            raise RuntimeError('cgc_timing_create failed')
 
-    def begin(self):
-        e = torch.cuda.Event(enable_timing=True)
-        e.record()
-        return e
+    def start(self):
+        self.lib.cgc_timing_attach(self.h)
+        return self
 
-    def end(self, tag, start, work):
-        e = torch.cuda.Event(enable_timing=True)
-        e.record()
-        self.records.setdefault(tag, []).append((start, e, work))
+    def stop(self):
+        self.lib.cgc_timing_attach(None)
 
-    def summary(self):
-        """tag -> dict(launches, total_ms, avg_ms, work_per_launch, rate = work/s) (call after synchronize)."""
-        out = {}
-        for tag, recs in self.records.items():
-            ms = [s.elapsed_time(e) for s, e, _ in recs]
-            work = sum(w for _, _, w in recs)
-            tot = sum(ms)
-            out[tag] = dict(launches=len(recs), total_ms=tot, avg_ms=tot / len(recs), work_per_launch=work / len(recs),
-                            rate=work / (tot * 1e-3) if tot > 0 else 0.0)
+    def records(self):
+        out = []
+        dims, ms = (ctypes.c_int * 8)(), ctypes.c_float()
+        for i in range(self.lib.cgc_timing_count(self.h)):
+            rc = self.lib.cgc_timing_read(self.h, i, dims, ctypes.byref(ms))
+            if rc != 0:
+                raise RuntimeError('cgc_timing_read failed with code %d' % rc)
+            out.append((self.TAGS.get(dims[0], str(dims[0])), tuple(dims[1:8]), float(ms.value)))
         return out
+
+    def counts(self):
+        c = {}
+        for i in range(self.lib.cgc_timing_count(self.h)):
+            dims, ms = (ctypes.c_int * 8)(), ctypes.c_float()
+            self.lib.cgc_timing_read(self.h, i, dims, ctypes.byref(ms))
+            c[self.TAGS.get(dims[0], str(dims[0]))] = c.get(self.TAGS.get(dims[0], str(dims[0])), 0) + 1
+        return c
+
+    def close(self):
+        if self.h:
+            self.lib.cgc_timing_destroy(self.h)
+            self.h = None
+
+    @staticmethod
+    def gemm_flops(dims, ragged_total):
+        """Algorithmic flops 2 M N K of a recorded GEMM launch; ``ragged_total`` = the rows the ragged extents add up to (the
+        batch's node count: the library does not know it)."""
+        M, N, K, batch, ragged, _, xk = dims
+        if ragged == 1:
+            return 2.0 * ragged_total * N * (K + xk)
+        if ragged == 2:
+            return 2.0 * M * N * ragged_total
+        if ragged == 3:
+            parts = -(-K // dims[5])
+            return 2.0 * M * N * K * (batch // parts)
+        return 2.0 * M * N * (K + xk) * batch
 
 
 class _NoWorkspace(object):
@@ -325,7 +353,6 @@ _NO_WS = _NoWorkspace()
 
 
 class HipKernels(KernelSpec):
-    timer = None   # set to a LaunchTimer by bench.py during the timed region
     tail_split = True   # hand cgc_gemm_f32_ws its slab workspace (False: every output tile is computed whole; tests / A-B timing)
 
     def __init__(self):
@@ -438,7 +465,6 @@ class HipKernels(KernelSpec):
     def spmm(self, rowptr, col, perm, val, pre, post, x, out, n, width, gptr=None, num_graphs=0, nmax=0, visit=0, ld=None, gorder=None):
         self._dev(rowptr, col, perm, val, pre, post, x, out, gptr)
         assert (x.is_contiguous() and out.is_contiguous()) if ld is None else (gptr is not None and x.stride(1) == 1 and out.stride(1) == 1)
-        t0 = self.timer.begin() if (self.timer is not None and width > 64) else None
         if gptr is not None:
             self._chk(self.lib.cgc_spmm_graphs_ordered(_ptr(rowptr), _ptr(col), _ptr(perm), _ptr(val), _ptr(pre), _ptr(post),
                                                        _ptr(x), _ptr(out), n, width, width if ld is None else ld, _ptr(gptr),
@@ -446,8 +472,6 @@ class HipKernels(KernelSpec):
         else:
             self._chk(self.lib.cgc_spmm(_ptr(rowptr), _ptr(col), _ptr(perm), _ptr(val), _ptr(pre), _ptr(post),
                                         _ptr(x), _ptr(out), n, width, self._stream()), 'cgc_spmm')
-        if t0 is not None:      # work = (width, weighted): bench.py turns it into algorithmic bytes with the batch's nnz
-            self.timer.end('spmm_wide', t0, 8.0 * n * width)
 
     # -- dense contractions
     def _gemm_ws(self, device, stream):
@@ -464,20 +488,6 @@ class HipKernels(KernelSpec):
     def gemm(self, A, B, C, M, N, K, transA, transB, lda, ldb, ldc, alpha=1.0, beta=0.0, bias=None,
              batch=1, strideA=0, strideB=0, strideC=0, gptr=None, ragged=0, max_ragged=0, ragged_total=0, extra=()):
         self._dev(A, B, C, bias, gptr)
-        t0 = None
-        if self.timer is not None:
-            # time exactly the launches that gemm_dispatch() (csrc/gemm.hip) sends to the 128x128 pipelined kernel
-            # k_gemm_f32<2,2,2,2,*>: N > 64, more than 64 rows, enough tiles to fill the chip, reduction longer than 160
-            m_ext = max_ragged if ragged == 1 else M
-            k_ext = max_ragged if ragged >= 2 else K
-            fill = -(-m_ext // 128) * batch
-            if N > 64 and m_ext > 64 and fill * (-(-N // 128)) >= 448 and (k_ext > 160 or extra):
-                kk = K + sum(e[4] for e in extra)
-                if ragged:   # ragged extents sum to ragged_total rows
-                    flops = 2.0 * (M if ragged >= 2 else kk) * N * ragged_total
-                else:
-                    flops = 2.0 * M * N * kk * batch
-                t0 = self.timer.begin()
         stream = self._stream()
         ws = self._gemm_ws(C.device, stream)
         if extra:
@@ -498,8 +508,6 @@ class HipKernels(KernelSpec):
                                           ctypes.c_int64(strideA), ctypes.c_int64(strideB), ctypes.c_int64(strideC),
                                           _ptr(gptr), ragged, max_ragged, ws.data_ptr(), ws.numel(), stream)
         self._chk(rc, 'cgc_gemm_f32')
-        if t0 is not None:
-            self.timer.end('gemm_128x128', t0, flops)
 
     def reduce_batch_sum(self, ws, out, parts, numel, beta=0.0):
         self._dev(ws, out)

@@ -362,6 +362,17 @@ int cgc_level_bwd(const cgc_level_desc* d, const cgc_block_params* emb, const cg
                   const float* d_readout, const float* d_x_out, const float* d_A_out, float* grads, float* d_x_in, float* d_A_in,
                   cgc_stream_t stream);
 
+/* ==== Measurement hook (csrc/timing.hip): HIP events around every launch of the dominant 128 x 128 GEMM (tag 1) and of the wide
+ * SpMM (tag 2), recorded on the stream of the launch, whoever asked for it (per-operator call or step sequencer).  One observer
+ * per process; nothing is recorded -- and nothing costs anything -- unless one is attached.  After the stream has been
+ * synchronised, record i gives tag_and_dims[8] = {tag, M, N, K, batch, ragged, ragged extent bound, extra K} (GEMM) or
+ * {tag, n, width, ld, weighted, 0, 0, 0} (SpMM) and the elapsed milliseconds. */
+void* cgc_timing_create(int max_records);
+int cgc_timing_attach(void* handle /* NULL detaches */);
+int cgc_timing_count(void* handle);
+int cgc_timing_read(void* handle, int i, int* tag_and_dims, float* ms);
+int cgc_timing_destroy(void* handle);
+
 #ifdef __cplusplus
 }
 #endif

@@ -200,16 +200,31 @@ def compare_model(cpu_batch, maxn, feat, flags, tol_grad=1e-4, timer=None, seed=
     ref.train()
     ref64 = copy.deepcopy(ref).double()
     ref64.load_data_sparse = False
-    K = kernels.get()
-    K.timer = timer
-    try:
-        with record_hip_decisions(model) as dec:
-            logits, loss = model(cpu_batch.to(DEV))
-            loss.backward()
-            torch.cuda.synchronize()
-    finally:
-        K.timer = None
+    # The decisions are recorded on the per-operator path (its Python-level operators are where the spies sit); the path under
+    # test is the DEFAULT one -- the step sequencer wherever it covers the configuration -- which enqueues the same kernels on
+    # the same operands: its outputs must be bitwise those of the twin, so the twin's decisions are its decisions.
+    twin = network.SoftPoolingGcnEncoder(*args, **kw)
+    twin.load_state_dict(ref.state_dict())
+    twin.to(DEV).train()
+    twin.native = False
+    with record_hip_decisions(twin) as dec:
+        tl, tloss = twin(cpu_batch.to(DEV))
+        tloss.backward()
+        torch.cuda.synchronize()
     assert kernels.is_native() and len(dec.winners) == 3
+    if timer is not None:
+        timer.start()
+    try:
+        logits, loss = model(cpu_batch.to(DEV))
+        loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        if timer is not None:
+            timer.stop()
+    assert torch.equal(logits, tl) and torch.equal(loss, tloss), 'sequencer and per-operator path disagree'
+    tg = dict(twin.named_parameters())
+    for k, p in model.named_parameters():
+        assert torch.equal(p.grad, tg[k].grad), ('sequencer and per-operator path disagree', k)
     rl, rloss = ref(cpu_batch)
     rloss.backward()
     adj = dense_ref.to_dense_adj(cpu_batch.edge_index, cpu_batch.batch)

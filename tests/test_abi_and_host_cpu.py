@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     import __graft_entry__ as ge
     ge.build()
     header = open(os.path.join(ROOT, 'include', 'cgc_hip.h')).read()
-    declared = set(re.findall(r'^(?:int|int64_t) (cgc_\w+)\(', header, flags=re.M))
+    declared = set(re.findall(r'^(?:int|int64_t|void\*) (cgc_\w+)\(', header, flags=re.M))
     assert declared == set(_abi.PROTOTYPES), declared ^ set(_abi.PROTOTYPES)
     lib = ctypes.CDLL(kernels.lib_path())
     for name in declared:

@@ -44,25 +44,31 @@ def check(got, want64, what):
 
 
 class _Spy(object):
-    """Counts the launches that gemm_dispatch sends to the 128x128 kernel (same predicate as kernels.LaunchTimer users)."""
+    """Counts the launches that gemm_dispatch sends to the 128x128 kernel and the wide SpMM launches: the library's measurement
+    hook (kernels.LaunchTimer), so launches issued by the step sequencer are seen as well."""
 
     def __init__(self):
-        self.records = {}
+        self.t = kernels.LaunchTimer(512)
 
-    def begin(self):
-        return self
+    def start(self):
+        self.t.start()
 
-    def end(self, tag, start, work):
-        self.records[tag] = self.records.get(tag, 0) + 1
+    def stop(self):
+        self.t.stop()
+
+    @property
+    def records(self):
+        torch.cuda.synchronize()
+        return self.t.counts()
 
 
 @pytest.fixture
 def spy():
-    K = kernels.get()
     s = _Spy()
-    K.timer = s
+    s.start()
     yield s
-    K.timer = None
+    s.stop()
+    s.t.close()
 
 
 COUNTS = [1790, 2150, 1475, 1803, 1999, 1644, 2161, 1440]     # B = 8 ragged graphs (C3 node counts): 9 x 8 x 9 = 648 tiles >= 448;
@@ -152,7 +158,9 @@ def _compare_model(cpu_batch, maxn, feat, flags):
     """tests/discrete.py::compare_model with the kernel-name spy of this file: returns (launch counts, worst gradient)."""
     spy = _Spy()
     worst = discrete.compare_model(cpu_batch, maxn, feat, flags, timer=spy)
-    return spy.records, worst
+    rec = spy.records
+    spy.t.close()
+    return rec, worst
 
 
 @pytest.mark.parametrize('flags', [dict(norm_adj=True, jk=True), dict()], ids=['shipped', 'plain'])
