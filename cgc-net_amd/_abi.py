@@ -33,11 +33,13 @@ PROTOTYPES = {
     'cgc_l2norm_act_bn': [P, I, I, I, I, P, P, P, D, F, F, P, P, P, P, P, P],
     'cgc_sage_wide_fwd': [P, I, P, P, I, I, I, I, I, P, I, P, I, P, D, F, F, P, P, P, P, P, P],
     'cgc_bn_act_apply': [P, I, I, I, P, P, P, P, P, I, P],
+    'cgc_bn_act_apply2': [P, I, I, I, P, P, P, P, P, I, P, I, P],
     'cgc_bn_bwd_reduce': [P, I, P, I, I, I, P, P, P, P, P],
     'cgc_bn_act_l2_bwd': [P, I, P, P, I, I, I, I, I, P, P, P, P, D, P, P, P, P],
     'cgc_sage_narrow_fwd': [P, I, P, P, I, I, I, I, I, P, P, I, P, D, F, F, P, P, P, P, P, P],
     'cgc_sage_narrow_ws_floats': [I, I, I],
     'cgc_sage_narrow_bwd': [P, I, P, P, I, I, I, I, I, P, P, P, P, D, P, I, I, P, P, P, P, P],
+    'cgc_sage_narrow_bwd_ld': [P, I, P, P, I, I, I, I, I, P, P, P, P, D, P, I, I, P, P, I, P, P, P],
     'cgc_colsum': [P, I, I, I, P, P, P],
     'cgc_softmax_fwd': [P, I, I, I, P, P],
     'cgc_softmax_bwd': [P, P, I, I, I, P, P, P, P],
@@ -57,6 +59,8 @@ PROTOTYPES = {
     'cgc_dense_renorm_bwd': [P, P, I, I, F, P, P],
     'cgc_adj_prep_fwd': [P, I, I, F, P, P, P, P, P],
     'cgc_adj_prep_bwd': [P, P, P, P, P, P, I, I, F, P, P],
+    'cgc_head_fwd': [P, I, I, I, I, I, I, P, P, P, P, P, F, C.c_uint64, P, P, P, P],
+    'cgc_head_bwd': [P, I, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P],
     'cgc_timing_create': [I],
     'cgc_timing_attach': [P],
     'cgc_timing_count': [P],

@@ -256,7 +256,7 @@ inline size_t stats_ws_floats(int n, int F) { return (size_t)(cgc_stats_blocks(n
 
 // y = BN(act(l2norm(agg W + b)))  (ops._SageProject.forward)
 int layer_fwd(const Ctx& c, const cgc_level_desc& d, const LayerP& p, const LayerS& s, const float* agg, int lda, int n, int fin, int F,
-              float* y, int ldy) {
+              float* y, int ldy, float* y2 = nullptr, int ldy2 = 0) {
   const size_t m = c.scratch->mark();
   float* ws = d.has_bn ? c.scratch->f(stats_ws_floats(n, F)) : nullptr;
   int fused = 0;
@@ -278,15 +278,15 @@ int layer_fwd(const Ctx& c, const cgc_level_desc& d, const LayerP& p, const Laye
     else
       CALL(cgc_l2norm_act_stats(s.hn, n, F, 1, d.act, s.hn, s.rinv, nullptr, nullptr, c.s));
   }
-  CALL(cgc_bn_act_apply(s.hn, n, F, d.act, d.has_bn ? s.mean : nullptr, s.istd, p.gamma, p.beta, y, ldy, c.s));
+  CALL(cgc_bn_act_apply2(s.hn, n, F, d.act, d.has_bn ? s.mean : nullptr, s.istd, p.gamma, p.beta, y, ldy, y2, ldy2, c.s));
   c.scratch->release(m);
   return 0;
 }
 
-// backward of the same (ops._SageProject.backward): dagg (may be nullptr) [n, fin] contiguous; dwdb = [dW (fin*F) | db (F)];
+// backward of the same (ops._SageProject.backward): dagg (may be nullptr) [n, fin] with row stride ldd; dwdb = [dW (fin*F) | db (F)];
 // sums = [d beta (F) | d gamma (F)]
 int layer_bwd(const Ctx& c, const cgc_level_desc& d, const LayerP& p, const LayerS& s, const float* agg, int lda, int n, int fin, int F,
-              const float* dy, int ldy, float* dagg, float* dwdb, float* sums) {
+              const float* dy, int ldy, float* dagg, int ldd, float* dwdb, float* sums) {
   const size_t m = c.scratch->mark();
   const int mode = d.has_bn ? 2 : 0;
   const size_t slot_floats = (size_t)(cgc_stats_blocks(n, F) > 1 ? cgc_stats_blocks(n, F) : 1) * 2 * F;
@@ -297,14 +297,14 @@ int layer_bwd(const Ctx& c, const cgc_level_desc& d, const LayerP& p, const Laye
   float* db = d.has_bias ? dwdb + (size_t)fin * F : nullptr;
   if (F <= 32 && fin <= 32) {
     float* ws = c.scratch->f((size_t)cgc_sage_narrow_ws_floats(n, fin, F));
-    CALL(cgc_sage_narrow_bwd(dy, ldy, s.hn, s.rinv, n, F, d.act, 1, mode, s.mean, s.istd, p.gamma, d.has_bn ? sums : nullptr, d.count, agg, lda,
-                             fin, p.W, dagg, dwdb, ws, c.s));
+    CALL(cgc_sage_narrow_bwd_ld(dy, ldy, s.hn, s.rinv, n, F, d.act, 1, mode, s.mean, s.istd, p.gamma, d.has_bn ? sums : nullptr, d.count, agg,
+                                lda, fin, p.W, dagg, ldd, dwdb, ws, c.s));
   } else {
     float* dh = c.scratch->f((size_t)n * F);
     float* ws = db ? c.scratch->f(slot_floats) : nullptr;
     CALL(cgc_bn_act_l2_bwd(dy, ldy, s.hn, s.rinv, n, F, d.act, 1, mode, s.mean, s.istd, p.gamma, d.has_bn ? sums : nullptr, d.count, dh, db, ws,
                            c.s));
-    if (dagg) TRY(gemm(c, 0, 1, n, fin, F, dh, F, p.W, F, 0.f, dagg, fin));
+    if (dagg) TRY(gemm(c, 0, 1, n, fin, F, dh, F, p.W, F, 0.f, dagg, ldd));
     TRY(gemm_tn_rows(c, agg, lda, fin, dh, F, F, n, dwdb));
   }
   c.scratch->release(m);
@@ -317,7 +317,7 @@ struct Level {
   int n, B, R, fin, H, E, AH, C, D, D3, wp, ldC, ldP, ldW, ftot, npad_jk, seg_nmax;
   bool dense, pool, tall;
   // saved arena
-  float *At, *An, *invd, *ge1, *agg0, *pair[2], *aggk[2], *he3, *hp3, *cat_e, *HS, *CS, *jk_out, *x12, *S, *P;
+  float *At, *An, *invd, *ge1, *agg0, *pair[2], *aggk[2], *hp3, *cat_e, *HS, *CS, *jk_out, *x12, *S, *P;
   int* arg;
   LayerS L[6];
   // gradient layout
@@ -353,7 +353,6 @@ struct Level {
       pair[k] = a.f((size_t)n * wp);
       aggk[k] = a.f((size_t)n * wp);
     }
-    he3 = a.f((size_t)n * E);
     hp3 = pool ? a.f((size_t)n * ldC) : nullptr;
     for (int k = 0; k < 6; ++k) {
       const bool emb = k < 3;
@@ -449,23 +448,27 @@ int level_fwd(const Ctx& c, Level& L, const cgc_block_params* emb, const cgc_blo
   for (int k = 0; k < 3; ++k) {
     const float* ain = k == 0 ? L.agg0 : L.aggk[k - 1];
     const int lda = k == 0 ? L.fin : wp;
-    float* ye = k < 2 ? L.pair[k] : L.he3;
-    const int ldye = k < 2 ? wp : L.E;
-    TRY(layer_fwd(c, d, layer_params(d, emb, k, k), L.L[k], ain, lda, n, L.width_in(k), L.width_out(k), ye, ldye));
+    // a layer's output goes where the next aggregation reads it ([he | hp] side by side) AND into its slot of the block's
+    // concatenation (cat[x1, x2, x3] of the embedding block, [hp1 | hp2] of the assignment block): no concatenation kernels
+    if (k < 2)
+      TRY(layer_fwd(c, d, layer_params(d, emb, k, k), L.L[k], ain, lda, n, L.width_in(k), L.width_out(k), L.pair[k], wp, L.cat_e + k * H,
+                    L.D3));
+    else
+      TRY(layer_fwd(c, d, layer_params(d, emb, k, k), L.L[k], ain, lda, n, L.width_in(k), L.width_out(k), L.cat_e + 2 * H, L.D3));
     if (L.pool) {
-      float* yp = k < 2 ? L.pair[k] + H : L.hp3;
-      const int ldyp = k < 2 ? wp : L.ldC;
-      TRY(layer_fwd(c, d, layer_params(d, pl, k, 3 + k), L.L[3 + k], k == 0 ? ain : ain + H, lda, n, L.width_in(3 + k), L.width_out(3 + k), yp,
-                    ldyp));
+      const float* ainp = k == 0 ? ain : ain + H;
+      if (k < 2)
+        TRY(layer_fwd(c, d, layer_params(d, pl, k, 3 + k), L.L[3 + k], ainp, lda, n, L.width_in(3 + k), L.width_out(3 + k), L.pair[k] + H, wp,
+                      L.x12 + k * AH, 2 * AH));
+      else
+        TRY(layer_fwd(c, d, layer_params(d, pl, k, 3 + k), L.L[3 + k], ainp, lda, n, L.width_in(3 + k), L.width_out(3 + k), L.hp3, L.ldC));
     }
     if (k < 2) TRY(aggregate(c, L, g, gptr, L.pair[k], wp, L.aggk[k]));
   }
-  TRY(cat3(c, L.cat_e, L.D3, n, L.pair[0], wp, H, L.pair[1], wp, H, L.he3, L.E, L.E));
   if (d.jk) CALL(cgc_jk_lstm_fwd(L.cat_e, n, L.npad_jk, H, jk->lstm, jk->w_att, jk->b_att, L.jk_out, L.HS, L.CS, c.s));
   CALL(cgc_segment_max_fwd(L.embed(), gptr, L.B, L.D, L.seg_nmax, readout, L.arg, c.s));
   if (!L.pool) return 0;
   // assignment matrix: softmax(Linear(cat[hp1, hp2, hp3]))  (model/network.py:118-124, 200) -- the cat is never formed for the wide piece
-  TRY(cat2(c, L.x12, 2 * AH, n, L.pair[0] + H, wp, AH, L.pair[1] + H, wp, AH));
   {
     const bool wide_main = C > 2 * AH;           // the widest piece is the main operand, the other rides along as an extra K segment
     const float* xm = wide_main ? L.hp3 : L.x12;
@@ -503,11 +506,11 @@ int level_fwd(const Ctx& c, Level& L, const cgc_block_params* emb, const cgc_blo
 
 // second half of a level's backward: DenseJK, then the blocks layer by layer from the last to the first, the transposed
 // aggregations in between, and (levels 2-3) the gradients of the level's inputs.  d_embed [n, D] = gradient of the level's node
-// embedding (readout + pooled features); dx12 [n, 2 AH] / dagg_p3 [n, AH] = what the assignment tail sends to hp1|hp2 and to the
-// aggregation feeding the third assignment layer; gAt = gradient reaching the re-normalised adjacency directly (or nullptr).
+// embedding (readout + pooled features); dx12 [n, 2 AH] / dagg1 [n, H + AH] = what the assignment tail sends to hp1|hp2 and to the
+// aggregation feeding the third layers (its assignment half filled in, nullptr without an assignment block); gAt = gradient reaching the re-normalised adjacency directly (or nullptr).
 int level_bwd_blocks(const Ctx& c, Level& L, const cgc_block_params* emb, const cgc_block_params* pl, const cgc_jk_params* jk,
                      const cgc_graph* g, const int* gptr, const float* x_in, const float* A_in, float* d_embed, const float* dx12,
-                     const float* dagg_p3, const float* gAt, float* grads, float* d_x_in, float* d_A_in) {
+                     float* dagg1, const float* gAt, float* grads, float* d_x_in, float* d_A_in) {
   const cgc_level_desc& d = L.d;
   Arena& sc = *c.scratch;
   const int n = L.n, H = L.H, AH = L.AH, wp = L.wp, B = L.B, R = L.R, D3 = L.D3, fin = L.fin;
@@ -525,13 +528,8 @@ int level_bwd_blocks(const Ctx& c, Level& L, const cgc_block_params* emb, const 
   }
   // ---- layer 3 -> gradient of the aggregation that fed it: [d agg_e3 | d agg_p3]
   float* dagg[2];                                           // dagg[k]: gradient of aggk[k] = A [pair k]
-  {
-    float* de3 = L.pool ? sc.f((size_t)n * H) : nullptr;
-    dagg[1] = sc.f((size_t)n * wp);
-    TRY(layer_bwd(c, d, layer_params(d, emb, 2, 2), L.L[2], L.aggk[1], wp, n, H, L.E, d_cat + 2 * H, D3, L.pool ? de3 : dagg[1],
-                  grads + L.gl.W[2], sums(2)));
-    if (L.pool) TRY(cat2(c, dagg[1], wp, n, de3, H, H, dagg_p3, AH, AH));
-  }
+  dagg[1] = dagg1 != nullptr ? dagg1 : sc.f((size_t)n * wp);
+  TRY(layer_bwd(c, d, layer_params(d, emb, 2, 2), L.L[2], L.aggk[1], wp, n, H, L.E, d_cat + 2 * H, D3, dagg[1], wp, grads + L.gl.W[2], sums(2)));
   float* dpair = nullptr;
   for (int k = 1; k >= 0; --k) {
     // gradient of pair[k] = [he_{k+1} | hp_{k+1}]: through the aggregation, plus what the concatenations (embedding cat, x12) send
@@ -545,22 +543,17 @@ int level_bwd_blocks(const Ctx& c, Level& L, const cgc_block_params* emb, const 
     const float* ain = first ? L.agg0 : L.aggk[k - 1];
     const int lda = first ? fin : wp;
     const int fi_e = L.width_in(k), fi_p = L.width_in(3 + k);
-    float* de = need_in ? sc.f((size_t)n * fi_e) : nullptr;
-    TRY(layer_bwd(c, d, layer_params(d, emb, k, k), L.L[k], ain, lda, n, fi_e, H, dpair, wp, de, grads + L.gl.W[k], sums(k)));
+    // second layers: both blocks write their halves of d aggk[0] in place; first layers (dense levels): two [n, fin] gradients
+    float* de = !need_in ? nullptr : first ? sc.f((size_t)n * fi_e) : (dagg[0] = sc.f((size_t)n * wp));
+    const int ldde = first ? fi_e : wp;
+    TRY(layer_bwd(c, d, layer_params(d, emb, k, k), L.L[k], ain, lda, n, fi_e, H, dpair, wp, de, ldde, grads + L.gl.W[k], sums(k)));
     float* dp = nullptr;
     if (L.pool) {
-      dp = need_in ? sc.f((size_t)n * fi_p) : nullptr;
+      dp = !need_in ? nullptr : first ? sc.f((size_t)n * fi_p) : de + H;
       TRY(layer_bwd(c, d, layer_params(d, pl, k, 3 + k), L.L[3 + k], first ? ain : ain + H, lda, n, fi_p, AH, dpair + H, wp, dp,
-                    grads + L.gl.W[3 + k], sums(3 + k)));
+                    first ? fi_p : wp, grads + L.gl.W[3 + k], sums(3 + k)));
     }
-    if (!first) {
-      if (L.pool) {
-        dagg[0] = sc.f((size_t)n * wp);
-        TRY(cat2(c, dagg[0], wp, n, de, H, H, dp, AH, AH));
-      } else {
-        dagg[0] = de;
-      }
-    } else if (L.dense) {
+    if (first && L.dense) {
       // both first layers read the same aggregation A x: their gradients add up
       if (L.pool) TRY(add1(c, de, fin, n, dp, fin, fin));
       TRY(aggregate_t(c, L, g, gptr, de, fin, d_x_in));
@@ -591,7 +584,6 @@ int level_bwd(const Ctx& c, Level& L, const cgc_block_params* emb, const cgc_blo
   if (L.pool) {
     const size_t m0 = sc.mark();
     float* ds = sc.f((size_t)n * L.ldC);
-    float* de = sc.f((size_t)n * D);
     if (!L.dense) {
       float* dp = sc.f((size_t)n * L.ldC);
       TRY(gemm(c, 0, 0, 0, C, C, L.S, L.ldC, d_ao, C, 0.f, dp, L.ldC, nullptr, B, 0, (int64_t)C * C, 0, gptr, 1, d.nmax));      // dP = S dA'
@@ -599,7 +591,7 @@ int level_bwd(const Ctx& c, Level& L, const cgc_block_params* emb, const cgc_blo
                                    c.s));                                                                                          // dS = A^T dP
       TRY(gemm_x1(c, 0, 1, 0, C, C, L.P, L.ldC, d_ao, C, 1.f, ds, L.ldC, nullptr, B, 0, (int64_t)C * C, 0, gptr, 1, d.nmax, L.embed(), D, 0, d_xo,
                   D, (int64_t)C * D, D));                                                                  // + P dA'^T + X dX'^T
-      TRY(gemm(c, 0, 0, 0, D, C, L.S, L.ldC, d_xo, D, 0.f, de, D, nullptr, B, 0, (int64_t)C * D, 0, gptr, 1, d.nmax));           // dX = S dX'
+      TRY(gemm(c, 0, 0, 0, D, C, L.S, L.ldC, d_xo, D, 1.f, d_embed, D, nullptr, B, 0, (int64_t)C * D, 0, gptr, 1, d.nmax));     // dX += S dX'
     } else {
       gAt = sc.f((size_t)n * R);     // (allocated below ds / de on purpose: it outlives them -- see the release further down)
       float* dP = sc.f((size_t)n * L.ldP);
@@ -612,9 +604,8 @@ int level_bwd(const Ctx& c, Level& L, const cgc_block_params* emb, const cgc_blo
       TRY(bgemm(c, dP3, s3, T3{gAt, B, R, R, R}, 0, 1));      // d(A~) = dP S^T   (the gradient that reaches the re-normalised adjacency directly)
       TRY(bgemm(c, a3, dP3, ds3, 1, 0, 1.f));                 // dS += A~^T dP
       TRY(bgemm(c, e3, dxo, ds3, 0, 1, 1.f));                 // dS += X dX'^T
-      TRY(bgemm(c, s3, dxo, T3{de, B, R, D, D}, 0, 0));       // dX  = S dX'
+      TRY(bgemm(c, s3, dxo, T3{d_embed, B, R, D, D}, 0, 0, 1.f));   // dX += S dX'
     }
-    TRY(add1(c, d_embed, D, n, de, D, D));
     // Linear over cat + softmax backward (ops._LinearCat.backward)
     float* dz = sc.f((size_t)n * L.ldC);
     {
@@ -623,7 +614,7 @@ int level_bwd(const Ctx& c, Level& L, const cgc_block_params* emb, const cgc_blo
       CALL(cgc_softmax_bwd(L.S, ds, n, C, L.ldC, dz, grads + L.gl.lin_b, ws, c.s));
       sc.release(m);
     }
-    // (ds, de and, at level 1, dp are dead from here on; dz stays.  The arena is a stack: what must survive was allocated first.)
+    // (ds and, at level 1, dp are dead from here on; dz stays.  The arena is a stack: what must survive was allocated first.)
     dx12 = sc.f((size_t)n * 2 * AH);
     float* dy3 = sc.f((size_t)n * L.ldC);
     TRY(gemm(c, 0, 0, n, 2 * AH, C, dz, L.ldC, pl->lin_W, L.ftot, 0.f, dx12, 2 * AH));
@@ -648,11 +639,11 @@ int level_bwd(const Ctx& c, Level& L, const cgc_block_params* emb, const cgc_blo
     }
     // third layer of the assignment block, from d hp3
     (void)m0;
-    float* dagg_p3 = sc.f((size_t)n * AH);
-    TRY(layer_bwd(c, d, layer_params(d, pl, 2, 5), L.L[5], L.aggk[1] + H, wp, n, AH, C, dy3, L.ldC, dagg_p3, grads + L.gl.W[5],
+    float* dagg1 = sc.f((size_t)n * wp);       // gradient of the aggregation feeding the third layers: [embedding part | assignment part]
+    TRY(layer_bwd(c, d, layer_params(d, pl, 2, 5), L.L[5], L.aggk[1] + H, wp, n, AH, C, dy3, L.ldC, dagg1 + H, wp, grads + L.gl.W[5],
                   grads + L.gl.W[5] + (int64_t)AH * C + C));
-    // keep: dagg_p3, dx12, gAt.  (dy3, dz are not needed any more but sit below dagg_p3 on the stack; they are simply left there.)
-    return level_bwd_blocks(c, L, emb, pl, jk, g, gptr, x_in, A_in, d_embed, dx12, dagg_p3, gAt, grads, d_x_in, d_A_in);
+    // keep: dagg1, dx12, gAt.  (dy3, dz are not needed any more but sit below dagg1 on the stack; they are simply left there.)
+    return level_bwd_blocks(c, L, emb, pl, jk, g, gptr, x_in, A_in, d_embed, dx12, dagg1, gAt, grads, d_x_in, d_A_in);
   }
   return level_bwd_blocks(c, L, emb, pl, jk, g, gptr, x_in, A_in, d_embed, nullptr, nullptr, nullptr, grads, d_x_in, d_A_in);
 }

@@ -335,7 +335,7 @@ template <int VEC, int MAXJ>
 __global__ __launch_bounds__(256) void k_bn_act_apply(const float* __restrict__ hn, int n, int F, int lpr, int act,
                                                       const float* __restrict__ mean, const float* __restrict__ istd,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                      float* __restrict__ y, int ldy) {
+                                                      float* __restrict__ y, int ldy, float* __restrict__ y2, int ldy2) {
   const RowGroup rg(lpr);
   // y = (act(hn) - mu) * sc + sh with sc = istd*gamma: the lane's columns never change, so the constants live in
   // registers.  (o - mu) is formed first, as nn.BatchNorm1d does: folding mu into the shift would cancel catastrophically
@@ -367,6 +367,7 @@ __global__ __launch_bounds__(256) void k_bn_act_apply(const float* __restrict__ 
 #pragma unroll
         for (int v = 0; v < VEC; ++v) x.v[v] = fmaf(act_fwd(x.v[v], act) - mu[j][v], sc[j][v], sh[j][v]);
         x.store(y + (size_t)row * ldy + c);
+        if (y2 != nullptr) x.store(y2 + (size_t)row * ldy2 + c);
       }
     }
   }
@@ -374,13 +375,20 @@ __global__ __launch_bounds__(256) void k_bn_act_apply(const float* __restrict__ 
 
 extern "C" int cgc_bn_act_apply(const float* hn, int n, int F, int act, const float* mean, const float* istd,
                                 const float* gamma, const float* beta, float* y, int ldy, cgc_stream_t stream) {
+  return cgc_bn_act_apply2(hn, n, F, act, mean, istd, gamma, beta, y, ldy, nullptr, 0, stream);
+}
+
+// the same result written to a second destination as well (y2 [n, F], row stride ldy2; NULL: none): a layer's output goes into the
+// buffer the next aggregation reads AND into its slot of the block's concatenation (model/network.py:118)
+extern "C" int cgc_bn_act_apply2(const float* hn, int n, int F, int act, const float* mean, const float* istd, const float* gamma,
+                                 const float* beta, float* y, int ldy, float* y2, int ldy2, cgc_stream_t stream) {
   if (n <= 0 || F <= 0) return 0;
-  const bool vec = (F % 4 == 0) && (ldy % 4 == 0) && aligned16(hn) && aligned16(y);
+  const bool vec = (F % 4 == 0) && (ldy % 4 == 0) && aligned16(hn) && aligned16(y) && (y2 == nullptr || (ldy2 % 4 == 0 && aligned16(y2)));
   ColCfg cfg = col_cfg(n, F, vec);
   if (!cfg.ok) return CGC_EINVAL;
   cfg.blocks = row_blocks(n, cfg.lpr, 1024);      // every wave first loads its columns' constants: 1024 longer-lived workgroups
                                                   // beat 2048 (119 vs 147 us on [57.7k, 1140])
-  DISPATCH_COL(k_bn_act_apply, cfg, 0, as_stream(stream), hn, n, F, cfg.lpr, act, mean, istd, gamma, beta, y, ldy);
+  DISPATCH_COL(k_bn_act_apply, cfg, 0, as_stream(stream), hn, n, F, cfg.lpr, act, mean, istd, gamma, beta, y, ldy, y2, ldy2);
   CGC_RETURN_IF_LAUNCH_FAILED();
   return 0;
 }

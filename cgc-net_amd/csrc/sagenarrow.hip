@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void k_sage_narrow_bwd(const float* __restrict
                                                          const float* __restrict__ mean, const float* __restrict__ istd,
                                                          const float* __restrict__ gamma, const float* __restrict__ sums, float inv_count,
                                                          const float* __restrict__ agg, int lda, int fin, const float* __restrict__ W,
-                                                         float* __restrict__ dagg, float* __restrict__ ws, int tiles) {
+                                                         float* __restrict__ dagg, int ldd, float* __restrict__ ws, int tiles) {
   __shared__ float strip[4][17 * 64];              // per wave: the 32 x 33 transposition strip; at the end the [17][64] exchange buffer
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int f = lane & 31, half = lane >> 5;
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void k_sage_narrow_bwd(const float* __restrict
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          if (row < n) dagg[(size_t)row * fin + f] = da[r];
+          if (row < n) dagg[(size_t)row * ldd + f] = da[r];
         }
       }
     }
@@ -159,9 +159,18 @@ extern "C" int cgc_sage_narrow_bwd(const float* dy, int ldy, const float* hn, co
                                    int mode, const float* mean, const float* istd, const float* gamma, const float* sums, double count,
                                    const float* agg, int lda, int fin, const float* W, float* dagg, float* dwdb, float* ws,
                                    cgc_stream_t stream_) {
+  return cgc_sage_narrow_bwd_ld(dy, ldy, hn, rinv, n, F, act, normalize, mode, mean, istd, gamma, sums, count, agg, lda, fin, W, dagg, fin,
+                                dwdb, ws, stream_);
+}
+
+// the same with a row stride for dagg (>= fin): the two blocks of a level write their halves of one [n, fin_e + fin_p] gradient
+extern "C" int cgc_sage_narrow_bwd_ld(const float* dy, int ldy, const float* hn, const float* rinv, int n, int F, int act, int normalize,
+                                      int mode, const float* mean, const float* istd, const float* gamma, const float* sums, double count,
+                                      const float* agg, int lda, int fin, const float* W, float* dagg, int ldd, float* dwdb, float* ws,
+                                      cgc_stream_t stream_) {
   hipStream_t st = as_stream(stream_);
   if (F <= 0 || fin <= 0) return 0;
-  if (F > 32 || fin > 32 || ws == nullptr || dwdb == nullptr) return CGC_EINVAL;
+  if (F > 32 || fin > 32 || ws == nullptr || dwdb == nullptr || (dagg != nullptr && ldd < fin)) return CGC_EINVAL;
   const int width = fin * F + F;
   if (n <= 0) {
     (void)hipMemsetAsync(dwdb, 0, sizeof(float) * width, st);
@@ -172,7 +181,7 @@ extern "C" int cgc_sage_narrow_bwd(const float* dy, int ldy, const float* hn, co
   const int fs = (F + 1) / 2;
 #define SN_LAUNCH(FS_, ACT_)                                                                                                         \
   hipLaunchKernelGGL((k_sage_narrow_bwd<FS_, ACT_>), dim3(grid), dim3(256), 0, st, dy, ldy, hn, rinv, n, F, act, normalize, mode, mean, \
-                     istd, gamma, sums, inv_count, agg, lda, fin, W, dagg, ws, tiles)
+                     istd, gamma, sums, inv_count, agg, lda, fin, W, dagg, ldd, ws, tiles)
 #define SN_ACT(FS_)                                                                                        \
   switch (act) {                                                                                           \
     case CGC_ACT_RELU: SN_LAUNCH(FS_, CGC_ACT_RELU); break;                                                \

@@ -265,3 +265,89 @@ def level(enc, desc, emb, pool, jk, g, gptr, x_in, A_in, assign=None):
 
 def dense_gptr(B, Cn, device):
     return uniform_ptr(B, Cn, device)
+
+
+# ---- classification head + loss as one kernel each way (csrc/head.hip) ---------------------------------------------------------
+class _Head(Function):
+    """(logits, loss) = head(readouts); ``cfg`` = dict(act, drop_p, seed, labels)."""
+
+    @staticmethod
+    def forward(ctx, cfg, W1, b1, W2, b2, *xs):
+        lib = _lib()
+        K = kernels.get()
+        K._dev(W1, b1, W2, b2, cfg['labels'], *xs)
+        xs = [x.contiguous() for x in xs]
+        B, D = xs[0].shape
+        H1, L_ = W1.shape[0], W2.shape[0]
+        dev = xs[0].device
+        ws = torch.empty(3 * B * H1 + B, dtype=torch.float32, device=dev)
+        logits = torch.empty(B, L_, dtype=torch.float32, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        y = cfg['labels']
+        px = (P * len(xs))(*[x.data_ptr() for x in xs])
+        rc = lib.cgc_head_fwd(px, len(xs), B, D, H1, L_, cfg['act'], _p(W1), _p(b1), _p(W2), _p(b2), _p(y), C.c_float(cfg['drop_p']),
+                              C.c_uint64(cfg['seed']), _p(ws), _p(logits), _p(loss), K._stream())
+        if rc != 0:
+            raise RuntimeError('cgc_head_fwd failed with code %d' % rc)
+        ctx.cfg, ctx.dims = cfg, (B, D, H1, L_, len(xs))
+        ctx.save_for_backward(W1, W2, ws, logits, *xs)
+        ctx.has_bias = (b1 is not None, b2 is not None)
+        ctx.mark_non_differentiable()
+        return logits, loss
+
+    @staticmethod
+    def backward(ctx, d_logits, d_loss):
+        lib = _lib()
+        K = kernels.get()
+        cfg = ctx.cfg
+        B, D, H1, L_, nseg = ctx.dims
+        W1, W2, ws, logits = ctx.saved_tensors[:4]
+        xs = ctx.saved_tensors[4:]
+        dev = ws.device
+        Kin = nseg * D
+        grads = torch.empty(H1 * Kin + H1 + L_ * H1 + L_, dtype=torch.float32, device=dev)
+        scratch = torch.empty(B * L_ + B * H1, dtype=torch.float32, device=dev)
+        dxs = [torch.empty(B, D, dtype=torch.float32, device=dev) for _ in range(nseg)]
+        d_loss = d_loss.contiguous().float() if d_loss is not None else None
+        d_logits = d_logits.contiguous().float() if d_logits is not None else None
+        px = (P * nseg)(*[x.data_ptr() for x in xs])
+        pdx = (P * nseg)(*[x.data_ptr() for x in dxs])
+        rc = lib.cgc_head_bwd(px, nseg, B, D, H1, L_, cfg['act'], _p(W1), _p(W2), _p(cfg['labels']), _p(ws), _p(logits), _p(d_loss),
+                              _p(d_logits), _p(scratch), _p(grads), pdx, K._stream())
+        if rc != 0:
+            raise RuntimeError('cgc_head_bwd failed with code %d' % rc)
+        o = 0
+        dW1 = grads[o:o + H1 * Kin].view(H1, Kin)
+        o += H1 * Kin
+        db1 = grads[o:o + H1] if ctx.has_bias[0] else None
+        o += H1
+        dW2 = grads[o:o + L_ * H1].view(L_, H1)
+        o += L_ * H1
+        db2 = grads[o:o + L_] if ctx.has_bias[1] else None
+        return (None, dW1, db1, dW2, db2) + tuple(dxs)
+
+
+def head(pred_model, readouts, labels, training):
+    """``pred_model(cat(readouts))`` + mean cross-entropy through the fused head kernels; None when the head is not the
+    Linear -> activation -> [Dropout] -> Linear stack they cover (the caller then runs the modules one by one)."""
+    import torch.nn as nn
+    layers = list(pred_model) if isinstance(pred_model, nn.Sequential) else [pred_model]
+    if len(layers) not in (3, 4) or not isinstance(layers[0], nn.Linear) or not isinstance(layers[-1], nn.Linear):
+        return None
+    act = {nn.ReLU: 'relu', nn.ELU: 'elu', nn.LeakyReLU: 'leakyrelu'}.get(type(layers[1]))
+    if act is None or (act == 'elu' and layers[1].alpha != 1.0) or (act == 'leakyrelu' and layers[1].negative_slope != 0.01):
+        return None
+    drop_p = 0.0
+    if len(layers) == 4:
+        if not isinstance(layers[2], nn.Dropout):
+            return None
+        drop_p = float(layers[2].p) if training else 0.0
+    if len(readouts) > 3 or any(r.shape != readouts[0].shape for r in readouts) or not (0.0 <= drop_p < 1.0):
+        return None
+    l1, l2 = layers[0], layers[-1]
+    if l1.in_features != len(readouts) * readouts[0].shape[1] or not _f32ok(l1.weight, l1.bias, l2.weight, l2.bias):
+        return None
+    # the mask is a function of (seed, element): the seed comes from torch's CPU generator (no device work; torch.manual_seed governs it)
+    seed = int(torch.empty((), dtype=torch.int64).random_().item()) if drop_p > 0.0 else 0
+    cfg = dict(act=ACT_CODES[act], drop_p=drop_p, seed=seed, labels=labels.view(-1).contiguous())
+    return _Head.apply(cfg, l1.weight, l1.bias, l2.weight, l2.bias, *readouts)

@@ -325,6 +325,7 @@ class SoftPoolingGcnEncoder(nn.Module):
         # levels run through the step sequencer (native.py / csrc/exec.hip: one library call per level and direction) whenever it
         # covers the configuration; False (or CGC_NATIVE=0): always the per-operator path (ops.py), one autograd node per operator
         self.native = os.environ.get('CGC_NATIVE', '1') != '0'
+        self.native_head = os.environ.get('CGC_NATIVE_HEAD', '1') != '0'     # classification head + loss as one kernel each way
 
     def build_readout_module(self, pred_input_dim, pred_hidden_dims, label_dim, activation):
         if len(pred_hidden_dims) == 0:
@@ -530,6 +531,11 @@ class SoftPoolingGcnEncoder(nn.Module):
             data = self._flat_from_dense(data[0], data[1], data[2])
         out1, x, adj = self._level1(data)
         out2, out3 = self._dense_levels(x, adj)
+        if self.native_head and self.training and self._use_native(data.x) and label.dtype == torch.int64:
+            # head + mean cross-entropy as one kernel each way (native.head; csrc/head.hip)
+            res = native.head(self.pred_model, [out1, out2, out3], label, True)
+            if res is not None:
+                return res
         output = self._head([out1, out2, out3])
         if self.training:
             cls_loss = F.cross_entropy(output, label.view(-1))

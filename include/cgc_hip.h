@@ -186,6 +186,9 @@ int cgc_l2norm_act_bn(const float* h, int n, int F, int normalize, int act, floa
                       float* mean, float* istd, cgc_stream_t stream);
 int cgc_bn_act_apply(const float* hn, int n, int F, int act, const float* mean /*NULL: no BN*/, const float* istd,
                      const float* gamma, const float* beta, float* y, int ldy, cgc_stream_t stream);
+/* cgc_bn_act_apply writing the same values to a second destination y2 [n, F] (row stride ldy2) as well (NULL: none) */
+int cgc_bn_act_apply2(const float* hn, int n, int F, int act, const float* mean, const float* istd, const float* gamma,
+                      const float* beta, float* y, int ldy, float* y2, int ldy2, cgc_stream_t stream);
 int cgc_bn_bwd_reduce(const float* dy, int ldy, const float* hn, int n, int F, int act, const float* mean,
                       const float* istd, float* sums /*[2,F]*/, float* ws, cgc_stream_t stream);
 /* mode: 2 batch statistics, 1 running statistics, 0 no BN */
@@ -264,6 +267,12 @@ int cgc_sage_narrow_bwd(const float* dy, int ldy, const float* hn, const float* 
                         int mode, const float* mean, const float* istd, const float* gamma, const float* sums, double count,
                         const float* agg, int lda, int fin, const float* W, float* dagg, float* dwdb, float* ws,
                         cgc_stream_t stream);
+
+/* cgc_sage_narrow_bwd with a row stride ldd (>= fin) for dagg */
+int cgc_sage_narrow_bwd_ld(const float* dy, int ldy, const float* hn, const float* rinv, int n, int F, int act, int normalize,
+                           int mode, const float* mean, const float* istd, const float* gamma, const float* sums, double count,
+                           const float* agg, int lda, int fin, const float* W, float* dagg, int ldd, float* dwdb, float* ws,
+                           cgc_stream_t stream);
 
 /* ---- A4/A6 at levels 2-3 (dense, real-valued adjacency that carries gradient) */
 int cgc_dense_rownorm_fwd(const float* A, int R, int C, float* out, float* invd, float* ge1, cgc_stream_t stream);
@@ -361,6 +370,19 @@ int cgc_level_bwd(const cgc_level_desc* d, const cgc_block_params* emb, const cg
                   const cgc_graph* g, const int* gptr, const float* x_in, const float* A_in, const float* saved, float* scratch,
                   const float* d_readout, const float* d_x_out, const float* d_A_out, float* grads, float* d_x_in, float* d_A_in,
                   cgc_stream_t stream);
+
+/* ==== A10: classification head + loss (model/network.py:220-234, 286-289): logits = Linear2(dropout(act(Linear1(cat(readouts))))),
+ * loss = mean cross-entropy(logits, y), one kernel; the backward another.  x: HOST array of nseg (<= 3) device pointers [B, D] (the
+ * readouts; never concatenated); W1 [H1, nseg*D], W2 [L, H1] in nn.Linear layout; y int64 [B] (NULL: logits only); drop_p in [0,1):
+ * the mask is a counter-based function of (seed, element index).  ws: 3*B*H1 + B floats, passed again to the backward.
+ * Backward: dloss = device scalar gradient of the mean loss (NULL = 0), dlogits_ext [B, L] or NULL; scratch: B*L + B*H1 floats;
+ * grads = dW1 | db1 | dW2 | db2 back to back; dx: HOST array of nseg device pointers [B, D]. */
+int cgc_head_fwd(const float* const* x, int nseg, int B, int D, int H1, int L, int act, const float* W1, const float* b1,
+                 const float* W2, const float* b2, const int64_t* y, float drop_p, uint64_t seed, float* ws, float* logits,
+                 float* loss, cgc_stream_t stream);
+int cgc_head_bwd(const float* const* x, int nseg, int B, int D, int H1, int L, int act, const float* W1, const float* W2,
+                 const int64_t* y, const float* ws, const float* logits, const float* dloss, const float* dlogits_ext,
+                 float* scratch, float* grads, float* const* dx, cgc_stream_t stream);
 
 /* ==== Measurement hook (csrc/timing.hip): HIP events around every launch of the dominant 128 x 128 GEMM (tag 1) and of the wide
  * SpMM (tag 2), recorded on the stream of the launch, whoever asked for it (per-operator call or step sequencer).  One observer

@@ -14,12 +14,13 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 
 
-def _pair(args, kw, seed=5):
+def _pair(args, kw, seed=5, head=False):
     torch.manual_seed(seed)
     a = network.SoftPoolingGcnEncoder(*args, **kw).to(DEV)
     b = network.SoftPoolingGcnEncoder(*args, **kw).to(DEV)
     b.load_state_dict(a.state_dict())
     a.native, b.native = True, False
+    a.native_head = head                # the fused head kernel sums in its own (fixed) order: not bitwise the per-operator head
     return a.train(), b.train()
 
 
@@ -120,3 +121,41 @@ def test_sequencer_falls_back_outside_its_scope():
     (_, loss), calls = _used_native(g, b)
     assert calls == 0
     loss.backward()
+
+
+@pytest.mark.parametrize('flags', [dict(), dict(norm_adj=True, jk=True), dict(activation='elu', jk=True)], ids=['plain', 'shipped', 'elu'])
+def test_fused_head_matches_the_module_stack(flags):
+    """native.head (Linear -> act -> Dropout -> Linear -> mean cross-entropy in one kernel, its backward in another) against the
+    registered modules + F.cross_entropy: logits, loss and every gradient to fp32 rounding; with dropout: the mask keeps the
+    expectation and the same seed gives the same mask."""
+    ds = SyntheticCellGraphs(5, 300, num_features=16, base_seed=2)
+    b = Batch.from_data_list([ds[i] for i in range(5)]).to(DEV)
+    kw = dict(concat=True, load_data_sparse=True, drop_out=0.)
+    kw.update(flags)
+    nat, ref = _pair((600, 16, 20, 20, True, True, 20, 3, 0.1, [50]), kw, head=True)
+    ref.native = True                                  # same levels; only the head differs
+    ref.native_head = False
+    ln, lossn = nat(b)
+    lr, lossr = ref(b)
+    lossn.backward()
+    lossr.backward()
+    rel = lambda x, y: float((x.double() - y.double()).abs().max() / (y.double().abs().max() + 1e-30))
+    assert rel(ln, lr) < 2e-6 and rel(lossn, lossr) < 2e-6
+    gr = dict(ref.named_parameters())
+    for k, p in nat.named_parameters():
+        # the head's own parameters to rounding; upstream gradients are long cancelling sums of what the head sends down (1e-4 bar)
+        assert rel(p.grad, gr[k].grad) < (5e-6 if k.startswith('pred_model') else 1e-4), (k, rel(p.grad, gr[k].grad))
+    # dropout: deterministic under torch.manual_seed, ~p of the hidden units dropped, survivors scaled by 1/(1-p)
+    kw['drop_out'] = 0.5
+    m, _ = _pair((600, 16, 20, 20, True, True, 20, 3, 0.1, [50]), kw, head=True)
+    outs = []
+    for seed in (1, 1, 2):
+        torch.manual_seed(seed)
+        m.zero_grad()
+        lg, ls = m(b)
+        ls.backward()
+        outs.append((lg.detach().clone(), m.pred_model[0].weight.grad.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert not torch.equal(outs[0][0], outs[2][0])
+    dead_rows = float((outs[0][1].abs().sum(1) == 0).float().mean())      # hidden units dropped for EVERY graph are rare; most rows live
+    assert dead_rows < 0.5
