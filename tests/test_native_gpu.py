@@ -143,6 +143,9 @@ def test_fused_head_matches_the_module_stack(flags):
     assert rel(ln, lr) < 2e-6 and rel(lossn, lossr) < 2e-6
     gr = dict(ref.named_parameters())
     for k, p in nat.named_parameters():
+        if k.endswith('att.bias'):        # mathematically zero (the attention softmax is shift-invariant): absolute
+            assert float(p.grad.abs().max()) < 1e-6, k
+            continue
         # the head's own parameters to rounding; upstream gradients are long cancelling sums of what the head sends down (1e-4 bar)
         assert rel(p.grad, gr[k].grad) < (5e-6 if k.startswith('pred_model') else 1e-4), (k, rel(p.grad, gr[k].grad))
     # dropout: deterministic under torch.manual_seed, ~p of the hidden units dropped, survivors scaled by 1/(1-p)
