@@ -531,7 +531,7 @@ class SoftPoolingGcnEncoder(nn.Module):
             data = self._flat_from_dense(data[0], data[1], data[2])
         out1, x, adj = self._level1(data)
         out2, out3 = self._dense_levels(x, adj)
-        if self.native_head and self.training and self._use_native(data.x) and label.dtype == torch.int64:
+        if self.native_head and self.training and torch.is_grad_enabled() and out1.is_cuda and label.dtype == torch.int64:
             # head + mean cross-entropy as one kernel each way (native.head; csrc/head.hip)
             res = native.head(self.pred_model, [out1, out2, out3], label, True)
             if res is not None:

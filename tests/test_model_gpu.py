@@ -8,11 +8,17 @@ import cgc_net_amd  # noqa: F401
 from cgc_net_amd import kernels, network
 from cgc_net_amd.data import Batch, SyntheticCellGraphs
 from oracle import dense_ref
-from util import CASES, build_model, load_case, rel_err
+from util import CASES, build_model, elementwise_excess, load_case, rel_err
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 TOL, TOL_GRAD = 1e-4, 5e-4      # see tests/test_flat_formulation_cpu.py for the gradient tolerance
+
+
+def strict(a, b):
+    """max|a-b| / max|b|: no absolute slack (util.rel_err adds 1e-3 to the denominator)."""
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
 
 @pytest.mark.parametrize('name', CASES)
@@ -23,13 +29,21 @@ def test_golden_forward_backward(name):
     model.to(DEV).train()
     logits, loss = model(batch)
     assert kernels.is_native()
-    assert rel_err(logits, out['logits']) < TOL
+    assert rel_err(logits, out['logits']) < TOL and elementwise_excess(logits, out['logits'], TOL) <= 1.0
     assert rel_err(loss, out['loss']) < TOL
     for i, s in enumerate(model.assign_matrix):
-        assert rel_err(s, out['assign%d' % (i + 1)]) < TOL
+        ref_s = out['assign%d' % (i + 1)]
+        assert rel_err(s, ref_s) < TOL and elementwise_excess(s, ref_s, TOL) <= 1.0, i         # measured excess <= 0.25
     loss.backward()
     for k, p in model.named_parameters():
-        assert rel_err(p.grad, grad[k]) < TOL_GRAD, k
+        if k.endswith('att.bias') or float(grad[k].abs().max()) < 1e-9:   # mathematically zero (attention bias under the softmax): absolute
+            assert float(p.grad.abs().max()) < 1e-6, k
+            continue
+        # against the REFERENCE's own fp32 gradients, no absolute slack.  Measured worst per case: 9e-6 / 5.7e-4 / 1.7e-5 / 2.9e-4 /
+        # 3.7e-4 (tiny_plain / tiny_shipped / tiny_elu / medium_plain / medium_shipped): where it is above 1e-4 one column of one
+        # weight gradient carries it -- a ReLU whose sign the reference's fp32 evaluation and this one take differently (the
+        # fixture is fp32).  The fp64 yardstick with the decisions aligned is tests/discrete.py (1e-4 on every parameter).
+        assert strict(p.grad, grad[k]) < 7e-4, (k, strict(p.grad, grad[k]))
 
 
 @pytest.mark.parametrize('name', ['tiny_shipped', 'medium_plain', 'medium_shipped'])
@@ -48,12 +62,12 @@ def test_golden_three_adam_steps(name):
         opt.step()
     for k, v in model.state_dict().items():
         if v.dtype.is_floating_point:
-            assert rel_err(v, sd3[k]) < 2e-3, k
+            assert strict(v, sd3[k]) < 5e-4, (k, strict(v, sd3[k]))        # measured <= 2.6e-4 (was held to 2e-3 with absolute slack)
         else:
             assert int(v) == int(sd3[k]), k
     model.eval()
     with torch.no_grad():
-        assert rel_err(model(batch), out['eval_logits3']) < 5e-3
+        assert rel_err(model(batch), out['eval_logits3']) < 1e-4           # measured <= 2.4e-6 (was 5e-3)
 
 
 @pytest.mark.parametrize('flags', [dict(), dict(norm_adj=True, jk=True), dict(activation='leakyrelu', norm_adj=True),
@@ -77,12 +91,24 @@ def test_synthetic_cell_graphs_vs_oracle(flags):
     rloss.backward()
     assert rel_err(logits, rl) < TOL and rel_err(loss, rloss) < TOL
     gref = dict(ref.named_parameters())
-    # GIN has no L2 normalisation and sums (not averages) neighbours: the network is ill-conditioned in fp32 -- the
-    # reference's own fp32 gradients sit 1.3e-3 (relative) away from an fp64 evaluation on exactly this input
-    # (measured on CPU), so that is the meaningful yardstick for that variant.
-    tol_grad = 3e-3 if flags.get('gcn_name') == 'GIN' else TOL_GRAD
-    for k, p in model.named_parameters():
-        assert rel_err(p.grad, gref[k].grad) < tol_grad, k
+    if flags.get('gcn_name') == 'GIN':
+        # GIN has no L2 normalisation and sums (not averages) neighbours: the network is ill-conditioned in fp32 -- the reference's
+        # own fp32 gradients sit 6.3e-4 away from an fp64 evaluation on exactly this input.  The yardstick is therefore the fp64
+        # evaluation of the oracle itself, no absolute slack: measured 5.3e-4 for this path, held to 1e-3 (round 2: 3e-3 vs fp32).
+        import copy
+        ref64 = copy.deepcopy(ref).double()
+        ref64.load_data_sparse = False
+        ref64.zero_grad()
+        adj = dense_ref.to_dense_adj(cpu_batch.edge_index, cpu_batch.batch)
+        xd, counts = dense_ref.to_dense_batch(cpu_batch.x, cpu_batch.batch)
+        _, loss64 = ref64((xd.double(), adj.double(), counts, cpu_batch.y))
+        loss64.backward()
+        g64 = dict(ref64.named_parameters())
+        for k, p in model.named_parameters():
+            assert strict(p.grad, g64[k].grad) < 1e-3, (k, strict(p.grad, g64[k].grad), strict(gref[k].grad, g64[k].grad))
+    else:
+        for k, p in model.named_parameters():
+            assert rel_err(p.grad, gref[k].grad) < TOL_GRAD, k
     rbuf = dict(ref.named_buffers())
     for k, a in model.named_buffers():
         if a.dtype.is_floating_point:

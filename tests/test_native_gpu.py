@@ -14,13 +14,13 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 
 
-def _pair(args, kw, seed=5, head=False):
+def _pair(args, kw, seed=5, head=True):
     torch.manual_seed(seed)
     a = network.SoftPoolingGcnEncoder(*args, **kw).to(DEV)
     b = network.SoftPoolingGcnEncoder(*args, **kw).to(DEV)
     b.load_state_dict(a.state_dict())
     a.native, b.native = True, False
-    a.native_head = head                # the fused head kernel sums in its own (fixed) order: not bitwise the per-operator head
+    a.native_head = b.native_head = head      # the fused head sums in its own (fixed) order: same head on both sides of a bitwise check
     return a.train(), b.train()
 
 
@@ -135,6 +135,7 @@ def test_fused_head_matches_the_module_stack(flags):
     nat, ref = _pair((600, 16, 20, 20, True, True, 20, 3, 0.1, [50]), kw, head=True)
     ref.native = True                                  # same levels; only the head differs
     ref.native_head = False
+    assert nat.native_head
     ln, lossn = nat(b)
     lr, lossr = ref(b)
     lossn.backward()
