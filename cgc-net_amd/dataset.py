@@ -76,12 +76,13 @@ class NucleiDatasetBatchOutput(torch.utils.data.Dataset):
 
     def __init__(self, root, feature_type='ca', split='train', sampling_ratio=0.5, dynamic_graph=False,
                  sampling_method='fuse', neighbour=8, max_edge_distance=100, crossval=1, mean=None, std=None,
-                 fix_dir='fix_fuse_cia_knn', device_front_end=False):
+                 fix_dir='fix_fuse_cia_knn', device_front_end=False, task='colon'):
         assert feature_type in ('ca', 'c', 'a') and split in ('train', 'valid')
         self.root, self.feature_type, self.split = root, feature_type, split
         self.sampling_ratio, self.dynamic_graph, self.sample_method = sampling_ratio, dynamic_graph, sampling_method
         self.max_neighbours, self.max_edge_distance, self.cross_val = neighbour, max_edge_distance, crossval
         self.device_front_end = device_front_end
+        self.task = task                 # setting.name (dataflow/data.py:121): graphs under 100 nodes keep all nodes unless 'colon'
         self.epoch = self.val_epoch = 0
         self.processed_root = osp.join(root, 'proto', 'cross_val')
         self.processed_fix_data_root = osp.join(root, 'proto', fix_dir)
@@ -92,6 +93,7 @@ class NucleiDatasetBatchOutput(torch.utils.data.Dataset):
         for fold in folds:                                       # dataflow/data.py:159-161
             d = osp.join(listing_root, fold)
             if osp.isdir(d):
+                # (sorted: the reference takes os.listdir order, which is file-system dependent; patch_idx values follow this list)
                 self.idxlist.extend(osp.join(fold, f) for f in sorted(os.listdir(d)) if f.endswith('.pt'))
         self.mean = None if mean is None else self._slice_cols(torch.as_tensor(mean, dtype=torch.float32))
         self.std = None if std is None else self._slice_cols(torch.as_tensor(std, dtype=torch.float32))
@@ -133,8 +135,8 @@ class NucleiDatasetBatchOutput(torch.utils.data.Dataset):
     def __getitem__(self, idx):
         data = load_pt(self.path_of(idx))
         data.x = self._slice_cols(data.x.to(torch.float32))
-        if self.dynamic_graph and self.sampling_ratio < 1:       # dataflow/data.py:338-344 (host-side, one image)
-            n = data.num_nodes
+        if self.dynamic_graph:                                   # dataflow/data.py:338-344 (host-side, one image): the reference draws
+            n = data.num_nodes                                   # and permutes also at ratio 1
             choice = self._sample(data.pos, n)
             for key, item in list(data):
                 if torch.is_tensor(item) and item.dim() > 0 and item.size(0) == n:
@@ -150,14 +152,16 @@ class NucleiDatasetBatchOutput(torch.utils.data.Dataset):
 
     def _sample(self, pos, n):
         """Reference-compatible draw on the host for ONE image (the table's int16 distances re-derived from ``pos``)."""
-        return _sample_one_host(pos, n, self.sampling_ratio, self.sample_method)
+        return _sample_one_host(pos, n, self.sampling_ratio, self.sample_method, self.task)
 
 
-def _sample_one_host(pos, n, ratio, method):
+def _sample_one_host(pos, n, ratio, method, task='colon'):
     """FarthestSampler / 'fuse' / 'random' on the host with the table's arithmetic (dataflow/data.py:195-223;
     common/utils.py:187-203; dataflow/construct_feature_graph.py:17-24), row by row instead of from a stored n x n file."""
     import random as pyrandom
     k = int(n * ratio)
+    if task != 'colon' and n < 100:                              # dataflow/data.py:199-201
+        k = n
     p = pos.detach().cpu().numpy().astype(np.float32)[:, :2]
 
     def farthest(kf):

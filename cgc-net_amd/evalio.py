@@ -105,7 +105,9 @@ def evaluate(loader, model, vote, test_time=1, max_num_examples=None, batch_size
                 if hasattr(model, 'local_chunk'):            # parallel.DataParallel: this rank scores its chunk of the list,
                     data = model.local_chunk(data)           # then every rank receives every rank's results (rank order =
                     ypred = _forward_local(model, data) if len(data) else model._idle_step()       # list order)
-                    if model.world > 1:
+                    # (shard_input = False: the loader already hands every rank its OWN list -- or every rank the same one; a gather
+                    # would then count every patch world-size times, so each rank scores what it was given)
+                    if model.world > 1 and getattr(model, 'shard_input', True):
                         mine = ([loader.dataset.idxlist[int(d.patch_idx)] for d in data],
                                 [int(v) for d in data for v in d.y.reshape(-1)], ypred.detach().cpu().numpy())
                         parts = [None] * model.world
@@ -115,7 +117,8 @@ def evaluate(loader, model, vote, test_time=1, max_num_examples=None, batch_size
                         allp = np.concatenate([p[2] for p in parts if len(p[0])], 0)
                         vote.batch_patch_result(names, allp.argmax(1))
                         preds.append(allp)
-                        if max_num_examples is not None and (batch_idx + 1) * (batch_size or len(names)) > max_num_examples:
+                        seen = sum(len(l) for l in labels)       # examples scored so far, all ranks (the gathered count)
+                        if max_num_examples is not None and seen > max_num_examples:
                             break
                         continue
                 else:                                        # bare module: collate here

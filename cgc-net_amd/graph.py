@@ -47,7 +47,13 @@ class BatchGraph(object):
             for q, b in enumerate(by_size):
                 r, x = divmod(q, 8)
                 lanes[x if r % 2 == 0 else 7 - x].append(b)
-            self.gorder = torch.tensor([b for lane in lanes for b in lane], dtype=torch.int32, device=device)
+            # (a pinned staging buffer + non_blocking copy: torch.tensor(list, device=...) is a blocking copy that also waits for
+            # everything queued before it -- the whole previous step)
+            host = torch.tensor([b for lane in lanes for b in lane], dtype=torch.int32)
+            if torch.device(device).type == 'cuda':
+                self.gorder = host.pin_memory().to(device, non_blocking=True)
+            else:
+                self.gorder = host.to(device)
         self.val = None
         self.t_val = None
         self.renorm_p = None

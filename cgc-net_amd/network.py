@@ -496,7 +496,13 @@ class SoftPoolingGcnEncoder(nn.Module):
         if (self._graphed is None or not self.training or not torch.is_grad_enabled() or self.collect_assign
                 or not x.is_cuda or not (x.requires_grad and adj.requires_grad)):
             return self._dense_levels_eager(x, adj)
-        key = (tuple(x.shape), tuple(adj.shape), x.device.index)
+        mods = [self.GCN_embed_2, self.GCN_pool_2, self.GCN_embed_3]
+        # the capture bakes in what the host decided while it ran: BatchNorm's momentum (momentum = None means 1 / num_batches_tracked,
+        # a new value every step -> never captured), which parameters take gradients, the mode flags
+        if any(getattr(m, 'bn%d' % k).momentum is None for m in mods if m.use_bn for k in (1, 2, 3)):
+            return self._dense_levels_eager(x, adj)
+        key = (tuple(x.shape), tuple(adj.shape), x.device.index, self.jk, self.norm_adj,
+               tuple(p.requires_grad for m in mods for p in m.parameters()))
         g = self._graphed.get(key)
         if g is None:
             g = self._capture_dense_levels(x, adj)

@@ -106,6 +106,25 @@ def test_dynamic_graph_resamples_with_the_reference_sampler(tmp_path):
     assert torch.equal(d.pos, full.pos[choice]) and len(set(choice.tolist())) == choice.numel()
 
 
+def test_dynamic_graph_sampling_rules_of_the_reference(tmp_path):
+    """dataflow/data.py:195-223: graphs under 100 nodes keep every node unless the task is 'colon'; with dynamic_graph the draw
+    (and the permutation it implies) happens at ratio 1 as well."""
+    import random
+    _write_pyg_pickles(str(tmp_path))                        # graphs of 60..89 nodes
+    full = dsmod.load_pt(dsmod.NucleiDatasetBatchOutput(str(tmp_path), 'ca', split='valid', dynamic_graph=True).path_of(0))
+    n = full.x.shape[0]
+    other = dsmod.NucleiDatasetBatchOutput(str(tmp_path), 'ca', split='valid', dynamic_graph=True, sampling_method='random', task='prostate')
+    assert other[0].x.shape[0] == n                          # < 100 nodes, not 'colon': all of them
+    colon = dsmod.NucleiDatasetBatchOutput(str(tmp_path), 'ca', split='valid', dynamic_graph=True, sampling_method='random')
+    assert colon[0].x.shape[0] == int(n * 0.5)
+    one = dsmod.NucleiDatasetBatchOutput(str(tmp_path), 'ca', split='valid', dynamic_graph=True, sampling_method='random', sampling_ratio=1.0)
+    np.random.seed(3), random.seed(3)
+    d = one[0]
+    np.random.seed(3), random.seed(3)
+    choice = dsmod._sample_one_host(full.pos, n, 1.0, 'random')
+    assert sorted(choice.tolist()) == list(range(n)) and torch.equal(d.pos, full.pos[choice]) and not torch.equal(d.pos, full.pos)
+
+
 def test_device_front_end_items_stay_raw(tmp_path, torch_kernels):
     _write_pyg_pickles(str(tmp_path))
     mean, std = np.zeros(18, dtype=np.float32) + 2.0, np.ones(18, dtype=np.float32) * 4.0
