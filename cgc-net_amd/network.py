@@ -22,6 +22,7 @@ from .graph import BatchGraph, uniform_ptr
 EPS = 1e-15
 _VALIDATE_INPUTS = os.environ.get('CGC_VALIDATE_INPUTS', '0') == '1'     # one device sync per batch: off by default
 RENORM_P = 0.4      # model/network.py:260,271,280
+REORDER_MIN_NODES = 4000    # graphs at least this large get their nodes listed grid cell by grid cell (_spatially_ordered)
 
 
 def _activation_module(name):
@@ -326,6 +327,8 @@ class SoftPoolingGcnEncoder(nn.Module):
         # covers the configuration; False (or CGC_NATIVE=0): always the per-operator path (ops.py), one autograd node per operator
         self.native = os.environ.get('CGC_NATIVE', '1') != '0'
         self.native_head = os.environ.get('CGC_NATIVE_HEAD', '1') != '0'     # classification head + loss as one kernel each way
+        self.reorder_large = os.environ.get('CGC_REORDER', '1') != '0'       # see _spatially_ordered
+        self._unorder = None
 
     def build_readout_module(self, pred_input_dim, pred_hidden_dims, label_dim, activation):
         if len(pred_hidden_dims) == 0:
@@ -402,7 +405,38 @@ class SoftPoolingGcnEncoder(nn.Module):
             self.assign_matrix.append(self._pad_assign(s, g) if level == 1 else s.view(desc.B, desc.rows_per_graph, -1))
         return out
 
+    def _spatially_ordered(self, data):
+        """Large graphs (thousands of nodes): list the nodes of every graph grid cell by grid cell before the CSR is built.  The
+        network is invariant to the node order (tested at full size); the order decides how far apart in HBM the rows are that
+        the wide aggregation A*S gathers together -- with > ~4000 nodes per graph an arbitrary order (the reference's is the
+        sampler's pick order, dataflow/data.py:210-219) makes the working set of a (graph, column tile) exceed an XCD's 4 MiB
+        L2: 0.30 of the HBM peak instead of 0.40 (DESIGN.md, K4 at C5).  Returns (data', inverse permutation) or (data, None)."""
+        pos, bvec = getattr(data, 'pos', None), getattr(data, 'batch', None)
+        counts = getattr(data, '_node_counts', None)
+        if (not self.reorder_large or pos is None or bvec is None or counts is None or not data.x.is_cuda
+                or max(counts, default=0) < REORDER_MIN_NODES or pos.shape[0] != data.x.shape[0]):
+            return data, None
+        cell = 100.0                                                      # the k-NN radius (dataflow/data.py:348)
+        p = pos.detach().to(torch.float32)
+        cx, cy = torch.floor(p[:, 0] / cell).long(), torch.floor(p[:, 1] / cell).long()
+        cx, cy = cx - cx.min(), cy - cy.min()
+        nx, ny = int(cx.max()) + 1, int(cy.max()) + 1                     # (two host reads per batch; only taken for large graphs)
+        by_x = torch.sort(p[:, 0], stable=True)[1]
+        key = ((bvec.long() * ny + cy) * nx + cx)[by_x]                   # graph, grid row, grid column; x breaks ties inside a cell
+        perm = by_x[torch.sort(key, stable=True)[1]]
+        inv = torch.empty_like(perm)
+        inv[perm] = torch.arange(perm.numel(), device=perm.device)
+        flat = self._Flat()
+        flat.x = data.x[perm]
+        flat.edge_index = inv[data.edge_index]
+        flat._node_counts = counts
+        for k in ('_gptr', '_dense_rows'):
+            if getattr(data, k, None) is not None:
+                setattr(flat, k, getattr(data, k))
+        return flat, inv
+
     def _level1(self, data):
+        data, self._unorder = self._spatially_ordered(data)
         g = BatchGraph.from_batch(data, RENORM_P if self.norm_adj else None)
         if _VALIDATE_INPUTS:
             g.validate()
@@ -430,9 +464,10 @@ class SoftPoolingGcnEncoder(nn.Module):
         xn, an = ops.diff_pool_sparse(embed, s, g)
         return readout, xn, an
 
-    @staticmethod
-    def _pad_assign(s, g):
-        """[Ntot, C] -> the reference's [B, Nmax, C]; its padded rows hold softmax(0) = 1/C."""
+    def _pad_assign(self, s, g):
+        """[Ntot, C] -> the reference's [B, Nmax, C]; its padded rows hold softmax(0) = 1/C.  Rows return to the caller's node order."""
+        if getattr(self, '_unorder', None) is not None:
+            s = s[self._unorder]
         out = s.new_full((g.B, g.npad, s.shape[1]), 1.0 / s.shape[1])
         for b in range(g.B):
             out[b, :g.counts[b]] = s[g.gptr_host[b]:g.gptr_host[b + 1]]
