@@ -47,6 +47,7 @@ PROTOTYPES = {
     'cgc_segment_max_bwd': [P, P, I, I, P, P],
     'cgc_segment_max_bwd_full': [P, P, P, I, I, I, P, P],
     'cgc_jk_supported': [I],
+    'cgc_jk_matrix_core': [I],
     'cgc_jk_lstm_fwd': [P, I, I, I, P, P, P, P, P, P, P],
     'cgc_jk_lstm_bwd': [P, P, I, I, I, P, P, P, P, P, P, P, P, P, P],
     'cgc_jk_bwd_ws_floats': [I],

@@ -10,6 +10,8 @@
 //
 // Reference expressions: GNN_Module.forward (model/network.py:109-125), _re_norm_adj (:183-191), DenseJK (:36-52), max readout
 // (:264), _diff_pool (:194-208).
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "common.hpp"
@@ -107,17 +109,22 @@ struct Ctx {
   int64_t gws_floats;
 };
 
-#define CALL(expr)                     \
-  do {                                 \
-    if (!c.dry) {                      \
-      const int rc__ = (expr);         \
-      if (rc__ != 0) return rc__;      \
-    }                                  \
+static int fail_at(int rc, const char* what, int line) {      // CGC_EXEC_DEBUG=1: say which call of the schedule failed
+  static const bool verbose = getenv("CGC_EXEC_DEBUG") != nullptr;
+  if (verbose) fprintf(stderr, "cgc exec.hip:%d: rc %d from %s\n", line, rc, what);
+  return rc;
+}
+#define CALL(expr)                                              \
+  do {                                                          \
+    if (!c.dry) {                                               \
+      const int rc__ = (expr);                                  \
+      if (rc__ != 0) return fail_at(rc__, #expr, __LINE__);     \
+    }                                                           \
   } while (0)
-#define TRY(expr)                      \
-  do {                                 \
-    const int rc__ = (expr);           \
-    if (rc__ != 0) return rc__;        \
+#define TRY(expr)                                               \
+  do {                                                          \
+    const int rc__ = (expr);                                    \
+    if (rc__ != 0) return fail_at(rc__, #expr, __LINE__);       \
   } while (0)
 
 inline int up(int v, int m) { return (v + m - 1) / m * m; }
@@ -658,7 +665,7 @@ extern "C" int cgc_level_supported(const cgc_level_desc* d) {
   if (d->level == 1 && (d->nmax < 1 || d->npad < d->nmax)) return 0;
   if (d->C > 0 && (d->AH < 1 || d->H + d->AH > 256 || (2 * d->AH) % 4 != 0)) return 0;
   if (d->C == 0 && d->level == 1) return 0;
-  if (d->jk && (d->E != d->H || !cgc_jk_supported(d->H))) return 0;
+  if (d->jk && (d->E != d->H || !cgc_jk_matrix_core(d->H))) return 0;   // (other channel counts: staged parameter gradients, per-operator path)
   return 1;
 }
 

@@ -275,8 +275,8 @@ __global__ __launch_bounds__(JK_THREADS) void k_jk_bwd(const float* __restrict__
     // fold this step's input gradient into time slot t (static index per direction)
 #pragma unroll
     for (int k = 0; k < C; ++k) {
-      if (d == 0) dx[s][k] += dxt[k];
-      else dx[2 - s][k] += dxt[k];
+      dx[s][k] += d == 0 ? dxt[k] : 0.f;
+      dx[2 - s][k] += d == 0 ? 0.f : dxt[k];
     }
   }
 #pragma unroll
@@ -299,10 +299,27 @@ static void fill_weights(JkWeights& w, const float* const* lstm, const float* w_
   w.b_att = b_att;
 }
 
-extern "C" int cgc_jk_supported(int C) { return C == 8 || C == 16 || C == 20; }
+// Channel counts the fused kernels are compiled for: every even C up to 32 (hidden H = 3C/2 <= 48; model/network.py:27-33 needs C
+// even for the bidirectional split).  C in {4, 8, 12, 16, 20} (C % 4 == 0, H <= 32) run on the matrix-core kernels (jk_mfma.hip),
+// the others on the thread-per-direction kernels of this file.
+extern "C" int cgc_jk_supported(int C) { return C >= 2 && C <= 32 && C % 2 == 0; }
+extern "C" int cgc_jk_matrix_core(int C) { return C == 4 || C == 8 || C == 12 || C == 16 || C == 20; }
+
+#define JK_FOR_EACH_C(X) X(2) X(4) X(6) X(8) X(10) X(12) X(14) X(16) X(18) X(20) X(22) X(24) X(26) X(28) X(30) X(32)
+
+template <int C>
+static void jk_allow_lds() {      // the LDS image of the weights exceeds the 64 KB default for C >= 24
+  static bool done = false;
+  if (!done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_jk_fwd<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)JkDims<C>::lds_bytes);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_jk_bwd<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)JkDims<C>::lds_bytes);
+    done = true;
+  }
+}
 
 template <int C>
 static int launch_jk_fwd(const float* xs, int n, int npad, const JkWeights& w, float* out, float* HS, float* CS, hipStream_t st) {
+  jk_allow_lds<C>();
   hipLaunchKernelGGL(k_jk_fwd<C>, dim3(ceil_div(2 * n, JK_THREADS)), dim3(JK_THREADS), JkDims<C>::lds_bytes, st, xs, n, npad, w, out, HS, CS);
   CGC_RETURN_IF_LAUNCH_FAILED();
   return 0;
@@ -310,6 +327,7 @@ static int launch_jk_fwd(const float* xs, int n, int npad, const JkWeights& w, f
 template <int C>
 static int launch_jk_bwd(const float* xs, const float* dout, int n, int npad, const JkWeights& w, const float* HS, const float* CS,
                          float* dxs, float* DGT, float* INT, float* DHC, hipStream_t st) {
+  jk_allow_lds<C>();
   hipLaunchKernelGGL(k_jk_bwd<C>, dim3(ceil_div(2 * npad, JK_THREADS)), dim3(JK_THREADS), JkDims<C>::lds_bytes, st, xs, dout, n, npad, w,
                      HS, CS, dxs, DGT, INT, DHC);
   CGC_RETURN_IF_LAUNCH_FAILED();
@@ -328,9 +346,9 @@ extern "C" int cgc_jk_lstm_fwd(const float* xs, int n, int npad, int C, const fl
     if (rc != CGC_EINVAL) return rc;          // unaligned buffers: the thread-per-direction kernel takes any alignment
   }
   switch (C) {
-    case 8: return launch_jk_fwd<8>(xs, n, npad, w, out, HS, CS, as_stream(stream));
-    case 16: return launch_jk_fwd<16>(xs, n, npad, w, out, HS, CS, as_stream(stream));
-    case 20: return launch_jk_fwd<20>(xs, n, npad, w, out, HS, CS, as_stream(stream));
+#define X(C_) case C_: return launch_jk_fwd<C_>(xs, n, npad, w, out, HS, CS, as_stream(stream));
+    JK_FOR_EACH_C(X)
+#undef X
     default: return CGC_EINVAL;
   }
 }
@@ -348,9 +366,9 @@ extern "C" int cgc_jk_lstm_bwd(const float* xs, const float* dout, int n, int np
     if (rc != CGC_EINVAL) return rc;
   }
   switch (C) {
-    case 8: return launch_jk_bwd<8>(xs, dout, n, npad, w, HS, CS, dxs, DGT, INT, DHC, as_stream(stream));
-    case 16: return launch_jk_bwd<16>(xs, dout, n, npad, w, HS, CS, dxs, DGT, INT, DHC, as_stream(stream));
-    case 20: return launch_jk_bwd<20>(xs, dout, n, npad, w, HS, CS, dxs, DGT, INT, DHC, as_stream(stream));
+#define X(C_) case C_: return launch_jk_bwd<C_>(xs, dout, n, npad, w, HS, CS, dxs, DGT, INT, DHC, as_stream(stream));
+    JK_FOR_EACH_C(X)
+#undef X
     default: return CGC_EINVAL;
   }
 }

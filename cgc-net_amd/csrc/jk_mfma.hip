@@ -600,7 +600,9 @@ static int launch_fwd(const float* xs, int n, int npad, const JkWeights& w, floa
 int jk_mfma_fwd(const float* xs, int n, int npad, int C, const JkWeights& w, float* out, float* HS, float* CS, hipStream_t st) {
   if ((reinterpret_cast<uintptr_t>(xs) & 15u) || (reinterpret_cast<uintptr_t>(out) & 15u)) return CGC_EINVAL;
   switch (C) {
+    case 4: return launch_fwd<4>(xs, n, npad, w, out, HS, CS, st);
     case 8: return launch_fwd<8>(xs, n, npad, w, out, HS, CS, st);
+    case 12: return launch_fwd<12>(xs, n, npad, w, out, HS, CS, st);
     case 16: return launch_fwd<16>(xs, n, npad, w, out, HS, CS, st);
     case 20: return launch_fwd<20>(xs, n, npad, w, out, HS, CS, st);
     default: return CGC_EINVAL;
@@ -639,7 +641,9 @@ int jk_mfma_bwd(const float* xs, const float* dout, int n, int npad, int C, cons
       npad % (32 * JKB_TILES) != 0)
     return CGC_EINVAL;
   switch (C) {
+    case 4: return launch_bwd<4, false>(xs, dout, n, npad, w, HS, CS, dxs, DGT, INT, nullptr, nullptr, st);
     case 8: return launch_bwd<8, false>(xs, dout, n, npad, w, HS, CS, dxs, DGT, INT, nullptr, nullptr, st);
+    case 12: return launch_bwd<12, false>(xs, dout, n, npad, w, HS, CS, dxs, DGT, INT, nullptr, nullptr, st);
     case 16: return launch_bwd<16, false>(xs, dout, n, npad, w, HS, CS, dxs, DGT, INT, nullptr, nullptr, st);
     case 20: return launch_bwd<20, false>(xs, dout, n, npad, w, HS, CS, dxs, DGT, INT, nullptr, nullptr, st);
     default: return CGC_EINVAL;
@@ -658,7 +662,9 @@ int jk_mfma_bwd_params(const float* xs, const float* dout, int n, int npad, int 
   if ((reinterpret_cast<uintptr_t>(xs) & 15u) || (reinterpret_cast<uintptr_t>(dout) & 15u) || (reinterpret_cast<uintptr_t>(dxs) & 15u))
     return CGC_EINVAL;
   switch (C) {
+    case 4: return launch_bwd<4, true>(xs, dout, n, npad, w, HS, CS, dxs, nullptr, nullptr, G, ws, st);
     case 8: return launch_bwd<8, true>(xs, dout, n, npad, w, HS, CS, dxs, nullptr, nullptr, G, ws, st);
+    case 12: return launch_bwd<12, true>(xs, dout, n, npad, w, HS, CS, dxs, nullptr, nullptr, G, ws, st);
     case 16: return launch_bwd<16, true>(xs, dout, n, npad, w, HS, CS, dxs, nullptr, nullptr, G, ws, st);
     case 20: return launch_bwd<20, true>(xs, dout, n, npad, w, HS, CS, dxs, nullptr, nullptr, G, ws, st);
     default: return CGC_EINVAL;

@@ -21,7 +21,7 @@ template <int VEC>
 __global__ __launch_bounds__(256) void k_spmm(const int* __restrict__ rowptr, const int* __restrict__ col, const int* __restrict__ perm,
                                               const float* __restrict__ val, const float* __restrict__ pre,
                                               const float* __restrict__ post, const float* __restrict__ x, float* __restrict__ out,
-                                              int n, int W, int lpr, int n_ctiles, int rows_per_block, int blocks_per_ct,
+                                              int n, int W, int ld, int lpr, int n_ctiles, int rows_per_block, int blocks_per_ct,
                                               int n_chunks, int nt_store, const int* __restrict__ gptr) {
   // XCD-contiguous virtual block id (blocks are dealt round-robin to the 8 XCDs; speed only, never correctness)
   const int nb = gridDim.x, b = blockIdx.x;
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void k_spmm(const int* __restrict__ rowptr, co
           const int cc = __shfl(myc, tt & (lpr - 1), lpr);
           ww[u] = __shfl(myw, tt & (lpr - 1), lpr);
           if (tt < cnt && colok) {
-            xv[u].load(x + (size_t)cc * W + c0);
+            xv[u].load(x + (size_t)cc * ld + c0);
           } else {
             ww[u] = 0.f;
 #pragma unroll
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void k_spmm(const int* __restrict__ rowptr, co
     }
     if (valid && colok) {
       const float ps = post != nullptr ? post[r] : 1.f;
-      float* op = out + (size_t)r * W + c0;
+      float* op = out + (size_t)r * ld + c0;
       if (nt_store && VEC == 4) {   // streaming result: keep it from evicting the re-read neighbour rows out of L2
         typedef float f4v __attribute__((ext_vector_type(4)));
         f4v o4 = {acc[0] * ps, acc[VEC > 1 ? 1 : 0] * ps, acc[VEC > 2 ? 2 : 0] * ps, acc[VEC > 3 ? 3 : 0] * ps};
@@ -275,16 +275,15 @@ static int launch_gather(const int* rowptr, const int* col, const int* perm, con
     CGC_RETURN_IF_LAUNCH_FAILED();
     return 0;
   }
-  if (ld != width) return CGC_EINVAL;                  // padded rows: wide (wave-per-row) path only
   int nb = n_chunks * blocks_per_ct * n_ctiles;
   nb = ceil_div(nb, 8) * 8;
   dim3 grid(nb), block(CGC_BLOCK);
   const int nt = (n_ctiles > 1) ? k_nt : 0;
   if (vec)
-    hipLaunchKernelGGL(k_spmm<4>, grid, block, k_lds, stream, rowptr, col, perm, val, pre, post, x, out, n, width, lpr,
+    hipLaunchKernelGGL(k_spmm<4>, grid, block, k_lds, stream, rowptr, col, perm, val, pre, post, x, out, n, width, ld, lpr,
                        n_ctiles, rows_per_block, blocks_per_ct, n_chunks, nt, gptr);
   else
-    hipLaunchKernelGGL(k_spmm<1>, grid, block, 0, stream, rowptr, col, perm, val, pre, post, x, out, n, width, lpr,
+    hipLaunchKernelGGL(k_spmm<1>, grid, block, 0, stream, rowptr, col, perm, val, pre, post, x, out, n, width, ld, lpr,
                        n_ctiles, rows_per_block, blocks_per_ct, n_chunks, nt, gptr);
   CGC_RETURN_IF_LAUNCH_FAILED();
   return 0;

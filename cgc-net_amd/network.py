@@ -116,7 +116,8 @@ class DenseGINConv(nn.Module):
 # ------------------------------------------------------------------------------------------------
 class DenseJK(nn.Module):
     """LSTM-attention jumping knowledge over a block's three layer outputs (model/network.py:11-55).
-    Three layers with 8/16/20 channels run on the fused HIP kernels (csrc/jk.hip); anything else on torch.nn.LSTM."""
+    Three layers with an even channel count <= 32 run on the fused HIP kernels (csrc/jk.hip, csrc/jk_mfma.hip); anything else on
+    torch.nn.LSTM."""
 
     def __init__(self, mode, channels=None, num_layers=None):
         super().__init__()

@@ -107,7 +107,7 @@ int cgc_spmm(const int* rowptr, const int* col, const int* perm, const float* va
 int cgc_spmm_graphs(const int* rowptr, const int* col, const int* perm, const float* val, const float* pre,
                     const float* post, const float* x, float* out, int n, int width, int ld /* row stride of x and out
                     (>= width): wide rows are kept at a multiple of 32 floats so that a 128-byte line never holds parts
-                    of two rows; ld != width needs width > 128 */, const int* gptr, int B, int nmax, int visit,
+                    of two rows */, const int* gptr, int B, int nmax, int visit,
                     cgc_stream_t stream);
 /* The same with a caller-supplied visiting sequence: gorder[B] (NULL = as above) lists the graphs in the order in which they are
  * swept, the eight XCDs taking consecutive eighths.  For a few LARGE graphs of unequal size (the stress configuration: 32 graphs of
@@ -214,11 +214,13 @@ int cgc_segment_max_bwd_full(const float* dout, const int* arg, const int* gptr,
  * attention + softmax-weighted sum, one thread per node.  xs [n, 3C], out [n, C].  lstm = HOST array of 8 device pointers
  * {w_ih[4H,C], w_hh[4H,H], b_ih[4H], b_hh[4H]} for the forward direction, then the same four for the reverse direction
  * (torch.nn.LSTM layout, gate order i,f,g,o).  HS, CS: [6H, npad] saved hidden / cell states (npad >= n).
- * cgc_jk_supported(C): 1 if this C is compiled in (8, 16, 20).
+ * cgc_jk_supported(C): 1 if this C is compiled in (every even C <= 32); cgc_jk_matrix_core(C): 1 if it runs on the matrix-core
+ * kernels (C in 4, 8, 12, 16, 20: those also have cgc_jk_lstm_bwd_params), else on the thread-per-direction kernels.
  * Backward writes dxs [n, 3C] and, for the parameter gradients, the transposed buffers DGT [2][4H+1][3*npad] and
  * INT [2][C+2H+1][3*npad] (zero in padded columns) whose per-direction product DGT_d * INT_d^T (cgc_gemm_f32, NT) holds
  * [dW_ih | dW_hh | db | .] in rows 0..4H-1 and [. | . | d b_att | d w_att[dH:(d+1)H]] in row 4H.  DHC: [2][2][H][npad] scratch. */
 int cgc_jk_supported(int C);
+int cgc_jk_matrix_core(int C);
 int cgc_jk_lstm_fwd(const float* xs, int n, int npad, int C, const float* const* lstm, const float* w_att,
                     const float* b_att, float* out, float* HS, float* CS, cgc_stream_t stream);
 int cgc_jk_lstm_bwd(const float* xs, const float* dout, int n, int npad, int C, const float* const* lstm,

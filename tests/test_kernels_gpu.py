@@ -720,9 +720,12 @@ def test_fused_adjacency_preparation(B_, C, p, second_stream):
         close(x, y, 2e-5, 'adj_prep %d' % i)
 
 
-@pytest.mark.parametrize('C,n', [(8, 37), (20, 300), (16, 1500), (20, 2500)])
+@pytest.mark.parametrize('C,n', [(8, 37), (20, 300), (16, 1500), (20, 2500), (4, 200), (12, 700), (6, 130), (24, 300), (32, 257)])
 def test_dense_jk_kernels(C, n):
-    """Fused bi-LSTM + attention (csrc/jk.hip) against the torch restatement, and that restatement against torch.nn.LSTM."""
+    """Fused bi-LSTM + attention (csrc/jk.hip, csrc/jk_mfma.hip) against the torch restatement, and that restatement against
+    torch.nn.LSTM.  Every even channel count up to 32 is compiled in (--hidden-dim of train.py): C in 4/8/12/16/20 on the matrix-core
+    kernels, the rest on the thread-per-direction kernels with staged parameter gradients."""
+    assert hip().jk_supported(C)
     H = 3 * C // 2
     torch.manual_seed(C + n)
     lstm_mod = torch.nn.LSTM(C, H, bidirectional=True, batch_first=True)

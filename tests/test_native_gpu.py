@@ -193,3 +193,36 @@ def test_large_graphs_are_reordered_transparently():
         # (a different row order is a different summation order: a handful of the ~1e7 ReLU inputs sit within fp32 rounding of zero
         # and flip, as in test_c3_permutation_invariance_forward_backward -- same 2e-3 bar; measured 5e-4)
         assert rel(p.grad, gf[k].grad) < 2e-3, (k, rel(p.grad, gf[k].grad))
+
+
+@pytest.mark.parametrize('hidden', [12, 24])
+def test_other_hidden_dims_stay_on_the_fused_jk_kernels(hidden):
+    """--hidden-dim other than 8 / 16 / 20 (train.py): DenseJK no longer falls back to MIOpen's LSTM -- 12 runs on the matrix-core
+    kernels (and through the sequencer), 24 on the thread-per-direction kernels (per-operator path).  Against the dense oracle."""
+    from oracle import dense_ref
+    ds = SyntheticCellGraphs(4, 250, num_features=16, base_seed=8)
+    cpu_batch = Batch.from_data_list([ds[i] for i in range(4)])
+    args = (500, 16, hidden, hidden, True, True, hidden, 3, 0.1, [50])
+    kw = dict(concat=True, load_data_sparse=True, norm_adj=True, jk=True, drop_out=0.)
+    torch.manual_seed(4)
+    ref = dense_ref.SoftPoolingGcnEncoder(*args, **kw).train()
+    model = network.SoftPoolingGcnEncoder(*args, **kw)
+    model.load_state_dict(ref.state_dict())
+    model.to(DEV).train()
+    calls = []
+    orig = torch.nn.LSTM.forward
+    torch.nn.LSTM.forward = lambda self, *a, **k: calls.append(1) or orig(self, *a, **k)
+    try:
+        (logits, loss), ncalls = _used_native(model, cpu_batch.to(DEV))
+        loss.backward()
+    finally:
+        torch.nn.LSTM.forward = orig
+    assert not calls, 'DenseJK went through torch.nn.LSTM'
+    assert ncalls == (3 if hidden == 12 else 0)
+    rl, rloss = ref(cpu_batch)
+    rloss.backward()
+    rel = lambda x, y: float((x.double().cpu() - y.double()).abs().max() / (y.double().abs().max() + 1e-3))
+    assert rel(logits, rl) < 1e-4 and rel(loss, rloss) < 1e-4
+    gr = dict(ref.named_parameters())
+    for k, p in model.named_parameters():
+        assert rel(p.grad, gr[k].grad) < 5e-4, (k, rel(p.grad, gr[k].grad))
