@@ -332,7 +332,10 @@ __global__ __launch_bounds__(JKB_THREADS) void k_jk_bwd_mfma(const float* __rest
     for (int r = 0; r < 16; ++r) { dhc[r] = 0.f; dcc[r] = 0.f; }
 
     // (the staged variant is ~7 % faster with the recurrence rolled, the in-kernel-gradient variant ~20 % slower)
-#pragma clang loop unroll_count(PG ? 3 : 1)
+#ifndef JKB_PG_UNROLL
+#define JKB_PG_UNROLL 3
+#endif
+#pragma clang loop unroll_count(PG ? JKB_PG_UNROLL : 1)
     for (int s = 2; s >= 0; --s) {
       const int t = d ? 2 - s : s, tprev = d ? t + 1 : t - 1;
       const size_t col = (size_t)t * npad + node;
@@ -448,14 +451,26 @@ __global__ __launch_bounds__(JKB_THREADS) void k_jk_bwd_mfma(const float* __rest
           *reinterpret_cast<float4*>(Iw + 32 * 36 + l31 * 36 + 8 * q + 4 * lhi) = xv;
         }
         __builtin_amdgcn_wave_barrier();
+#ifndef JKB_BF_RELOAD
+#define JKB_BF_RELOAD 0      // 1: the input fragments are read from the LDS tile again for every gate (32 registers less held)
+#endif
         float bf[2][16];
+        if (!JKB_BF_RELOAD) {
 #pragma unroll
-        for (int kk = 0; kk < 16; ++kk) {
-          bf[0][kk] = Iw[(2 * kk + lhi) * 36 + l31];
-          bf[1][kk] = Iw[32 * 36 + (2 * kk + lhi) * 36 + l31];
+          for (int kk = 0; kk < 16; ++kk) {
+            bf[0][kk] = Iw[(2 * kk + lhi) * 36 + l31];
+            bf[1][kk] = Iw[32 * 36 + (2 * kk + lhi) * 36 + l31];
+          }
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
+          if (JKB_BF_RELOAD) {
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+              bf[0][kk] = Iw[(2 * kk + lhi) * 36 + l31];
+              bf[1][kk] = Iw[32 * 36 + (2 * kk + lhi) * 36 + l31];
+            }
+          }
           __builtin_amdgcn_wave_barrier();
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
