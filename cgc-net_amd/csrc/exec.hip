@@ -15,6 +15,7 @@
 #include <string.h>
 
 #include "common.hpp"
+#include "groups.hpp"
 
 // ------------------------------------------------------------------------------------------------ layout kernels
 struct CatArgs {
@@ -318,6 +319,48 @@ int layer_bwd(const Ctx& c, const cgc_level_desc& d, const LayerP& p, const Laye
   return 0;
 }
 
+// The same two functions for the embedding and the assignment block's layer of one step TOGETHER, when both are narrow layers of one
+// shape (hidden width -> hidden width from the same aggregation buffer): every kernel is launched once for both (groups.hpp).
+// Identical arithmetic per layer; at 4 graphs per GPU these kernels are ~5 us of launch + drain each.
+inline bool pairable(int fin_e, int F_e, int fin_p, int F_p) { return fin_e == fin_p && F_e == F_p && fin_e <= 32 && F_e <= 32; }
+
+int layer_fwd_pair(const Ctx& c, const cgc_level_desc& d, const LayerP* p, const LayerS* s, const float* const* agg, int lda, int n, int fin, int F,
+                   float* const* y, int ldy, float* const* y2, const int* ldy2) {
+  const size_t m = c.scratch->mark();
+  SnFwdPtrs g[2];
+  SnFwdBn bn[2];
+  BnApplyPtrs ap[2];
+  for (int i = 0; i < 2; ++i) {
+    float* ws = d.has_bn ? c.scratch->f(stats_ws_floats(n, F)) : nullptr;
+    g[i] = SnFwdPtrs{agg[i], p[i].W, p[i].b, s[i].hn, s[i].rinv, ws};
+    bn[i] = SnFwdBn{p[i].eps, p[i].mom, p[i].rm, p[i].rv, p[i].nbt, s[i].mean, s[i].istd};
+    ap[i] = BnApplyPtrs{s[i].hn, d.has_bn ? s[i].mean : nullptr, s[i].istd, p[i].gamma, p[i].beta, y[i], y2[i], ldy2[i]};
+  }
+  CALL(sage_narrow_fwd_groups(g, bn, 2, lda, n, fin, F, 1, d.act, d.has_bn, d.count, as_stream(c.s)));
+  CALL(bn_act_apply_groups(ap, 2, n, F, d.act, ldy, as_stream(c.s)));
+  c.scratch->release(m);
+  return 0;
+}
+
+int layer_bwd_pair(const Ctx& c, const cgc_level_desc& d, const LayerP* p, const LayerS* s, const float* const* agg, int lda, int n, int fin, int F,
+                   const float* const* dy, int ldy, float* const* dagg, int ldd, float* const* dwdb, float* const* sums) {
+  const size_t m = c.scratch->mark();
+  const int mode = d.has_bn ? 2 : 0;
+  const size_t slot_floats = (size_t)(cgc_stats_blocks(n, F) > 1 ? cgc_stats_blocks(n, F) : 1) * 2 * F;
+  if (d.has_bn) {
+    BnRedPtrs r[2];
+    for (int i = 0; i < 2; ++i) r[i] = BnRedPtrs{dy[i], s[i].hn, s[i].mean, s[i].istd, c.scratch->f(slot_floats)};
+    CALL(bn_bwd_reduce_groups(r, sums, 2, ldy, n, F, d.act, as_stream(c.s)));
+  }
+  SnBwdPtrs g[2];
+  for (int i = 0; i < 2; ++i)
+    g[i] = SnBwdPtrs{dy[i], s[i].hn, s[i].rinv, s[i].mean, s[i].istd, p[i].gamma, d.has_bn ? sums[i] : nullptr, agg[i], p[i].W, dagg[i],
+                     c.scratch->f((size_t)cgc_sage_narrow_ws_floats(n, fin, F))};
+  CALL(sage_narrow_bwd_groups(g, dwdb, 2, ldy, n, F, d.act, 1, mode, d.count, lda, fin, ldd, as_stream(c.s)));
+  c.scratch->release(m);
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------------ a level
 struct Level {
   const cgc_level_desc& d;
@@ -457,6 +500,17 @@ int level_fwd(const Ctx& c, Level& L, const cgc_block_params* emb, const cgc_blo
     const int lda = k == 0 ? L.fin : wp;
     // a layer's output goes where the next aggregation reads it ([he | hp] side by side) AND into its slot of the block's
     // concatenation (cat[x1, x2, x3] of the embedding block, [hp1 | hp2] of the assignment block): no concatenation kernels
+    if (k < 2 && L.pool && pairable(L.width_in(k), H, L.width_in(3 + k), AH)) {
+      const LayerP pp[2] = {layer_params(d, emb, k, k), layer_params(d, pl, k, 3 + k)};
+      const LayerS ss[2] = {L.L[k], L.L[3 + k]};
+      const float* ag[2] = {ain, k == 0 ? ain : ain + H};
+      float* yy[2] = {L.pair[k], L.pair[k] + H};
+      float* y2[2] = {L.cat_e + k * H, L.x12 + k * AH};
+      const int l2[2] = {L.D3, 2 * AH};
+      TRY(layer_fwd_pair(c, d, pp, ss, ag, lda, n, L.width_in(k), H, yy, wp, y2, l2));
+      if (k < 2) TRY(aggregate(c, L, g, gptr, L.pair[k], wp, L.aggk[k]));
+      continue;
+    }
     if (k < 2)
       TRY(layer_fwd(c, d, layer_params(d, emb, k, k), L.L[k], ain, lda, n, L.width_in(k), L.width_out(k), L.pair[k], wp, L.cat_e + k * H,
                     L.D3));
@@ -553,12 +607,24 @@ int level_bwd_blocks(const Ctx& c, Level& L, const cgc_block_params* emb, const 
     // second layers: both blocks write their halves of d aggk[0] in place; first layers (dense levels): two [n, fin] gradients
     float* de = !need_in ? nullptr : first ? sc.f((size_t)n * fi_e) : (dagg[0] = sc.f((size_t)n * wp));
     const int ldde = first ? fi_e : wp;
-    TRY(layer_bwd(c, d, layer_params(d, emb, k, k), L.L[k], ain, lda, n, fi_e, H, dpair, wp, de, ldde, grads + L.gl.W[k], sums(k)));
     float* dp = nullptr;
-    if (L.pool) {
+    if (L.pool && pairable(fi_e, H, fi_p, AH)) {
       dp = !need_in ? nullptr : first ? sc.f((size_t)n * fi_p) : de + H;
-      TRY(layer_bwd(c, d, layer_params(d, pl, k, 3 + k), L.L[3 + k], first ? ain : ain + H, lda, n, fi_p, AH, dpair + H, wp, dp,
-                    first ? fi_p : wp, grads + L.gl.W[3 + k], sums(3 + k)));
+      const LayerP pp[2] = {layer_params(d, emb, k, k), layer_params(d, pl, k, 3 + k)};
+      const LayerS ss[2] = {L.L[k], L.L[3 + k]};
+      const float* ag[2] = {ain, first ? ain : ain + H};
+      const float* dyy[2] = {dpair, dpair + H};
+      float* dg[2] = {de, dp};
+      float* dw[2] = {grads + L.gl.W[k], grads + L.gl.W[3 + k]};
+      float* sm[2] = {sums(k), sums(3 + k)};
+      TRY(layer_bwd_pair(c, d, pp, ss, ag, lda, n, fi_e, H, dyy, wp, dg, ldde, dw, sm));
+    } else {
+      TRY(layer_bwd(c, d, layer_params(d, emb, k, k), L.L[k], ain, lda, n, fi_e, H, dpair, wp, de, ldde, grads + L.gl.W[k], sums(k)));
+      if (L.pool) {
+        dp = !need_in ? nullptr : first ? sc.f((size_t)n * fi_p) : de + H;
+        TRY(layer_bwd(c, d, layer_params(d, pl, k, 3 + k), L.L[3 + k], first ? ain : ain + H, lda, n, fi_p, AH, dpair + H, wp, dp,
+                      first ? fi_p : wp, grads + L.gl.W[3 + k], sums(3 + k)));
+      }
     }
     if (first && L.dense) {
       // both first layers read the same aggregation A x: their gradients add up

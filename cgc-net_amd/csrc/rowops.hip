@@ -5,6 +5,7 @@
 //     deterministically (wave -> LDS -> per-block slot -> second-stage kernel): no float atomics anywhere.
 // Reference arithmetic: see the citations in include/cgc_hip.h.
 #include "common.hpp"
+#include "groups.hpp"
 
 #define L2_EPS 1e-12f
 #define RENORM_EPS 1e-15f
@@ -85,6 +86,40 @@ __global__ __launch_bounds__(32 * RS_GROUPS) void k_reduce_slots(const float* __
 }
 #define REDUCE_SLOTS_GRID(width) dim3(ceil_div((width), 32))
 
+// the same for two slot areas in one launch (blockIdx.y picks the pair)
+__global__ __launch_bounds__(32 * RS_GROUPS) void k_reduce_slots_pair(const float* __restrict__ ws0, float* __restrict__ out0,
+                                                                     const float* __restrict__ ws1, float* __restrict__ out1, int slots, int width) {
+  const float* __restrict__ ws = blockIdx.y ? ws1 : ws0;
+  float* __restrict__ out = blockIdx.y ? out1 : out0;
+  __shared__ double part[RS_GROUPS][32];
+  const int cl = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  double s = 0.0;
+  if (c < width) {
+    double a[4] = {0.0, 0.0, 0.0, 0.0};
+    int k = grp;
+    for (; k + 3 * RS_GROUPS < slots; k += 4 * RS_GROUPS) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a[u] += (double)ws[(size_t)(k + RS_GROUPS * u) * width + c];
+    }
+    for (; k < slots; k += RS_GROUPS) a[0] += (double)ws[(size_t)k * width + c];
+    s = (a[0] + a[1]) + (a[2] + a[3]);
+  }
+  part[grp][cl] = s;
+  __syncthreads();
+  if (grp == 0 && c < width) {
+    double t[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int g = 0; g < RS_GROUPS; g += 4) { t[0] += part[g][cl]; t[1] += part[g + 1][cl]; t[2] += part[g + 2][cl]; t[3] += part[g + 3][cl]; }
+    out[c] = (float)((t[0] + t[1]) + (t[2] + t[3]));
+  }
+}
+int launch_reduce_slots_f32_pair(const float* ws0, float* out0, const float* ws1, float* out1, int ng, int slots, int width, hipStream_t stream) {
+  hipLaunchKernelGGL(k_reduce_slots_pair, dim3(ceil_div(width, 32), ng), dim3(32 * RS_GROUPS), 0, stream, ws0, out0, ws1, out1, slots, width);
+  CGC_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}
+
 int launch_reduce_slots_f32(const float* ws, int slots, int width, float* out, hipStream_t stream) {
   hipLaunchKernelGGL(k_reduce_slots<float>, REDUCE_SLOTS_GRID(width), dim3(32 * RS_GROUPS), 0, stream, ws, slots, width, out);
   CGC_RETURN_IF_LAUNCH_FAILED();
@@ -139,6 +174,30 @@ static ColCfg col_cfg(int n, int F, bool vec_ok) {
       }                                                                                                      \
     }                                                                                                        \
   } while (0)
+
+#define DISPATCH_COL_Y(KERNEL, cfg, ny, smem_bytes, stream, ...)                                                   \
+  do {                                                                                                       \
+    dim3 g__((cfg).blocks, (ny)), b__(CGC_BLOCK);                                                                    \
+    if ((cfg).vec == 4) {                                                                                    \
+      switch ((cfg).maxj) {                                                                                  \
+        case 1: hipLaunchKernelGGL((KERNEL<4, 1>), g__, b__, smem_bytes, stream, __VA_ARGS__); break;        \
+        case 2: hipLaunchKernelGGL((KERNEL<4, 2>), g__, b__, smem_bytes, stream, __VA_ARGS__); break;        \
+        case 4: hipLaunchKernelGGL((KERNEL<4, 4>), g__, b__, smem_bytes, stream, __VA_ARGS__); break;        \
+        case 5: hipLaunchKernelGGL((KERNEL<4, 5>), g__, b__, smem_bytes, stream, __VA_ARGS__); break;        \
+        default: hipLaunchKernelGGL((KERNEL<4, 8>), g__, b__, smem_bytes, stream, __VA_ARGS__); break;       \
+      }                                                                                                      \
+    } else {                                                                                                 \
+      switch ((cfg).maxj) {                                                                                  \
+        case 1: hipLaunchKernelGGL((KERNEL<1, 1>), g__, b__, smem_bytes, stream, __VA_ARGS__); break;        \
+        case 2: hipLaunchKernelGGL((KERNEL<1, 2>), g__, b__, smem_bytes, stream, __VA_ARGS__); break;        \
+        case 4: hipLaunchKernelGGL((KERNEL<1, 4>), g__, b__, smem_bytes, stream, __VA_ARGS__); break;        \
+        case 8: hipLaunchKernelGGL((KERNEL<1, 8>), g__, b__, smem_bytes, stream, __VA_ARGS__); break;        \
+        case 16: hipLaunchKernelGGL((KERNEL<1, 16>), g__, b__, smem_bytes, stream, __VA_ARGS__); break;      \
+        default: hipLaunchKernelGGL((KERNEL<1, 32>), g__, b__, smem_bytes, stream, __VA_ARGS__); break;      \
+      }                                                                                                      \
+    }                                                                                                        \
+  } while (0)
+
 
 extern "C" int cgc_stats_blocks(int n, int F) {
   (void)F;
@@ -252,9 +311,15 @@ extern "C" int cgc_bn_finalize(const double* stats, int F, double count, float e
 
 // second stage of the statistics + finalize in one kernel: the column sums of the slots (same grouping and order as
 // k_reduce_slots<double>, so the same bits) and mean / istd / running statistics / num_batches_tracked of k_bn_finalize
-__global__ __launch_bounds__(32 * RS_GROUPS) void k_stats_finalize(const float* __restrict__ ws, int slots, int F, double count, float eps,
-                                                                  float momentum, float* running_mean, float* running_var,
-                                                                  float* __restrict__ mean, float* __restrict__ istd, long long* nbt) {
+__global__ __launch_bounds__(32 * RS_GROUPS) void k_stats_finalize(const StatsFinPtrs p0, const StatsFinPtrs p1, int slots, int F, double count) {
+  const StatsFinPtrs& p = blockIdx.y ? p1 : p0;
+  const float* __restrict__ ws = p.ws;
+  const float eps = p.eps, momentum = p.momentum;
+  float* running_mean = p.running_mean;
+  float* running_var = p.running_var;
+  float* __restrict__ mean = p.mean;
+  float* __restrict__ istd = p.istd;
+  long long* nbt = p.nbt;
   __shared__ double part[2][RS_GROUPS][32];
   const int cl = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int f = blockIdx.x * 32 + cl;
@@ -296,12 +361,15 @@ __global__ __launch_bounds__(32 * RS_GROUPS) void k_stats_finalize(const float* 
   }
 }
 
-int launch_stats_finalize(const float* ws, int slots, int F, double count, float eps, float momentum, float* running_mean,
-                          float* running_var, float* mean, float* istd, int64_t* nbt, hipStream_t stream) {
-  hipLaunchKernelGGL(k_stats_finalize, dim3(ceil_div(F, 32)), dim3(32 * RS_GROUPS), 0, stream, ws, slots, F, count, eps, momentum,
-                     running_mean, running_var, mean, istd, reinterpret_cast<long long*>(nbt));
+int launch_stats_finalize_groups(const StatsFinPtrs* g, int ng, int slots, int F, double count, hipStream_t stream) {
+  hipLaunchKernelGGL(k_stats_finalize, dim3(ceil_div(F, 32), ng), dim3(32 * RS_GROUPS), 0, stream, g[0], g[ng - 1], slots, F, count);
   CGC_RETURN_IF_LAUNCH_FAILED();
   return 0;
+}
+int launch_stats_finalize(const float* ws, int slots, int F, double count, float eps, float momentum, float* running_mean,
+                          float* running_var, float* mean, float* istd, int64_t* nbt, hipStream_t stream) {
+  const StatsFinPtrs g{ws, running_mean, running_var, mean, istd, reinterpret_cast<long long*>(nbt), eps, momentum};
+  return launch_stats_finalize_groups(&g, 1, slots, F, count, stream);
 }
 
 // The training forward's statistics as ONE call: l2norm + activation sums, then second stage + finalize + running statistics +
@@ -322,20 +390,23 @@ extern "C" int cgc_l2norm_act_bn(const float* h, int n, int F, int normalize, in
     CGC_RETURN_IF_LAUNCH_FAILED();
     slots = cfg.blocks;
   }
-  hipLaunchKernelGGL(k_stats_finalize, dim3(ceil_div(F, 32)), dim3(32 * RS_GROUPS), 0, as_stream(stream), ws, slots, F, count, eps, momentum,
-                     running_mean, running_var, mean, istd, reinterpret_cast<long long*>(num_batches_tracked));
-  CGC_RETURN_IF_LAUNCH_FAILED();
-  return 0;
+  return launch_stats_finalize(ws, slots, F, count, eps, momentum, running_mean, running_var, mean, istd, num_batches_tracked, as_stream(stream));
 }
 
 // ------------------------------------------------------------------------------------------------
 // y = BN(act(hn))   (elementwise; y may be a column slice of a wider buffer: ldy)
 // ------------------------------------------------------------------------------------------------
 template <int VEC, int MAXJ>
-__global__ __launch_bounds__(256) void k_bn_act_apply(const float* __restrict__ hn, int n, int F, int lpr, int act,
-                                                      const float* __restrict__ mean, const float* __restrict__ istd,
-                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                      float* __restrict__ y, int ldy, float* __restrict__ y2, int ldy2) {
+__global__ __launch_bounds__(256) void k_bn_act_apply(const BnApplyPtrs p0, const BnApplyPtrs p1, int n, int F, int lpr, int act, int ldy) {
+  const BnApplyPtrs& p = blockIdx.y ? p1 : p0;
+  const float* __restrict__ hn = p.hn;
+  const float* __restrict__ mean = p.mean;
+  const float* __restrict__ istd = p.istd;
+  const float* __restrict__ gamma = p.gamma;
+  const float* __restrict__ beta = p.beta;
+  float* __restrict__ y = p.y;
+  float* __restrict__ y2 = p.y2;
+  const int ldy2 = p.ldy2;
   const RowGroup rg(lpr);
   // y = (act(hn) - mu) * sc + sh with sc = istd*gamma: the lane's columns never change, so the constants live in
   // registers.  (o - mu) is formed first, as nn.BatchNorm1d does: folding mu into the shift would cancel catastrophically
@@ -380,26 +451,37 @@ extern "C" int cgc_bn_act_apply(const float* hn, int n, int F, int act, const fl
 
 // the same result written to a second destination as well (y2 [n, F], row stride ldy2; NULL: none): a layer's output goes into the
 // buffer the next aggregation reads AND into its slot of the block's concatenation (model/network.py:118)
-extern "C" int cgc_bn_act_apply2(const float* hn, int n, int F, int act, const float* mean, const float* istd, const float* gamma,
-                                 const float* beta, float* y, int ldy, float* y2, int ldy2, cgc_stream_t stream) {
+int bn_act_apply_groups(const BnApplyPtrs* g, int ng, int n, int F, int act, int ldy, hipStream_t stream) {
   if (n <= 0 || F <= 0) return 0;
-  const bool vec = (F % 4 == 0) && (ldy % 4 == 0) && aligned16(hn) && aligned16(y) && (y2 == nullptr || (ldy2 % 4 == 0 && aligned16(y2)));
+  if (ng < 1 || ng > 2) return CGC_EINVAL;
+  bool vec = (F % 4 == 0) && (ldy % 4 == 0);
+  for (int i = 0; i < ng; ++i)
+    vec = vec && aligned16(g[i].hn) && aligned16(g[i].y) && (g[i].y2 == nullptr || (g[i].ldy2 % 4 == 0 && aligned16(g[i].y2)));
   ColCfg cfg = col_cfg(n, F, vec);
   if (!cfg.ok) return CGC_EINVAL;
   cfg.blocks = row_blocks(n, cfg.lpr, 1024);      // every wave first loads its columns' constants: 1024 longer-lived workgroups
                                                   // beat 2048 (119 vs 147 us on [57.7k, 1140])
-  DISPATCH_COL(k_bn_act_apply, cfg, 0, as_stream(stream), hn, n, F, cfg.lpr, act, mean, istd, gamma, beta, y, ldy, y2, ldy2);
+  DISPATCH_COL_Y(k_bn_act_apply, cfg, ng, 0, stream, g[0], g[ng - 1], n, F, cfg.lpr, act, ldy);
   CGC_RETURN_IF_LAUNCH_FAILED();
   return 0;
+}
+extern "C" int cgc_bn_act_apply2(const float* hn, int n, int F, int act, const float* mean, const float* istd, const float* gamma,
+                                 const float* beta, float* y, int ldy, float* y2, int ldy2, cgc_stream_t stream) {
+  const BnApplyPtrs g{hn, mean, istd, gamma, beta, y, y2, ldy2};
+  return bn_act_apply_groups(&g, 1, n, F, act, ldy, as_stream(stream));
 }
 
 // ------------------------------------------------------------------------------------------------
 // BatchNorm backward, stage 1: sums[0] = sum dy, sums[1] = sum dy * xhat
 // ------------------------------------------------------------------------------------------------
 template <int VEC, int MAXJ>
-__global__ __launch_bounds__(256) void k_bn_bwd_reduce(const float* __restrict__ dy, int ldy, const float* __restrict__ hn, int n,
-                                                       int F, int lpr, int act, const float* __restrict__ mean,
-                                                       const float* __restrict__ istd, float* __restrict__ ws) {
+__global__ __launch_bounds__(256) void k_bn_bwd_reduce(const BnRedPtrs p0, const BnRedPtrs p1, int ldy, int n, int F, int lpr, int act) {
+  const BnRedPtrs& p = blockIdx.y ? p1 : p0;
+  const float* __restrict__ dy = p.dy;
+  const float* __restrict__ hn = p.hn;
+  const float* __restrict__ mean = p.mean;
+  const float* __restrict__ istd = p.istd;
+  float* __restrict__ ws = p.ws;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const RowGroup rg(lpr);
   float acc[2][MAXJ][VEC];
@@ -436,22 +518,27 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const float* __restrict__
   col_reduce_store<VEC, MAXJ, 2>(acc, F, lpr, smem, ws + (size_t)blockIdx.x * 2 * F);
 }
 
-extern "C" int cgc_bn_bwd_reduce(const float* dy, int ldy, const float* hn, int n, int F, int act, const float* mean,
-                                 const float* istd, float* sums, float* ws, cgc_stream_t stream) {
+int bn_bwd_reduce_groups(const BnRedPtrs* g, float* const* sums, int ng, int ldy, int n, int F, int act, hipStream_t stream) {
   if (F <= 0) return 0;
+  if (ng < 1 || ng > 2) return CGC_EINVAL;
   if (n <= 0) {
-    (void)hipMemsetAsync(sums, 0, sizeof(float) * 2 * F, as_stream(stream));
+    for (int i = 0; i < ng; ++i) (void)hipMemsetAsync(sums[i], 0, sizeof(float) * 2 * F, stream);
     return 0;
   }
-  const bool vec_ok = (F % 4 == 0) && (ldy % 4 == 0) && aligned16(dy) && aligned16(hn);
+  bool vec_ok = (F % 4 == 0) && (ldy % 4 == 0);
+  for (int i = 0; i < ng; ++i) vec_ok = vec_ok && aligned16(g[i].dy) && aligned16(g[i].hn);
   ColCfg cfg = col_cfg(n, F, vec_ok);
   if (!cfg.ok) return CGC_EINVAL;
   const size_t smem = sizeof(float) * 3 * 2 * F;
-  DISPATCH_COL(k_bn_bwd_reduce, cfg, smem, as_stream(stream), dy, ldy, hn, n, F, cfg.lpr, act, mean, istd, ws);
+  DISPATCH_COL_Y(k_bn_bwd_reduce, cfg, ng, smem, stream, g[0], g[ng - 1], ldy, n, F, cfg.lpr, act);
   CGC_RETURN_IF_LAUNCH_FAILED();
-  hipLaunchKernelGGL(k_reduce_slots<float>, REDUCE_SLOTS_GRID(2 * F), dim3(32 * RS_GROUPS), 0, as_stream(stream), ws, cfg.blocks, 2 * F, sums);
-  CGC_RETURN_IF_LAUNCH_FAILED();
-  return 0;
+  return launch_reduce_slots_f32_pair(g[0].ws, sums[0], g[ng - 1].ws, sums[ng - 1], ng, cfg.blocks, 2 * F, stream);
+}
+extern "C" int cgc_bn_bwd_reduce(const float* dy, int ldy, const float* hn, int n, int F, int act, const float* mean,
+                                 const float* istd, float* sums, float* ws, cgc_stream_t stream) {
+  const BnRedPtrs g{dy, hn, mean, istd, ws};
+  float* const out[1] = {sums};
+  return bn_bwd_reduce_groups(&g, out, 1, ldy, n, F, act, as_stream(stream));
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -15,6 +15,7 @@
 // wave-private LDS strip (rows become lanes: the A operand), W^T sits in registers as B fragments.  Each workgroup leaves one slot
 // row [d W | d b] (its four waves folded through LDS); cgc's fixed-order slot reduction folds the slots (deterministic).
 #include "common.hpp"
+#include "groups.hpp"
 
 #define L2_EPS 1e-12f
 typedef float floatx16 __attribute__((ext_vector_type(16)));
@@ -37,12 +38,20 @@ __device__ __forceinline__ float half_sum(float v) {
 #define SN_LDT 33       // LDS row stride of the transposition strip (words): conflict-free column reads
 
 template <int FS, int ACT>       // FS = ceil(F / 2): MFMA steps of the d agg product; ACT: activation code (compile time: no per-element branch)
-__global__ __launch_bounds__(256) void k_sage_narrow_bwd(const float* __restrict__ dy, int ldy, const float* __restrict__ hn,
-                                                         const float* __restrict__ rinv, int n, int F, int /*act*/, int normalize, int mode,
-                                                         const float* __restrict__ mean, const float* __restrict__ istd,
-                                                         const float* __restrict__ gamma, const float* __restrict__ sums, float inv_count,
-                                                         const float* __restrict__ agg, int lda, int fin, const float* __restrict__ W,
-                                                         float* __restrict__ dagg, int ldd, float* __restrict__ ws, int tiles) {
+__global__ __launch_bounds__(256) void k_sage_narrow_bwd(const SnBwdPtrs p0, const SnBwdPtrs p1, int ldy, int n, int F, int /*act*/,
+                                                         int normalize, int mode, float inv_count, int lda, int fin, int ldd, int tiles) {
+  const bool second = blockIdx.y != 0;
+  const float* __restrict__ dy = second ? p1.dy : p0.dy;
+  const float* __restrict__ hn = second ? p1.hn : p0.hn;
+  const float* __restrict__ rinv = second ? p1.rinv : p0.rinv;
+  const float* __restrict__ mean = second ? p1.mean : p0.mean;
+  const float* __restrict__ istd = second ? p1.istd : p0.istd;
+  const float* __restrict__ gamma = second ? p1.gamma : p0.gamma;
+  const float* __restrict__ sums = second ? p1.sums : p0.sums;
+  const float* __restrict__ agg = second ? p1.agg : p0.agg;
+  const float* __restrict__ W = second ? p1.W : p0.W;
+  float* __restrict__ dagg = second ? p1.dagg : p0.dagg;
+  float* __restrict__ ws = second ? p1.ws : p0.ws;
   __shared__ float strip[4][17 * 64];              // per wave: the 32 x 33 transposition strip; at the end the [17][64] exchange buffer
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int f = lane & 31, half = lane >> 5;
@@ -164,24 +173,25 @@ extern "C" int cgc_sage_narrow_bwd(const float* dy, int ldy, const float* hn, co
 }
 
 // the same with a row stride for dagg (>= fin): the two blocks of a level write their halves of one [n, fin_e + fin_p] gradient
-extern "C" int cgc_sage_narrow_bwd_ld(const float* dy, int ldy, const float* hn, const float* rinv, int n, int F, int act, int normalize,
-                                      int mode, const float* mean, const float* istd, const float* gamma, const float* sums, double count,
-                                      const float* agg, int lda, int fin, const float* W, float* dagg, int ldd, float* dwdb, float* ws,
-                                      cgc_stream_t stream_) {
-  hipStream_t st = as_stream(stream_);
+// One launch for up to two layers of equal shape (the embedding and the assignment block of a level run in lockstep): sets g[0..ng)
+int sage_narrow_bwd_groups(const SnBwdPtrs* g, float* const* dwdb, int ng, int ldy, int n, int F, int act, int normalize, int mode, double count,
+                           int lda, int fin, int ldd, hipStream_t st) {
   if (F <= 0 || fin <= 0) return 0;
-  if (F > 32 || fin > 32 || ws == nullptr || dwdb == nullptr || (dagg != nullptr && ldd < fin)) return CGC_EINVAL;
+  if (F > 32 || fin > 32 || ng < 1 || ng > 2) return CGC_EINVAL;
+  for (int i = 0; i < ng; ++i)
+    if (g[i].ws == nullptr || dwdb[i] == nullptr || (g[i].dagg != nullptr && ldd < fin)) return CGC_EINVAL;
   const int width = fin * F + F;
   if (n <= 0) {
-    (void)hipMemsetAsync(dwdb, 0, sizeof(float) * width, st);
+    for (int i = 0; i < ng; ++i) (void)hipMemsetAsync(dwdb[i], 0, sizeof(float) * width, st);
     return 0;
   }
   const int tiles = ceil_div(n, 32), grid = sn_grid(n);
   const float inv_count = (float)(1.0 / count);
   const int fs = (F + 1) / 2;
-#define SN_LAUNCH(FS_, ACT_)                                                                                                         \
-  hipLaunchKernelGGL((k_sage_narrow_bwd<FS_, ACT_>), dim3(grid), dim3(256), 0, st, dy, ldy, hn, rinv, n, F, act, normalize, mode, mean, \
-                     istd, gamma, sums, inv_count, agg, lda, fin, W, dagg, ldd, ws, tiles)
+  const SnBwdPtrs& g1 = g[ng - 1];
+#define SN_LAUNCH(FS_, ACT_)                                                                                                       \
+  hipLaunchKernelGGL((k_sage_narrow_bwd<FS_, ACT_>), dim3(grid, ng), dim3(256), 0, st, g[0], g1, ldy, n, F, act, normalize, mode, inv_count, \
+                     lda, fin, ldd, tiles)
 #define SN_ACT(FS_)                                                                                        \
   switch (act) {                                                                                           \
     case CGC_ACT_RELU: SN_LAUNCH(FS_, CGC_ACT_RELU); break;                                                \
@@ -193,7 +203,16 @@ extern "C" int cgc_sage_narrow_bwd_ld(const float* dy, int ldy, const float* hn,
 #undef SN_ACT
 #undef SN_LAUNCH
   CGC_RETURN_IF_LAUNCH_FAILED();
-  return launch_reduce_slots_f32(ws, grid, width, dwdb, st);
+  return launch_reduce_slots_f32_pair(g[0].ws, dwdb[0], g1.ws, dwdb[ng - 1], ng, grid, width, st);
+}
+
+extern "C" int cgc_sage_narrow_bwd_ld(const float* dy, int ldy, const float* hn, const float* rinv, int n, int F, int act, int normalize,
+                                      int mode, const float* mean, const float* istd, const float* gamma, const float* sums, double count,
+                                      const float* agg, int lda, int fin, const float* W, float* dagg, int ldd, float* dwdb, float* ws,
+                                      cgc_stream_t stream_) {
+  const SnBwdPtrs g{dy, hn, rinv, mean, istd, gamma, sums, agg, W, dagg, ws};
+  float* const out[1] = {dwdb};
+  return sage_narrow_bwd_groups(&g, out, 1, ldy, n, F, act, normalize, mode, count, lda, fin, ldd, as_stream(stream_));
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -202,10 +221,15 @@ extern "C" int cgc_sage_narrow_bwd_ld(const float* dy, int ldy, const float* hn,
 // row-per-lane: the A operand) and lands in the lane = column layout, where the row norm is a 5-step shuffle reduction per
 // register and the column statistics are per-lane sums.  One slot row [2, F] per workgroup (four waves folded through LDS).
 template <int KS, int ACT>
-__global__ __launch_bounds__(256) void k_sage_narrow_fwd(const float* __restrict__ agg, int lda, const float* __restrict__ W,
-                                                         const float* __restrict__ bias, int n, int K, int F, int normalize, int /*act*/,
-                                                         float* __restrict__ hn, float* __restrict__ rinv_out, float* __restrict__ ws,
-                                                         int tiles) {
+__global__ __launch_bounds__(256) void k_sage_narrow_fwd(const SnFwdPtrs p0, const SnFwdPtrs p1, int lda, int n, int K, int F, int normalize,
+                                                         int /*act*/, int tiles) {
+  const bool second = blockIdx.y != 0;
+  const float* __restrict__ agg = second ? p1.agg : p0.agg;
+  const float* __restrict__ W = second ? p1.W : p0.W;
+  const float* __restrict__ bias = second ? p1.bias : p0.bias;
+  float* __restrict__ hn = second ? p1.hn : p0.hn;
+  float* __restrict__ rinv_out = second ? p1.rinv : p0.rinv;
+  float* __restrict__ ws = second ? p1.ws : p0.ws;
   __shared__ float xch[4][2][32];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int f = lane & 31, half = lane >> 5;
@@ -267,19 +291,13 @@ __global__ __launch_bounds__(256) void k_sage_narrow_fwd(const float* __restrict
 }
 
 extern "C" int cgc_stats_blocks(int n, int F);
-int launch_stats_finalize(const float* ws, int slots, int F, double count, float eps, float momentum, float* running_mean,
-                          float* running_var, float* mean, float* istd, int64_t* nbt, hipStream_t stream);   // rowops.hip
-
-// hn [n,F] (contiguous) = l2norm(agg [n,K] (row stride lda) @ W [K,F] + bias), rinv [n]; stats != 0: mean / istd / running statistics /
-// num_batches_tracked as cgc_l2norm_act_bn (ws: its slot area).  Envelope K <= 32, F <= 32; otherwise CGC_EINVAL, nothing launched.
-extern "C" int cgc_sage_narrow_fwd(const float* agg, int lda, const float* W, const float* bias, int n, int K, int F, int normalize,
-                                   int act, float* hn, float* rinv, int stats, float* ws, double count, float eps, float momentum,
-                                   float* running_mean, float* running_var, int64_t* num_batches_tracked, float* mean, float* istd,
-                                   cgc_stream_t stream_) {
-  hipStream_t st = as_stream(stream_);
+// hn = l2norm(agg W + bias) (+ BatchNorm statistics) for up to two layers of equal shape in one launch each
+int sage_narrow_fwd_groups(const SnFwdPtrs* g, const SnFwdBn* bn, int ng, int lda, int n, int K, int F, int normalize, int act, int stats,
+                           double count, hipStream_t st) {
   if (F <= 0) return 0;
-  if (K <= 0 || K > 32 || F > 32) return CGC_EINVAL;
-  if (stats && (ws == nullptr || mean == nullptr || istd == nullptr)) return CGC_EINVAL;
+  if (K <= 0 || K > 32 || F > 32 || ng < 1 || ng > 2) return CGC_EINVAL;
+  for (int i = 0; i < ng; ++i)
+    if (stats && (g[i].ws == nullptr || bn[i].mean == nullptr || bn[i].istd == nullptr)) return CGC_EINVAL;
   int slots = 0;
   if (n > 0) {
     const int tiles = ceil_div(n, 32);
@@ -287,10 +305,11 @@ extern "C" int cgc_sage_narrow_fwd(const float* agg, int lda, const float* W, co
     const int cap = cgc_stats_blocks(n, F);
     if (grid > 1024) grid = 1024;
     if (stats && grid > cap) grid = cap > 0 ? cap : 1;
-    float* wsp = stats ? ws : nullptr;
+    SnFwdPtrs a0 = g[0], a1 = g[ng - 1];
+    if (!stats) a0.ws = a1.ws = nullptr;
     const int ks = (K + 1) / 2;
-#define SNF_LAUNCH(KS_, ACT_)                                                                                                      \
-  hipLaunchKernelGGL((k_sage_narrow_fwd<KS_, ACT_>), dim3(grid), dim3(256), 0, st, agg, lda, W, bias, n, K, F, normalize, act, hn, rinv, wsp, tiles)
+#define SNF_LAUNCH(KS_, ACT_) \
+  hipLaunchKernelGGL((k_sage_narrow_fwd<KS_, ACT_>), dim3(grid, ng), dim3(256), 0, st, a0, a1, lda, n, K, F, normalize, act, tiles)
 #define SNF_ACT(KS_)                                                                                       \
   switch (act) {                                                                                           \
     case CGC_ACT_RELU: SNF_LAUNCH(KS_, CGC_ACT_RELU); break;                                               \
@@ -304,6 +323,23 @@ extern "C" int cgc_sage_narrow_fwd(const float* agg, int lda, const float* W, co
     CGC_RETURN_IF_LAUNCH_FAILED();
     slots = grid;
   }
-  if (stats) return launch_stats_finalize(ws, slots, F, count, eps, momentum, running_mean, running_var, mean, istd, num_batches_tracked, st);
+  if (stats) {
+    StatsFinPtrs f[2];
+    for (int i = 0; i < ng; ++i)
+      f[i] = StatsFinPtrs{g[i].ws, bn[i].running_mean, bn[i].running_var, bn[i].mean, bn[i].istd, reinterpret_cast<long long*>(bn[i].nbt),
+                          bn[i].eps, bn[i].momentum};
+    return launch_stats_finalize_groups(f, ng, slots, F, count, st);
+  }
   return 0;
+}
+
+// hn [n,F] (contiguous) = l2norm(agg [n,K] (row stride lda) @ W [K,F] + bias), rinv [n]; stats != 0: mean / istd / running statistics /
+// num_batches_tracked as cgc_l2norm_act_bn (ws: its slot area).  Envelope K <= 32, F <= 32; otherwise CGC_EINVAL, nothing launched.
+extern "C" int cgc_sage_narrow_fwd(const float* agg, int lda, const float* W, const float* bias, int n, int K, int F, int normalize,
+                                   int act, float* hn, float* rinv, int stats, float* ws, double count, float eps, float momentum,
+                                   float* running_mean, float* running_var, int64_t* num_batches_tracked, float* mean, float* istd,
+                                   cgc_stream_t stream_) {
+  const SnFwdPtrs g{agg, W, bias, hn, rinv, ws};
+  const SnFwdBn bn{eps, momentum, running_mean, running_var, num_batches_tracked, mean, istd};
+  return sage_narrow_fwd_groups(&g, &bn, 1, lda, n, K, F, normalize, act, stats, count, as_stream(stream_));
 }
