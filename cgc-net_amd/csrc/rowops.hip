@@ -935,11 +935,22 @@ __global__ __launch_bounds__(64 * SEGMAX_WAVES) void k_segment_max_fwd(const flo
   const int lo = gptr[b], hi = gptr[b + 1];
   float best = -INFINITY;
   int idx = -1;
-  if (d < D)
-    for (int r = lo + wave * rpw + sub; r < hi; r += SEGMAX_WAVES * rpw) {   // increasing rows + strict '>' keeps the FIRST maximum
+  if (d < D) {
+    const int stride = SEGMAX_WAVES * rpw;
+    int r = lo + wave * rpw + sub;
+    for (; r + 3 * stride < hi; r += 4 * stride) {       // four independent loads in flight (the scan is pure latency: ~60 dependent
+      float v[4];                                        // iterations per wave on an 1800-node graph); compared in row order
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = x[(size_t)(r + u * stride) * D + d];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (v[u] > best) { best = v[u]; idx = r + u * stride; }
+    }
+    for (; r < hi; r += stride) {                        // increasing rows + strict '>' keeps the FIRST maximum
       const float v = x[(size_t)r * D + d];
       if (v > best) { best = v; idx = r; }
     }
+  }
   bv[wave][lane] = best;
   bi[wave][lane] = idx;
   __syncthreads();

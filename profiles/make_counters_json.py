@@ -11,7 +11,11 @@ The flops-derived `frac` of bench.py divides by the 2.4 GHz peak instead, so fra
 usage: make_counters_json.py profiles/r02_bench_c3_pmc_sq.txt > profiles/r02_counters.json"""
 import collections
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import source_hash  # noqa: E402  (the kernel sources these counters were measured on: bench.py quotes them only for the same hash)
 
 vals = collections.defaultdict(dict)
 for line in open(sys.argv[1]):
@@ -39,4 +43,5 @@ for k, c in vals.items():
     tot_cyc += 1024.0 * cyc * calls
 out['gemm_128x128'] = {'mfma_busy': round(tot_busy / tot_cyc, 4) if tot_cyc else None,
                        'definition': 'SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE / 8), launch-weighted over the three instantiations'}
+out['source_sha256'] = source_hash()
 print(json.dumps(out, indent=1))

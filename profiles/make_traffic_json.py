@@ -6,7 +6,11 @@ usage: make_traffic_json.py <pmc_FETCH_dir> <pmc_WRITE_dir> > profiles/rNN_traff
 import collections
 import csv
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import source_hash  # noqa: E402  (the kernel sources these counters were measured on: bench.py quotes them only for the same hash)
 
 
 def per_kernel(d, counter):
@@ -31,6 +35,7 @@ def main():
             out[tag]['hbm_bytes_per_launch'] = out[tag]['fetch_bytes_per_launch'] + out[tag]['write_bytes_per_launch']
     out['_note'] = ('rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `bench.py --steps 3 --warmup 1 --no-cpu-baseline '
                     '--no-kernel-timing`; FETCH_SIZE x2 (gfx950 wide-read correction), KB -> bytes; mean over all launches of the kernel')
+    out['source_sha256'] = source_hash()
     print(json.dumps(out, indent=1))
 
 
