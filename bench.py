@@ -217,7 +217,11 @@ def main():
     dp = DataParallel(model) if world > 1 else model
     # the reference's optimiser (common/utils.py:119-121: Adam, lr 1e-3, weight decay 1e-4); fused=True is the same update as
     # ONE kernel over all parameters instead of ~16 multi-tensor launches (host-side cost matters at small per-GPU batches)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4, fused=not args.plain_adam)
+    if args.plain_adam:
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
+    else:       # torch's fused Adam kernel behind cgc_net_amd.optim.Adam: the same update, the parameter lists built once
+        from cgc_net_amd.optim import Adam
+        opt = Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
     torch.autograd.set_multithreading_enabled(False)     # backward on the calling thread: no engine-thread hand-off per node
 
     def step(b):

@@ -16,6 +16,7 @@ PROTOTYPES = {
     'cgc_edge_renorm': [P, P, I, F, P, P],
     'cgc_csr_transpose_vals': [P, P, P, I, P, P],
     'cgc_csr_invdeg': [P, P, I, P, P],
+    'cgc_graph_build': [P, L, I, F, P, P, P, P, P, P, P, P, P, P, P],
     'cgc_spmm': [P, P, P, P, P, P, P, P, I, I, P],
     'cgc_spmm_graphs': [P, P, P, P, P, P, P, P, I, I, I, P, I, I, I, P],
     'cgc_spmm_graphs_ordered': [P, P, P, P, P, P, P, P, I, I, I, P, I, I, I, P, P],

@@ -291,3 +291,20 @@ extern "C" int cgc_csr_invdeg(const int* rowptr, const float* val, int n, float*
   CGC_RETURN_IF_LAUNCH_FAILED();
   return 0;
 }
+
+// Everything graph.BatchGraph holds, behind one call: cgc_csr_build, then (renorm_p >= 0) cgc_edge_renorm + cgc_csr_transpose_vals,
+// then cgc_csr_invdeg.  val / t_val may be NULL when renorm_p < 0.  Same kernels in the same order: one host call instead of four.
+extern "C" int cgc_graph_build(const int64_t* edge_index, int64_t E, int n, float renorm_p, int* rowptr, int* col, int* rowidx, int* t_rowptr,
+                               int* t_col, int* t_perm, float* val, float* t_val, float* inv_d, int* ws, cgc_stream_t stream) {
+  const bool renorm = renorm_p >= 0.f;
+  int rc = cgc_csr_build(edge_index, E, n, renorm ? 1 : 0, rowptr, col, rowidx, t_rowptr, t_col, t_perm, ws, stream);
+  if (rc != 0) return rc;
+  if (renorm) {
+    if (val == nullptr || t_val == nullptr) return CGC_EINVAL;
+    rc = cgc_edge_renorm(rowptr, col, n, renorm_p, val, stream);
+    if (rc != 0) return rc;
+    rc = cgc_csr_transpose_vals(t_rowptr, t_perm, val, n, t_val, stream);
+    if (rc != 0) return rc;
+  }
+  return cgc_csr_invdeg(rowptr, renorm ? val : nullptr, n, inv_d, stream);
+}

@@ -82,6 +82,14 @@ class BatchGraph(object):
 
     def _build(self, edge_index, renorm_p):
         K = kernels.get()
+        if hasattr(K, 'graph_build'):          # the library's composite entry point: one call, two allocations
+            s = K.graph_build(edge_index, self.n, None if renorm_p is None else float(renorm_p))
+            self.rowptr, self.col, self.rowidx = s['rowptr'], s['col'], s['rowidx']
+            self.t_rowptr, self.t_col, self.t_perm = s['t_rowptr'], s['t_col'], s['t_perm']
+            self.cap, self.bad_edges = s['cap'], s['bad_edges']
+            self.val, self.t_val, self.inv_d = s['val'], s['t_val'], s['inv_d']
+            self.renorm_p = None if renorm_p is None else float(renorm_p)
+            return
         s = K.csr_build(edge_index, self.n, add_diag=renorm_p is not None)
         self.rowptr, self.col, self.rowidx = s['rowptr'], s['col'], s['rowidx']
         self.t_rowptr, self.t_col, self.t_perm = s['t_rowptr'], s['t_col'], s['t_perm']

@@ -414,6 +414,34 @@ class HipKernels(KernelSpec):
         out['bad_edges'] = ws[o:o + 1]              # device-side count of dropped out-of-range edges (no sync here)
         return out
 
+    def graph_build(self, edge_index, n, renorm_p):
+        """csr_build (+ edge_renorm + csr_transpose_vals when renorm_p is not None) + csr_invdeg behind ONE library call, all
+        outputs carved out of two allocations.  Returns the dict of csr_build plus val / t_val (None without renorm) and inv_d."""
+        self._dev(edge_index)
+        edge_index = edge_index.to(torch.int64).contiguous()
+        E = edge_index.shape[1]
+        renorm = renorm_p is not None
+        cap = max(E + (n if renorm else 0), 1)
+        dev = edge_index.device
+        a = lambda k: -(-k // 64) * 64                    # 256-byte aligned pieces
+        sizes = [n + 1, n + 1, cap, cap, cap, cap, 3 * (n + 1) + 2 * cap]
+        ibuf = torch.empty(sum(a(k) for k in sizes), dtype=torch.int32, device=dev)
+        parts, o = [], 0
+        for k in sizes:
+            parts.append(ibuf[o:o + k])
+            o += a(k)
+        rowptr, t_rowptr, col, rowidx, t_col, t_perm, ws = parts
+        fbuf = torch.empty((2 * a(cap) if renorm else 0) + max(n, 1), dtype=torch.float32, device=dev)
+        val = fbuf[:cap] if renorm else None
+        t_val = fbuf[a(cap):a(cap) + cap] if renorm else None
+        inv_d = fbuf[2 * a(cap):] if renorm else fbuf
+        self._chk(self.lib.cgc_graph_build(_ptr(edge_index), ctypes.c_int64(E), n, ctypes.c_float(-1.0 if renorm_p is None else renorm_p),
+                                           _ptr(rowptr), _ptr(col), _ptr(rowidx), _ptr(t_rowptr), _ptr(t_col), _ptr(t_perm), _ptr(val),
+                                           _ptr(t_val), _ptr(inv_d), _ptr(ws), self._stream()), 'cgc_graph_build')
+        bo = int(self.lib.cgc_csr_bad_edges_offset(ctypes.c_int64(E), n, int(renorm)))
+        return dict(rowptr=rowptr, t_rowptr=t_rowptr, col=col, rowidx=rowidx, t_col=t_col, t_perm=t_perm, cap=E + (n if renorm else 0),
+                    bad_edges=ws[bo:bo + 1], val=val, t_val=t_val, inv_d=inv_d)
+
     def collate(self, x, mean, std, gptr, num_graphs, batch_out, edge_index, eptr):
         self._dev(x, mean, std, gptr, batch_out, edge_index, eptr)
         assert x.is_contiguous() and x.dtype == torch.float32

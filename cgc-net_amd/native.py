@@ -108,7 +108,39 @@ def _f32ok(*ts):
     return all(t is None or (t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda) for t in ts)
 
 
-def describe(enc, level, emb, pool, jk, B, n, rows_per_graph, nmax, npad, fin, count):
+def prepared(enc, level, emb, pool, jk, fin):
+    """Everything about a level that does not change from batch to batch: whether the sequencer covers it, a LevelDesc template,
+    the parameter tensors in the Function's order and the pointer structs -- ~0.4 ms of Python per step when it was redone for
+    every call.  Cached on the encoder and keyed by what would invalidate it: the parameter objects and their storage, the mode
+    flags (train / eval, norm_adj), BatchNorm's eps / momentum."""
+    blocks = [emb] + ([pool] if pool is not None else [])
+    if any(not b.mean_aggregation or b.add_loop for b in blocks) or (jk is not None and jk.mode != 'lstm'):
+        return None                                   # (GIN blocks have no .weight to list)
+    params = _block_tensors(emb) + (_block_tensors(pool) if pool is not None else []) + (_jk_tensors(jk) if jk is not None else [])
+    bn_cfg = tuple((getattr(b, 'bn%d' % k).eps, getattr(b, 'bn%d' % k).momentum, getattr(b, 'bn%d' % k).track_running_stats)
+                   for b in blocks if b.use_bn for k in (1, 2, 3))
+    key = (tuple(id(t) for t in params), tuple(t.data_ptr() for t in params if t is not None), emb.training, enc.norm_adj, fin, bn_cfg,
+           emb.activation)
+    cache = enc.__dict__.setdefault('_native_prepared', {})
+    hit = cache.get(level)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    d = describe(enc, level, emb, pool, jk, 1, 1, 1 if level >= 2 else 0, 1, 1, fin, 1.0, check_lib=False)
+    res = None
+    if d is not None:
+        res = dict(template=bytes(d), params=params, structs=(_block_params(emb), _block_params(pool), _jk_params(jk)))
+    cache[level] = (key, res)
+    return res
+
+
+def describe_from(prep, level, B, n, rows_per_graph, nmax, npad, count):
+    """The batch's LevelDesc from the cached template, or None when the library refuses the dimensions."""
+    d = LevelDesc.from_buffer_copy(prep['template'])
+    d.level, d.B, d.n, d.rows_per_graph, d.nmax, d.npad, d.count = level, B, n, rows_per_graph, nmax, npad, float(count)
+    return d if _lib().cgc_level_supported(C.byref(d)) else None
+
+
+def describe(enc, level, emb, pool, jk, B, n, rows_per_graph, nmax, npad, fin, count, check_lib=True):
     """LevelDesc for one level, or None when the sequencer does not cover the configuration (the caller then takes the
     per-operator path)."""
     blocks = [emb] + ([pool] if pool is not None else [])
@@ -148,12 +180,31 @@ def describe(enc, level, emb, pool, jk, B, n, rows_per_graph, nmax, npad, fin, c
     d.count = float(count)
     if emb.gcn1.in_channels != fin or (pool is not None and pool.gcn1.in_channels != fin):
         return None
-    if not _lib().cgc_level_supported(C.byref(d)):
+    if check_lib and not _lib().cgc_level_supported(C.byref(d)):
         return None
     return d
 
 
 RENORM_P = 0.4      # model/network.py:260,271,280
+
+
+_SIZES = {}
+
+
+def _sizes(d):
+    """(saved floats, scratch floats, gradient layout) of a LevelDesc; memoised on the descriptor's bytes (bounded: the level-1
+    descriptor changes with every batch's node count)."""
+    key = bytes(d)
+    hit = _SIZES.get(key)
+    if hit is None:
+        lib = _lib()
+        lay = GradLayout()
+        lib.cgc_level_grad_layout_of(C.byref(d), C.byref(lay))
+        hit = (int(lib.cgc_level_saved_floats(C.byref(d))), int(lib.cgc_level_scratch_floats(C.byref(d))), lay)
+        if len(_SIZES) > 256:
+            _SIZES.clear()
+        _SIZES[key] = hit
+    return hit
 
 
 class _Level(Function):
@@ -166,13 +217,14 @@ class _Level(Function):
         dev = x_in.device
         kernels.get()._dev(x_in, A_in, gptr)
         stream = kernels.get()._stream()
-        saved = torch.empty(int(lib.cgc_level_saved_floats(C.byref(d))), dtype=torch.float32, device=dev)
-        scratch = torch.empty(int(lib.cgc_level_scratch_floats(C.byref(d))), dtype=torch.float32, device=dev)
+        n_saved, n_scratch, _ = _sizes(d)
+        saved = torch.empty(n_saved, dtype=torch.float32, device=dev)
+        scratch = torch.empty(n_scratch, dtype=torch.float32, device=dev)
         D = d.H if d.jk else 2 * d.H + d.E
         readout = torch.empty(d.B, D, dtype=torch.float32, device=dev)
         x_out = torch.empty(d.B, d.C, D, dtype=torch.float32, device=dev) if d.C else None
         A_out = torch.empty(d.B, d.C, d.C, dtype=torch.float32, device=dev) if d.C else None
-        pe, pp, pj = _block_params(emb), _block_params(pool), _jk_params(jk)
+        pe, pp, pj = cfg['structs'] if cfg.get('structs') is not None else (_block_params(emb), _block_params(pool), _jk_params(jk))
         gs = Graph()
         if g is not None:
             gs.rowptr, gs.col, gs.t_rowptr, gs.t_col = _p(g.rowptr), _p(g.col), _p(g.t_rowptr), _p(g.t_col)
@@ -202,10 +254,9 @@ class _Level(Function):
         pe, pp, pj, gs = ctx.structs
         dev = saved.device
         stream = kernels.get()._stream()
-        lay = GradLayout()
-        lib.cgc_level_grad_layout_of(C.byref(d), C.byref(lay))
+        _, n_scratch, lay = _sizes(d)
         grads = torch.empty(int(lay.total), dtype=torch.float32, device=dev)
-        scratch = torch.empty(int(lib.cgc_level_scratch_floats(C.byref(d))), dtype=torch.float32, device=dev)
+        scratch = torch.empty(n_scratch, dtype=torch.float32, device=dev)
         D = d.H if d.jk else 2 * d.H + d.E
         d_readout = d_readout.contiguous().float()
         if d.C:
@@ -253,10 +304,11 @@ def _param_offsets(d, lay):
     return offs
 
 
-def level(enc, desc, emb, pool, jk, g, gptr, x_in, A_in, assign=None):
+def level(enc, desc, emb, pool, jk, g, gptr, x_in, A_in, assign=None, prep=None):
     """Run one level through the sequencer.  Returns (readout, x_out, A_out) (x_out / A_out None at the last level)."""
-    cfg = dict(desc=desc, emb=emb, pool=pool, jk=jk, graph=g, gptr=gptr, assign=assign)
-    params = _block_tensors(emb) + (_block_tensors(pool) if pool is not None else []) + (_jk_tensors(jk) if jk is not None else [])
+    cfg = dict(desc=desc, emb=emb, pool=pool, jk=jk, graph=g, gptr=gptr, assign=assign, structs=prep['structs'] if prep else None)
+    params = prep['params'] if prep else (_block_tensors(emb) + (_block_tensors(pool) if pool is not None else []) +
+                                          (_jk_tensors(jk) if jk is not None else []))
     out = _Level.apply(cfg, x_in, A_in, *params)
     if desc.C:
         return out

@@ -389,18 +389,22 @@ class SoftPoolingGcnEncoder(nn.Module):
         emb = getattr(self, 'GCN_embed_%d' % level)
         pool = getattr(self, 'GCN_pool_%d' % level) if level < 3 else None
         jk = getattr(self, 'jk%d' % level) if self.jk else None
+        fin = x.shape[-1]
+        prep = native.prepared(self, level, emb, pool, jk, fin)
+        if prep is None:
+            return None
         if level == 1:
-            desc = native.describe(self, 1, emb, pool, jk, g.B, g.n, 0, g.nmax, g.npad, x.shape[1], g.padded_rows)
+            desc = native.describe_from(prep, 1, g.B, g.n, 0, g.nmax, g.npad, g.padded_rows)
             gptr = g.gptr
         else:
-            B, Cn, fin = x.shape
-            desc = native.describe(self, level, emb, pool, jk, B, B * Cn, Cn, 0, 0, fin, B * Cn)
+            B, Cn, _ = x.shape
+            desc = native.describe_from(prep, level, B, B * Cn, Cn, 0, 0, B * Cn)
             gptr = uniform_ptr(B, Cn, x.device)
             x, adj = ops._f32c(x).view(B * Cn, fin), ops._f32c(adj)
         if desc is None:
             return None
         assign = [] if (self.collect_assign and pool is not None) else None
-        out = native.level(self, desc, emb, pool, jk, g, gptr, x.contiguous(), adj, assign)
+        out = native.level(self, desc, emb, pool, jk, g, gptr, x.contiguous(), adj, assign, prep)
         if assign:
             s = assign[0]
             self.assign_matrix.append(self._pad_assign(s, g) if level == 1 else s.view(desc.B, desc.rows_per_graph, -1))

@@ -91,6 +91,12 @@ int cgc_csr_transpose_vals(const int* t_rowptr, const int* t_perm, const float* 
 /* out[i] = 1/max(rowsum_i, 1): the clamp(min=1) mean divisor of DenseSAGEConv (PyG 1.2.1; model/network.py:114). val may be NULL (=1). */
 int cgc_csr_invdeg(const int* rowptr, const float* val, int n, float* out, cgc_stream_t stream);
 
+/* The four calls above as one (what graph.BatchGraph needs per batch): CSR + transpose, then -- renorm_p >= 0 -- the edge weights of
+ * _re_norm_adj in both slot orders (the CSR then holds its diagonal: cap = E + n), then the mean divisor.  val / t_val: [cap] or NULL
+ * when renorm_p < 0.  ws as cgc_csr_build. */
+int cgc_graph_build(const int64_t* edge_index, int64_t E, int n, float renorm_p, int* rowptr, int* col, int* rowidx, int* t_rowptr,
+                    int* t_col, int* t_perm, float* val, float* t_val, float* inv_d, int* ws, cgc_stream_t stream);
+
 /* ---- A4 / A8: neighbour aggregation.  Replaces torch.matmul(adj, x) inside DenseSAGEConv
  * (model/network.py:114-116) and the inner product of (S^T A) S (model/network.py:207):
  * out[i,:] = post[i] * sum_{k in row i} w_k * pre[col[k]] * x[col[k],:],  w_k = val[perm[k]] | val[k] | 1.

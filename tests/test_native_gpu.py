@@ -226,3 +226,55 @@ def test_other_hidden_dims_stay_on_the_fused_jk_kernels(hidden):
     gr = dict(ref.named_parameters())
     for k, p in model.named_parameters():
         assert rel(p.grad, gr[k].grad) < 5e-4, (k, rel(p.grad, gr[k].grad))
+
+
+def test_cached_list_adam_equals_torch_fused_adam():
+    """cgc_net_amd.optim.Adam = torch.optim.Adam(fused=True) with the parameter lists built once: bitwise the same parameters and
+    optimiser state over steps, an LR change included."""
+    from cgc_net_amd.optim import Adam
+    ds = SyntheticCellGraphs(4, 200, num_features=16, base_seed=9)
+    b = Batch.from_data_list([ds[i] for i in range(4)]).to(DEV)
+    a, c = _pair((400, 16, 20, 20, True, True, 20, 3, 0.1, [50]), dict(concat=True, load_data_sparse=True, norm_adj=True, jk=True))
+    c.native = True
+    oa, oc = Adam(a.parameters(), lr=1e-3, weight_decay=1e-4), torch.optim.Adam(c.parameters(), lr=1e-3, weight_decay=1e-4, fused=True)
+    for step in range(5):
+        if step == 3:
+            for o in (oa, oc):
+                o.param_groups[0]['lr'] = 5e-4
+        for m, o in ((a, oa), (c, oc)):
+            _, loss = m(b)
+            o.zero_grad()
+            loss.backward()
+            o.step()
+    for (k, p), (_, q) in zip(a.state_dict().items(), c.state_dict().items()):
+        assert torch.equal(p, q), k
+    sa, sc = oa.state_dict()['state'], oc.state_dict()['state']
+    for i in sa:
+        for key in ('step', 'exp_avg', 'exp_avg_sq'):
+            assert torch.equal(sa[i][key], sc[i][key]), (i, key)
+
+
+def test_composite_graph_build_equals_the_four_calls():
+    from cgc_net_amd import kernels
+    K = kernels.get()
+    ds = SyntheticCellGraphs(3, 400, num_features=16, base_seed=4)
+    b = Batch.from_data_list([ds[i] for i in range(3)]).to(DEV)
+    n = b.x.shape[0]
+    for p in (None, 0.4):
+        one = K.graph_build(b.edge_index, n, p)
+        s = K.csr_build(b.edge_index, n, add_diag=p is not None)
+        nnz = int(s['rowptr'][n])
+        for k in ('rowptr', 't_rowptr'):
+            assert torch.equal(one[k], s[k]), k
+        for k in ('col', 'rowidx', 't_col', 't_perm'):
+            assert torch.equal(one[k][:nnz], s[k][:nnz]), k
+        val = t_val = None
+        if p is not None:
+            val = torch.empty(s['cap'], device=DEV)
+            K.edge_renorm(s['rowptr'], s['col'], n, p, val)
+            t_val = torch.empty_like(val)
+            K.csr_transpose_vals(s['t_rowptr'], s['t_perm'], val, n, t_val)
+            assert torch.equal(one['val'][:nnz], val[:nnz]) and torch.equal(one['t_val'][:nnz], t_val[:nnz])
+        inv = torch.empty(n, device=DEV)
+        K.csr_invdeg(s['rowptr'], val, n, inv)
+        assert torch.equal(one['inv_d'][:n], inv) and int(one['bad_edges']) == 0
