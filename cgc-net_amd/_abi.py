@@ -53,6 +53,7 @@ PROTOTYPES = {
     'cgc_jk_lstm_bwd': [P, P, I, I, I, P, P, P, P, P, P, P, P, P, P],
     'cgc_jk_bwd_ws_floats': [I],
     'cgc_jk_lstm_bwd_params': [P, P, I, I, I, P, P, P, P, P, P, P, P, P],
+    'cgc_jk_lstm_bwd_flat': [P, P, I, I, I, P, P, P, P, P, P, P, P, P],
     'cgc_jk_param_grad_floats': [I],
     'cgc_jk_unpack_param_grads': [P, I, P, P],
     'cgc_dense_rownorm_fwd': [P, I, I, P, P, P, P],

@@ -364,10 +364,10 @@ int layer_bwd_pair(const Ctx& c, const cgc_level_desc& d, const LayerP* p, const
 // ------------------------------------------------------------------------------------------------ a level
 struct Level {
   const cgc_level_desc& d;
-  int n, B, R, fin, H, E, AH, C, D, D3, wp, ldC, ldP, ldW, ftot, npad_jk, seg_nmax;
+  int n, B, R, fin, H, E, AH, C, D, D3, wp, wt, ldp, ldC, ldP, ldW, ftot, npad_jk, seg_nmax;
   bool dense, pool, tall;
   // saved arena
-  float *At, *An, *invd, *ge1, *agg0, *pair[2], *aggk[2], *hp3, *cat_e, *HS, *CS, *jk_out, *x12, *S, *P;
+  float *At, *An, *invd, *ge1, *agg0, *pair[2], *xcat, *aggk[2], *hp3, *cat_e, *HS, *CS, *jk_out, *x12, *S, *P;
   int* arg;
   LayerS L[6];
   // gradient layout
@@ -380,6 +380,10 @@ struct Level {
     D3 = 2 * H + E;
     D = d.jk ? H : D3;
     wp = pool ? H + AH : H;
+    // dense levels: the operands of the deferred adjacency gradient [pair 2 | pair 1 | x] live side by side in ONE buffer (row
+    // stride wt), and so do the gradients [d agg 2 | d agg 1 | d agg 0] in the backward: that product needs no concatenation
+    wt = 2 * wp + fin;
+    ldp = dense ? wt : wp;
     ldC = pool ? wide_ld(C) : 0;
     ldP = dense ? pad4_ld(C) : ldC;
     ftot = 2 * AH + C;
@@ -399,8 +403,9 @@ struct Level {
       ge1 = a.f(n);
     }
     agg0 = a.f((size_t)n * fin);
+    xcat = dense ? a.f((size_t)n * wt) : nullptr;
     for (int k = 0; k < 2; ++k) {
-      pair[k] = a.f((size_t)n * wp);
+      pair[k] = dense ? xcat + (1 - k) * wp : a.f((size_t)n * wp);
       aggk[k] = a.f((size_t)n * wp);
     }
     hp3 = pool ? a.f((size_t)n * ldC) : nullptr;
@@ -471,20 +476,20 @@ struct Level {
 };
 
 // neighbour aggregation of a level and its transpose: level 1 on the CSR (ops._Aggregate), levels 2-3 A_norm @ h (ops._BMatmul)
-int aggregate(const Ctx& c, const Level& L, const cgc_graph* g, const int* gptr, const float* h, int w, float* out) {
+int aggregate(const Ctx& c, const Level& L, const cgc_graph* g, const int* gptr, const float* h, int ldh, int w, float* out) {
   if (!L.dense) {
     CALL(cgc_spmm_graphs_ordered(g->rowptr, g->col, nullptr, g->val, nullptr, g->inv_d, h, out, L.n, w, w, gptr, L.B, L.d.nmax, 0, nullptr, c.s));
     return 0;
   }
-  return bgemm(c, T3{L.An, L.B, L.R, L.R, L.R}, T3{const_cast<float*>(h), L.B, L.R, w, w}, T3{out, L.B, L.R, w, w}, 0, 0);
+  return bgemm(c, T3{L.An, L.B, L.R, L.R, L.R}, T3{const_cast<float*>(h), L.B, L.R, w, ldh}, T3{out, L.B, L.R, w, w}, 0, 0);
 }
-int aggregate_t(const Ctx& c, const Level& L, const cgc_graph* g, const int* gptr, const float* dy, int w, float* dx) {
+int aggregate_t(const Ctx& c, const Level& L, const cgc_graph* g, const int* gptr, const float* dy, int ldy, int w, float* dx) {
   if (!L.dense) {
     CALL(cgc_spmm_graphs_ordered(g->t_rowptr, g->t_col, nullptr, g->t_val, g->inv_d, nullptr, dy, dx, L.n, w, w, gptr, L.B, L.d.nmax, 0, nullptr,
                                  c.s));
     return 0;
   }
-  return bgemm(c, T3{L.An, L.B, L.R, L.R, L.R}, T3{const_cast<float*>(dy), L.B, L.R, w, w}, T3{dx, L.B, L.R, w, w}, 1, 0);
+  return bgemm(c, T3{L.An, L.B, L.R, L.R, L.R}, T3{const_cast<float*>(dy), L.B, L.R, w, ldy}, T3{dx, L.B, L.R, w, w}, 1, 0);
 }
 
 int level_fwd(const Ctx& c, Level& L, const cgc_block_params* emb, const cgc_block_params* pl, const cgc_jk_params* jk, const cgc_graph* g,
@@ -493,7 +498,12 @@ int level_fwd(const Ctx& c, Level& L, const cgc_block_params* emb, const cgc_blo
   const int n = L.n, H = L.H, AH = L.AH, wp = L.wp, C = L.C;
   if (L.dense)
     CALL(cgc_adj_prep_fwd(A_in, n, L.R, d.renorm ? d.renorm_p : -1.f, L.At, L.An, L.invd, L.ge1, c.s));
-  TRY(aggregate(c, L, g, gptr, x_in, L.fin, L.agg0));
+  TRY(aggregate(c, L, g, gptr, x_in, L.fin, L.fin, L.agg0));
+  if (L.dense) {      // the level's input next to the pair buffers (third operand block of the deferred adjacency gradient)
+    const float* s1[1] = {x_in};
+    const int l1[1] = {L.fin}, w1[1] = {L.fin};
+    CALL(cgc_cat_cols(L.xcat + 2 * wp, L.wt, n, 1, s1, l1, w1, 0, c.s));
+  }
   // the two blocks layer by layer: both read the SAME aggregation (network.run_blocks_paired)
   for (int k = 0; k < 3; ++k) {
     const float* ain = k == 0 ? L.agg0 : L.aggk[k - 1];
@@ -507,24 +517,24 @@ int level_fwd(const Ctx& c, Level& L, const cgc_block_params* emb, const cgc_blo
       float* yy[2] = {L.pair[k], L.pair[k] + H};
       float* y2[2] = {L.cat_e + k * H, L.x12 + k * AH};
       const int l2[2] = {L.D3, 2 * AH};
-      TRY(layer_fwd_pair(c, d, pp, ss, ag, lda, n, L.width_in(k), H, yy, wp, y2, l2));
-      if (k < 2) TRY(aggregate(c, L, g, gptr, L.pair[k], wp, L.aggk[k]));
+      TRY(layer_fwd_pair(c, d, pp, ss, ag, lda, n, L.width_in(k), H, yy, L.ldp, y2, l2));
+      if (k < 2) TRY(aggregate(c, L, g, gptr, L.pair[k], L.ldp, wp, L.aggk[k]));
       continue;
     }
     if (k < 2)
-      TRY(layer_fwd(c, d, layer_params(d, emb, k, k), L.L[k], ain, lda, n, L.width_in(k), L.width_out(k), L.pair[k], wp, L.cat_e + k * H,
+      TRY(layer_fwd(c, d, layer_params(d, emb, k, k), L.L[k], ain, lda, n, L.width_in(k), L.width_out(k), L.pair[k], L.ldp, L.cat_e + k * H,
                     L.D3));
     else
       TRY(layer_fwd(c, d, layer_params(d, emb, k, k), L.L[k], ain, lda, n, L.width_in(k), L.width_out(k), L.cat_e + 2 * H, L.D3));
     if (L.pool) {
       const float* ainp = k == 0 ? ain : ain + H;
       if (k < 2)
-        TRY(layer_fwd(c, d, layer_params(d, pl, k, 3 + k), L.L[3 + k], ainp, lda, n, L.width_in(3 + k), L.width_out(3 + k), L.pair[k] + H, wp,
+        TRY(layer_fwd(c, d, layer_params(d, pl, k, 3 + k), L.L[3 + k], ainp, lda, n, L.width_in(3 + k), L.width_out(3 + k), L.pair[k] + H, L.ldp,
                       L.x12 + k * AH, 2 * AH));
       else
         TRY(layer_fwd(c, d, layer_params(d, pl, k, 3 + k), L.L[3 + k], ainp, lda, n, L.width_in(3 + k), L.width_out(3 + k), L.hp3, L.ldC));
     }
-    if (k < 2) TRY(aggregate(c, L, g, gptr, L.pair[k], wp, L.aggk[k]));
+    if (k < 2) TRY(aggregate(c, L, g, gptr, L.pair[k], L.ldp, wp, L.aggk[k]));
   }
   if (d.jk) CALL(cgc_jk_lstm_fwd(L.cat_e, n, L.npad_jk, H, jk->lstm, jk->w_att, jk->b_att, L.jk_out, L.HS, L.CS, c.s));
   CALL(cgc_segment_max_fwd(L.embed(), gptr, L.B, L.D, L.seg_nmax, readout, L.arg, c.s));
@@ -578,24 +588,23 @@ int level_bwd_blocks(const Ctx& c, Level& L, const cgc_block_params* emb, const 
   auto sums = [&](int k) { return grads + L.gl.W[k] + (int64_t)L.width_in(k) * L.width_out(k) + L.width_out(k); };
   float* d_cat = d_embed;                                   // [n, 2H + E]: gradient of cat[x1, x2, x3] of the embedding block
   if (d.jk) {
-    const int Hh = 3 * H / 2, ng = 4 * Hh + 1, ni = H + 2 * Hh + 1;
     d_cat = sc.f((size_t)n * D3);
     const size_t m = sc.mark();
-    float* G = sc.f((size_t)2 * ng * ni);
     float* ws = sc.f((size_t)cgc_jk_bwd_ws_floats(H));
-    CALL(cgc_jk_lstm_bwd_params(L.cat_e, d_embed, n, L.npad_jk, H, jk->lstm, jk->w_att, jk->b_att, L.HS, L.CS, d_cat, G, ws, c.s));
-    CALL(cgc_jk_unpack_param_grads(G, H, grads + L.gl.jk, c.s));
+    CALL(cgc_jk_lstm_bwd_flat(L.cat_e, d_embed, n, L.npad_jk, H, jk->lstm, jk->w_att, jk->b_att, L.HS, L.CS, d_cat, grads + L.gl.jk, ws, c.s));
     sc.release(m);
   }
   // ---- layer 3 -> gradient of the aggregation that fed it: [d agg_e3 | d agg_p3]
   float* dagg[2];                                           // dagg[k]: gradient of aggk[k] = A [pair k]
-  dagg[1] = dagg1 != nullptr ? dagg1 : sc.f((size_t)n * wp);
-  TRY(layer_bwd(c, d, layer_params(d, emb, 2, 2), L.L[2], L.aggk[1], wp, n, H, L.E, d_cat + 2 * H, D3, dagg[1], wp, grads + L.gl.W[2], sums(2)));
+  const int ldg = L.ldp;                                    // row stride of the d agg blocks (dense levels: one [n, wt] buffer)
+  float* const gcat = dagg1 != nullptr ? dagg1 : sc.f((size_t)n * ldg);
+  dagg[1] = gcat;
+  TRY(layer_bwd(c, d, layer_params(d, emb, 2, 2), L.L[2], L.aggk[1], wp, n, H, L.E, d_cat + 2 * H, D3, dagg[1], ldg, grads + L.gl.W[2], sums(2)));
   float* dpair = nullptr;
   for (int k = 1; k >= 0; --k) {
     // gradient of pair[k] = [he_{k+1} | hp_{k+1}]: through the aggregation, plus what the concatenations (embedding cat, x12) send
     dpair = sc.f((size_t)n * wp);
-    TRY(aggregate_t(c, L, g, gptr, dagg[k], wp, dpair));
+    TRY(aggregate_t(c, L, g, gptr, dagg[k], ldg, wp, dpair));
     if (L.pool) TRY(cat2(c, dpair, wp, n, d_cat + k * H, D3, H, dx12 + k * AH, 2 * AH, AH, 1));
     else TRY(add1(c, dpair, wp, n, d_cat + k * H, D3, H));
     // layer k+1 of both blocks (slot k)
@@ -604,12 +613,19 @@ int level_bwd_blocks(const Ctx& c, Level& L, const cgc_block_params* emb, const 
     const float* ain = first ? L.agg0 : L.aggk[k - 1];
     const int lda = first ? fin : wp;
     const int fi_e = L.width_in(k), fi_p = L.width_in(3 + k);
-    // second layers: both blocks write their halves of d aggk[0] in place; first layers (dense levels): two [n, fin] gradients
-    float* de = !need_in ? nullptr : first ? sc.f((size_t)n * fi_e) : (dagg[0] = sc.f((size_t)n * wp));
-    const int ldde = first ? fi_e : wp;
-    float* dp = nullptr;
+    // where the input gradients of this pair of layers go (row stride ldd): second layers -> the two halves of d aggk[0]; first
+    // layers (dense levels only) -> the embedding block's into the d agg_0 block, the assignment block's into a buffer of the same
+    // stride, added afterwards (both read the same aggregation A x)
+    float *de = nullptr, *dp = nullptr;
+    int ldd = ldg;
+    if (need_in && !first) {
+      de = dagg[0] = L.dense ? gcat + wp : sc.f((size_t)n * wp);
+      dp = de + H;
+    } else if (need_in) {
+      de = gcat + 2 * wp;
+      dp = L.pool ? sc.f((size_t)n * ldg) : nullptr;
+    }
     if (L.pool && pairable(fi_e, H, fi_p, AH)) {
-      dp = !need_in ? nullptr : first ? sc.f((size_t)n * fi_p) : de + H;
       const LayerP pp[2] = {layer_params(d, emb, k, k), layer_params(d, pl, k, 3 + k)};
       const LayerS ss[2] = {L.L[k], L.L[3 + k]};
       const float* ag[2] = {ain, first ? ain : ain + H};
@@ -617,28 +633,21 @@ int level_bwd_blocks(const Ctx& c, Level& L, const cgc_block_params* emb, const 
       float* dg[2] = {de, dp};
       float* dw[2] = {grads + L.gl.W[k], grads + L.gl.W[3 + k]};
       float* sm[2] = {sums(k), sums(3 + k)};
-      TRY(layer_bwd_pair(c, d, pp, ss, ag, lda, n, fi_e, H, dyy, wp, dg, ldde, dw, sm));
+      TRY(layer_bwd_pair(c, d, pp, ss, ag, lda, n, fi_e, H, dyy, wp, dg, ldd, dw, sm));
     } else {
-      TRY(layer_bwd(c, d, layer_params(d, emb, k, k), L.L[k], ain, lda, n, fi_e, H, dpair, wp, de, ldde, grads + L.gl.W[k], sums(k)));
-      if (L.pool) {
-        dp = !need_in ? nullptr : first ? sc.f((size_t)n * fi_p) : de + H;
-        TRY(layer_bwd(c, d, layer_params(d, pl, k, 3 + k), L.L[3 + k], first ? ain : ain + H, lda, n, fi_p, AH, dpair + H, wp, dp,
-                      first ? fi_p : wp, grads + L.gl.W[3 + k], sums(3 + k)));
-      }
+      TRY(layer_bwd(c, d, layer_params(d, emb, k, k), L.L[k], ain, lda, n, fi_e, H, dpair, wp, de, ldd, grads + L.gl.W[k], sums(k)));
+      if (L.pool)
+        TRY(layer_bwd(c, d, layer_params(d, pl, k, 3 + k), L.L[3 + k], first ? ain : ain + H, lda, n, fi_p, AH, dpair + H, wp, dp, ldd,
+                      grads + L.gl.W[3 + k], sums(3 + k)));
     }
     if (first && L.dense) {
-      // both first layers read the same aggregation A x: their gradients add up
-      if (L.pool) TRY(add1(c, de, fin, n, dp, fin, fin));
-      TRY(aggregate_t(c, L, g, gptr, de, fin, d_x_in));
+      if (L.pool) TRY(add1(c, de, ldg, n, dp, ldg, fin));
+      TRY(aggregate_t(c, L, g, gptr, de, ldg, fin, d_x_in));
       // deferred, batched gradient of the row-normalised adjacency (ops.SharedGrad): every aggregation A h_i contributed
-      // (d agg_i, h_i); ONE product [d agg_2 | d agg_1 | d agg_0] [h_2 | h_1 | h_0]^T writes the [B, C, C] gradient once
-      const int wt = 2 * wp + fin;
-      float* gcat = sc.f((size_t)n * wt);
-      float* xcat = sc.f((size_t)n * wt);
-      TRY(cat3(c, gcat, wt, n, dagg[1], wp, wp, dagg[0], wp, wp, de, fin, fin));
-      TRY(cat3(c, xcat, wt, n, L.pair[1], wp, wp, L.pair[0], wp, wp, x_in, fin, fin));
+      // (d agg_i, h_i); ONE product [d agg_2 | d agg_1 | d agg_0] [h_2 | h_1 | h_0]^T writes the [B, C, C] gradient once.  Both
+      // operands were laid out side by side when they were produced: no concatenation here.
       float* dAn = sc.f((size_t)n * R);
-      TRY(bgemm(c, T3{gcat, B, R, wt, wt}, T3{xcat, B, R, wt, wt}, T3{dAn, B, R, R, R}, 0, 1));
+      TRY(bgemm(c, T3{gcat, B, R, L.wt, L.wt}, T3{L.xcat, B, R, L.wt, L.wt}, T3{dAn, B, R, R, R}, 0, 1));
       CALL(cgc_adj_prep_bwd(A_in, L.An, L.invd, L.ge1, dAn, gAt, n, R, d.renorm ? d.renorm_p : -1.f, d_A_in, c.s));
     }
   }
@@ -712,8 +721,10 @@ int level_bwd(const Ctx& c, Level& L, const cgc_block_params* emb, const cgc_blo
     }
     // third layer of the assignment block, from d hp3
     (void)m0;
-    float* dagg1 = sc.f((size_t)n * wp);       // gradient of the aggregation feeding the third layers: [embedding part | assignment part]
-    TRY(layer_bwd(c, d, layer_params(d, pl, 2, 5), L.L[5], L.aggk[1] + H, wp, n, AH, C, dy3, L.ldC, dagg1 + H, wp, grads + L.gl.W[5],
+    // gradient of the aggregation feeding the third layers, [embedding part | assignment part]; on dense levels the first block of
+    // [d agg 2 | d agg 1 | d agg 0] (row stride ldp)
+    float* dagg1 = sc.f((size_t)n * L.ldp);
+    TRY(layer_bwd(c, d, layer_params(d, pl, 2, 5), L.L[5], L.aggk[1] + H, wp, n, AH, C, dy3, L.ldC, dagg1 + H, L.ldp, grads + L.gl.W[5],
                   grads + L.gl.W[5] + (int64_t)AH * C + C));
     // keep: dagg1, dx12, gAt.  (dy3, dz are not needed any more but sit below dagg1 on the stack; they are simply left there.)
     return level_bwd_blocks(c, L, emb, pl, jk, g, gptr, x_in, A_in, d_embed, dx12, dagg1, gAt, grads, d_x_in, d_A_in);

@@ -387,6 +387,17 @@ extern "C" int cgc_jk_lstm_bwd_params(const float* xs, const float* dout, int n,
   return jk_mfma_bwd_params(xs, dout, n, npad, C, w, HS, CS, dxs, G, ws, as_stream(stream));
 }
 
+// cgc_jk_lstm_bwd_params + cgc_jk_unpack_param_grads in one: flat = cgc_jk_param_grad_floats(C) floats in parameter order (no G).
+extern "C" int cgc_jk_lstm_bwd_flat(const float* xs, const float* dout, int n, int npad, int C, const float* const* lstm,
+                                    const float* w_att, const float* b_att, const float* HS, const float* CS, float* dxs,
+                                    float* flat, float* ws, cgc_stream_t stream) {
+  if (n <= 0) return 0;
+  if (npad < n) return CGC_EINVAL;
+  JkWeights w;
+  fill_weights(w, lstm, w_att, b_att);
+  return jk_mfma_bwd_flat(xs, dout, n, npad, C, w, HS, CS, dxs, flat, ws, as_stream(stream));
+}
+
 // G [2][4H+1][C+2H+1] -> the parameter gradients of DenseJK in ONE contiguous buffer, in torch.nn.LSTM / nn.Linear order:
 // per direction d: dW_ih [4H,C] | dW_hh [4H,H] | db_ih [4H] | db_hh [4H] (= db_ih), then d att.weight [2H] and d att.bias [1].
 // Every gradient is then a contiguous slice that autograd can hand to the parameter as it is -- returned as strided windows of

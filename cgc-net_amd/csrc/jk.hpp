@@ -29,3 +29,6 @@ int jk_mfma_bwd(const float* xs, const float* dout, int n, int npad, int C, cons
 int64_t jk_mfma_bwd_ws_floats(int C);
 int jk_mfma_bwd_params(const float* xs, const float* dout, int n, int npad, int C, const JkWeights& w, const float* HS,
                        const float* CS, float* dxs, float* G, float* ws, hipStream_t st);
+// the same with the gradients written straight into the flat parameter-order buffer of cgc_jk_unpack_param_grads
+int jk_mfma_bwd_flat(const float* xs, const float* dout, int n, int npad, int C, const JkWeights& w, const float* HS, const float* CS,
+                     float* dxs, float* flat, float* ws, hipStream_t st);

@@ -596,6 +596,47 @@ __global__ void k_jk_pg_finish(const float* __restrict__ tmp, int P2, float* __r
   }
 }
 
+// the same second stage writing the parameter gradients straight into the flat buffer of cgc_jk_unpack_param_grads (per direction
+// dW_ih [4H,C] | dW_hh [4H,H] | db_ih [4H] | db_hh [4H], then d att.weight [2H], d att.bias): no G, no memset, no unpack kernel.
+// Same summation order per element as k_jk_pg_finish.
+template <int C>
+__global__ void k_jk_pg_finish_flat(const float* __restrict__ tmp, int P2, float* __restrict__ flat) {
+  constexpr int H = JkM<C>::H, per = JkM<C>::PG_FLOATS;
+  constexpr int per_dir = 4 * H * C + 4 * H * H + 8 * H, total = 2 * per_dir + 2 * H + 1;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int d, row = 0, col = 0, att = -1;               // G coordinates of flat element i: (d, row = g*H + j, col) or an attention entry
+  if (i < 2 * per_dir) {
+    d = i / per_dir;
+    int e = i - d * per_dir;
+    if (e < 4 * H * C) { row = e / C; col = e % C; }
+    else if ((e -= 4 * H * C) < 4 * H * H) { row = e / H; col = C + e % H; }
+    else { e -= 4 * H * H; row = e % (4 * H); col = C + H; }
+  } else {
+    const int e = i - 2 * per_dir;
+    if (e < 2 * H) { d = e / H; att = e % H; }
+    else { d = 0; att = H; }                        // attention bias
+  }
+  const float* src = tmp + (size_t)d * P2 * per;
+  float a = 0.f;
+  if (att < 0) {
+    const int g = row / H, j = row - g * H;
+    const int m = col < C ? 1 : 0;                 // tile: m = 1 the x part, m = 0 the h part with the bias column at lane 31
+    const int kin = col < C ? col : (col == C + H ? 31 : col - C);
+    const int lhi = (j >> 2) & 1, r = (j & 3) + 4 * (j >> 3);
+    const int e = ((g * 2 + m) * 16 + r) * 64 + lhi * 32 + kin;
+    for (int k = 0; k < P2; ++k) a += src[(size_t)k * per + e];
+  } else if (att < H) {
+    const int j = att, lhi = (j >> 2) & 1, r = (j & 3) + 4 * (j >> 3), slot = 128 + r;
+    for (int k = 0; k < P2; ++k)
+      for (int l = 0; l < 32; ++l) a += src[(size_t)k * per + slot * 64 + lhi * 32 + l];
+  } else {
+    for (int k = 0; k < P2; ++k)
+      for (int l = 0; l < 32; ++l) a += src[(size_t)k * per + 144 * 64 + l];
+  }
+  flat[i] = a;
+}
+
 template <int C>
 static int launch_fwd(const float* xs, int n, int npad, const JkWeights& w, float* out, float* HS, float* CS, hipStream_t st) {
   static bool attr_set = false;
@@ -626,7 +667,7 @@ int jk_mfma_fwd(const float* xs, int n, int npad, int C, const JkWeights& w, flo
 
 template <int C, bool PG>
 static int launch_bwd(const float* xs, const float* dout, int n, int npad, const JkWeights& w, const float* HS, const float* CS,
-                      float* dxs, float* DGT, float* INT, float* G, float* ws, hipStream_t st) {
+                      float* dxs, float* DGT, float* INT, float* G, float* ws, hipStream_t st, float* flat = nullptr) {
   size_t lds = sizeof(float) * (JkM<C>::TOTAL + JKB_TILES * 192) + sizeof(float4) * JKB_TILES * 2 * 3 * JkM<C>::XG * 64;
   if (PG) lds += sizeof(float) * JKB_TILES * 2 * 3 * 32 * 36;
   static bool attr_set = false;
@@ -642,9 +683,14 @@ static int launch_bwd(const float* xs, const float* dout, int n, int npad, const
     constexpr int per = JkM<C>::PG_FLOATS, NG = 4 * JkM<C>::H + 1, NI = C + 2 * JkM<C>::H + 1;
     const int P = grid * JKB_TILES, P2 = ceil_div(P, 16);
     float* tmp = ws + (size_t)2 * P * per;
-    (void)hipMemsetAsync(G, 0, sizeof(float) * 2 * NG * NI, st);
     hipLaunchKernelGGL(k_jk_pg_fold, dim3(ceil_div(per, 256), P2, 2), dim3(256), 0, st, ws, P, P2, per, tmp);
-    hipLaunchKernelGGL(k_jk_pg_finish<C>, dim3(ceil_div(per, 256), 2), dim3(256), 0, st, tmp, P2, G);
+    if (flat != nullptr) {
+      constexpr int H = JkM<C>::H, total = 2 * (4 * H * C + 4 * H * H + 8 * H) + 2 * H + 1;
+      hipLaunchKernelGGL(k_jk_pg_finish_flat<C>, dim3(ceil_div(total, 256)), dim3(256), 0, st, tmp, P2, flat);
+    } else {
+      (void)hipMemsetAsync(G, 0, sizeof(float) * 2 * NG * NI, st);
+      hipLaunchKernelGGL(k_jk_pg_finish<C>, dim3(ceil_div(per, 256), 2), dim3(256), 0, st, tmp, P2, G);
+    }
     CGC_RETURN_IF_LAUNCH_FAILED();
   }
   return 0;
@@ -670,6 +716,20 @@ int64_t jk_mfma_bwd_ws_floats(int C) {
   const int64_t per = (8 * 16 + 16 + 1) * 64;
   (void)C;
   return 2 * 512 * per + 2 * 32 * per;
+}
+
+int jk_mfma_bwd_flat(const float* xs, const float* dout, int n, int npad, int C, const JkWeights& w, const float* HS, const float* CS,
+                     float* dxs, float* flat, float* ws, hipStream_t st) {
+  if ((reinterpret_cast<uintptr_t>(xs) & 15u) || (reinterpret_cast<uintptr_t>(dout) & 15u) || (reinterpret_cast<uintptr_t>(dxs) & 15u))
+    return CGC_EINVAL;
+  switch (C) {
+    case 4: return launch_bwd<4, true>(xs, dout, n, npad, w, HS, CS, dxs, nullptr, nullptr, nullptr, ws, st, flat);
+    case 8: return launch_bwd<8, true>(xs, dout, n, npad, w, HS, CS, dxs, nullptr, nullptr, nullptr, ws, st, flat);
+    case 12: return launch_bwd<12, true>(xs, dout, n, npad, w, HS, CS, dxs, nullptr, nullptr, nullptr, ws, st, flat);
+    case 16: return launch_bwd<16, true>(xs, dout, n, npad, w, HS, CS, dxs, nullptr, nullptr, nullptr, ws, st, flat);
+    case 20: return launch_bwd<20, true>(xs, dout, n, npad, w, HS, CS, dxs, nullptr, nullptr, nullptr, ws, st, flat);
+    default: return CGC_EINVAL;
+  }
 }
 
 int jk_mfma_bwd_params(const float* xs, const float* dout, int n, int npad, int C, const JkWeights& w, const float* HS,

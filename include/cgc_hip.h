@@ -241,6 +241,11 @@ int64_t cgc_jk_bwd_ws_floats(int C);
 int cgc_jk_lstm_bwd_params(const float* xs, const float* dout, int n, int npad, int C, const float* const* lstm,
                            const float* w_att, const float* b_att, const float* HS, const float* CS, float* dxs, float* G,
                            float* ws, cgc_stream_t stream);
+/* cgc_jk_lstm_bwd_params followed by cgc_jk_unpack_param_grads as one call without the intermediate G (matrix-core channel counts
+ * only): flat = cgc_jk_param_grad_floats(C) floats in parameter order.  ws as cgc_jk_lstm_bwd_params. */
+int cgc_jk_lstm_bwd_flat(const float* xs, const float* dout, int n, int npad, int C, const float* const* lstm,
+                         const float* w_att, const float* b_att, const float* HS, const float* CS, float* dxs, float* flat,
+                         float* ws, cgc_stream_t stream);
 /* G -> the DenseJK parameter gradients as ONE contiguous buffer of cgc_jk_param_grad_floats(C) floats, in parameter order:
  * per direction dW_ih [4H,C] | dW_hh [4H,H] | db_ih [4H] | db_hh [4H], then d att.weight [2H], d att.bias [1]
  * (model/network.py:27-33: nn.LSTM(C, 3C/2, bidirectional) + nn.Linear(3C, 1)). */
