@@ -1015,7 +1015,14 @@ static int gemm_dispatch(GemmArgs& a, int transA, int transB, int batch, int max
         return launch_cfg<4, 1, 1, 1>(a, transA, transB, batch, m_extent, k_extent, sk, ws_any, ws_floats, stream);
       return launch_cfg<2, 2, 1, 1>(a, transA, transB, batch, m_extent, k_extent, sk, ws_any, ws_floats, stream);
     }
-    if (transA) return launch_cfg<4, 1, 1, 2>(a, transA, transB, batch, m_extent, k_extent, sk, ws_any, ws_floats, stream);
+    if (transA) {
+      // long reductions (S^T P of a 4-graph shard: 324 tiles of 57 k-tiles): whole 128 x 128 tiles, cut in two along K, beat
+      // twice as many 128 x 64 tiles (235 -> 208 us).  (More pieces per tile -- 3 = 1.9 rounds of a third -- were measured
+      // too: 204 us, and a cost model that picked the piece count by rounds x length made the small tails slower.)
+      if (!sk && ws != nullptr && k_extent >= 24 * BK)
+        return launch_cfg<2, 2, 2, 2>(a, transA, transB, batch, m_extent, k_extent, sk, ws, ws_floats, stream);
+      return launch_cfg<4, 1, 1, 2>(a, transA, transB, batch, m_extent, k_extent, sk, ws_any, ws_floats, stream);
+    }
     return launch_cfg<1, 4, 2, 1>(a, transA, transB, batch, m_extent, k_extent, sk, ws_any, ws_floats, stream);
   }
   return launch_cfg<2, 2, 2, 2>(a, transA, transB, batch, m_extent, k_extent, sk, ws, ws_floats, stream);                        // 128 x 128

@@ -637,8 +637,565 @@ __global__ void k_jk_pg_finish_flat(const float* __restrict__ tmp, int P2, float
   flat[i] = a;
 }
 
+
+// =====================================================================================================================
+// Unit-split kernels (round 3).  The kernels above give one wave a whole (32-node tile, direction): 368 MFMAs per recurrence
+// step in the backward, 8 persistent accumulator tiles, 213 spilled registers, and ~100 us of strictly serial work per tile --
+// the launch is as long as its longest wave however few nodes there are (3 x 107 us at 4 graphs per GPU).  Here EIGHT waves
+// share a tile: wave (d, w) owns direction d and the hidden units 8w .. 8w+7.  Its M tile of the transposed gate product is
+// rows rho = 8 g + u (gate g, own unit u): in the accumulator layout register 4g + i of lane (node, half) is gate g of unit
+// 8w + 4 half + i, so a lane still holds all four gates of its (node, unit) pairs and the cell stays per-register arithmetic.
+// What no longer stays in registers is exchanged through LDS once per step: the new h (forward: 16 bytes per lane, double
+// buffered, one barrier), and in the backward the partial products of d[h|x]^T = W^T q, which contract over ALL (gate, unit)
+// rows (two barriers).  Per wave and step: 28 + 32 + 32 MFMAs instead of 112 + 128 + 128, two accumulator tiles for the
+// parameter gradients instead of eight, no spills.
+// =====================================================================================================================
+template <int C>
+struct JkU {
+  static constexpr int H = 3 * C / 2, XG = (C + 7) / 8, HG = (H + 7) / 8, NQ = XG + HG;
+  static constexpr int W_FLOATS = 2 * 4 * NQ * 256;            // [d][w][q][rho 32][lane half 2][t 4]
+  static constexpr int B_OFF = W_FLOATS;                       // bias [d][w][rho 32]
+  static constexpr int A_OFF = B_OFF + 256;                    // w_att [d][32], b_att
+  static constexpr int S_OFF = A_OFF + 68;                     // score partials [wave 8][t 3][32]
+  static constexpr int X_OFF = S_OFF + 768;                    // forward: h exchange [buffer 2][wave 8][64] float4
+  static constexpr int FWD_TOTAL = X_OFF + 2 * 8 * 256;
+  static constexpr int Q_OFF = S_OFF + 768;                    // backward, per wave: q transposed [node 32][36]; then its dh partials
+  static constexpr int I_OFF = Q_OFF + 8 * 1152;               // cell inputs, node-major [d][h tile | x tile][32][36]
+  static constexpr int P_OFF = I_OFF + 4 * 1152;               // dx partials [wave 8][XG][64] float4; at the end [d][q][t][64]
+  static constexpr int BWD_TOTAL = P_OFF + 8 * XG * 256;
+  static constexpr int PG_SLOTS = 37;                          // per wave: 2 x 16 accumulator registers, 4 attention registers, bias
+  static constexpr int PG_FLOATS = 8 * PG_SLOTS * 64;          // parameter-gradient partial of one workgroup
+  static_assert(H <= 30 && C % 4 == 0, "column 31 of the h tile is the bias column; 16-byte x fragments");
+};
+
+template <int C>
+__device__ __forceinline__ void jku_fill(const JkWeights& w, float* lds) {
+  using U = JkU<C>;
+  constexpr int H = U::H, XG = U::XG, NQ = U::NQ;
+  const int tid = threadIdx.x, d = tid >> 8;
+  const float* wih = d ? w.w_ih[1] : w.w_ih[0];
+  const float* whh = d ? w.w_hh[1] : w.w_hh[0];
+  const float* bih = d ? w.b_ih[1] : w.b_ih[0];
+  const float* bhh = d ? w.b_hh[1] : w.b_hh[0];
+  const int tt = tid & 3, lhi = (tid >> 2) & 1, rho = (tid >> 3) & 31, g = rho >> 3, u = rho & 7;
+  float v[4 * NQ];
+#pragma unroll
+  for (int it = 0; it < 4 * NQ; ++it) {
+    const int q = it % NQ, ww = it / NQ, j = 8 * ww + u;
+    v[it] = 0.f;
+    if (q < XG) {
+      const int k = 8 * q + 4 * lhi + tt;
+      if (j < H && k < C) v[it] = wih[(g * H + j) * C + k];
+    } else {
+      const int k = 8 * (q - XG) + 4 * lhi + tt;
+      if (j < H && k < H) v[it] = whh[(g * H + j) * H + k];
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < 4 * NQ; ++it) lds[(d * 4 * NQ + it) * 256 + (tid & 255)] = v[it];
+  if ((tid & 255) < 128) {
+    const int r2 = tid & 31, ww = (tid >> 5) & 3, j = 8 * ww + (r2 & 7), gg = r2 >> 3;
+    lds[U::B_OFF + (d * 4 + ww) * 32 + r2] = j < H ? bih[gg * H + j] + bhh[gg * H + j] : 0.f;
+  } else if ((tid & 255) < 160) {
+    const int j = tid & 31;
+    lds[U::A_OFF + d * 32 + j] = j < H ? w.w_att[d * H + j] : 0.f;
+  }
+  if (tid == 0) lds[U::A_OFF + 64] = w.b_att[0];
+}
+
+template <int C>
+__global__ __launch_bounds__(512) void k_jku_fwd(const float* __restrict__ xs, int n, int npad, const JkWeights w,
+                                                 float* __restrict__ out, float* __restrict__ HS, float* __restrict__ CS) {
+  using U = JkU<C>;
+  constexpr int H = U::H, XG = U::XG, HG = U::HG, NQ = U::NQ;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  jku_fill<C>(w, lds);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, l31 = lane & 31, lhi = lane >> 5;
+  const int wave = threadIdx.x >> 6, d = wave & 1, ww = wave >> 1;
+  const float4* Wl = reinterpret_cast<const float4*>(lds) + (size_t)(d * 4 + ww) * NQ * 64 + l31 * 2 + lhi;   // + q*64
+  const float* Bl = lds + U::B_OFF + (d * 4 + ww) * 32 + 4 * lhi;                                             // + 8g
+  const float4 wa4 = *reinterpret_cast<const float4*>(lds + U::A_OFF + d * 32 + 8 * ww + 4 * lhi);
+  const float was[4] = {wa4.x, wa4.y, wa4.z, wa4.w};
+  float* Sx = lds + U::S_OFF;
+  float4* Hx = reinterpret_cast<float4*>(lds + U::X_OFF);
+  const int ntiles = (n + 31) / 32;
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int node = tile * 32 + l31;
+    const bool valid = node < n, keep = node < npad;
+    const float* xrow = xs + (size_t)(valid ? node : 0) * 3 * C + 4 * lhi;
+    float cst[4] = {0.f, 0.f, 0.f, 0.f};
+    float4 hq[HG];
+#pragma unroll
+    for (int q = 0; q < HG; ++q) hq[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      const int t = d ? 2 - s : s;
+      floatx16 acc;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 b = *reinterpret_cast<const float4*>(Bl + 8 * g);
+        acc[4 * g + 0] = b.x; acc[4 * g + 1] = b.y; acc[4 * g + 2] = b.z; acc[4 * g + 3] = b.w;
+      }
+#pragma unroll
+      for (int q = 0; q < XG; ++q) {
+        float4 xf = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid && (8 * q + 4 * lhi < C)) xf = *reinterpret_cast<const float4*>(xrow + t * C + 8 * q);
+        const float4 a = Wl[q * 64];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, xf.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, xf.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, xf.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, xf.w, acc, 0, 0, 0);
+      }
+      if (s > 0) {
+#pragma unroll
+        for (int q = 0; q < HG; ++q) {
+          const float4 a = Wl[(XG + q) * 64];
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, hq[q].x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, hq[q].y, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, hq[q].z, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, hq[q].w, acc, 0, 0, 0);
+        }
+      }
+      float p = 0.f, hn[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int j = 8 * ww + 4 * lhi + i;
+        const float gi = fast_sigmoid(acc[i]), gf = fast_sigmoid(acc[4 + i]);
+        const float gg = fast_tanh(acc[8 + i]), go = fast_sigmoid(acc[12 + i]);
+        const float c = gf * cst[i] + gi * gg;
+        const float h = go * fast_tanh(c);
+        cst[i] = c;
+        hn[i] = h;
+        p = fmaf(was[i], h, p);
+        if (j < H && keep) {
+          const size_t slot = (size_t)((d * 3 + t) * H + j) * npad + node;
+          HS[slot] = h;
+          CS[slot] = c;
+        }
+      }
+      p += __shfl_xor(p, 32);
+      if (lhi == 0) Sx[(wave * 3 + t) * 32 + l31] = p;
+      if (s < 2) {        // h_t of all 32 units = the B operand of the next step's recurrent product: one 16-byte piece per wave
+        Hx[((s & 1) * 8 + wave) * 64 + lane] = make_float4(hn[0], hn[1], hn[2], hn[3]);
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < HG; ++q) hq[q] = Hx[((s & 1) * 8 + q * 2 + d) * 64 + lane];
+      }
+    }
+    __syncthreads();
+    if (d == 0 && ww < XG) {
+      float sc[3];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        float a = lds[U::A_OFF + 64];
+#pragma unroll
+        for (int v = 0; v < 8; ++v) a += Sx[(v * 3 + t) * 32 + l31];
+        sc[t] = a;
+      }
+      const float m = fmaxf(sc[0], fmaxf(sc[1], sc[2]));
+      float a3[3], den = 0.f;
+#pragma unroll
+      for (int t = 0; t < 3; ++t) { a3[t] = JK_EXP(sc[t] - m); den += a3[t]; }
+      const float inv = 1.f / den;
+      const int q = ww;
+      if (valid && 8 * q + 4 * lhi < C) {
+        const float4 x0 = *reinterpret_cast<const float4*>(xrow + 0 * C + 8 * q);
+        const float4 x1 = *reinterpret_cast<const float4*>(xrow + 1 * C + 8 * q);
+        const float4 x2 = *reinterpret_cast<const float4*>(xrow + 2 * C + 8 * q);
+        float4 o;
+        o.x = (a3[0] * x0.x + a3[1] * x1.x + a3[2] * x2.x) * inv;
+        o.y = (a3[0] * x0.y + a3[1] * x1.y + a3[2] * x2.y) * inv;
+        o.z = (a3[0] * x0.z + a3[1] * x1.z + a3[2] * x2.z) * inv;
+        o.w = (a3[0] * x0.w + a3[1] * x1.w + a3[2] * x2.w) * inv;
+        *reinterpret_cast<float4*>(out + (size_t)node * C + 8 * q + 4 * lhi) = o;
+      }
+    }
+    __syncthreads();          // the score partials are rewritten by the next tile
+  }
+}
+
+// Backward, unit-split (parameter gradients accumulated in-kernel; the staged variant stays with k_jk_bwd_mfma<C, false>).
+template <int C>
+__global__ __launch_bounds__(512) void k_jku_bwd(const float* __restrict__ xs, const float* __restrict__ dout, int n, int npad,
+                                                 const JkWeights w, const float* __restrict__ HS, const float* __restrict__ CS,
+                                                 float* __restrict__ dxs, float* __restrict__ PART) {
+  using U = JkU<C>;
+  constexpr int H = U::H, XG = U::XG, HG = U::HG, NQ = U::NQ;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  jku_fill<C>(w, lds);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, l31 = lane & 31, lhi = lane >> 5;
+  const int wave = threadIdx.x >> 6, d = wave & 1, ww = wave >> 1;
+  const float4* Wl = reinterpret_cast<const float4*>(lds) + (size_t)(d * 4 + ww) * NQ * 64 + l31 * 2 + lhi;
+  const float* Bl = lds + U::B_OFF + (d * 4 + ww) * 32 + 4 * lhi;
+  const float4 wa4 = *reinterpret_cast<const float4*>(lds + U::A_OFF + d * 32 + 8 * ww + 4 * lhi);
+  const float was[4] = {wa4.x, wa4.y, wa4.z, wa4.w};
+  float* Sx = lds + U::S_OFF;
+  float* Qw = lds + U::Q_OFF + wave * 1152;
+  float* Iw = lds + U::I_OFF + d * 2 * 1152;
+  float4* Dx = reinterpret_cast<float4*>(lds + U::P_OFF);
+  // W^T fragments out of the forward image: row kin = l31 of the (h | x) tile, k = this wave's (gate, unit) rows
+  const int kh = l31 < 8 * HG ? l31 : 8 * HG - 1, kx = l31 < 8 * XG ? l31 : 8 * XG - 1;
+  const float* WtH = lds + (size_t)((d * 4 + ww) * NQ + XG + kh / 8) * 256 + (kh & 7) + 32 * lhi;   // + (r>>2)*64 + (r&3)*8
+  const float* WtX = lds + (size_t)((d * 4 + ww) * NQ + kx / 8) * 256 + (kx & 7) + 32 * lhi;
+  const int ntiles = (n + 31) / 32;
+  floatx16 dW0, dW1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { dW0[r] = 0.f; dW1[r] = 0.f; }
+  float wacc[4] = {0.f, 0.f, 0.f, 0.f}, bacc = 0.f;
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int node = tile * 32 + l31;
+    const bool valid = node < n;
+    const float* xrow = xs + (size_t)(valid ? node : 0) * 3 * C + 4 * lhi;
+    // ---- attention: score partials over this wave's units, d out . x_t per time slot
+    float da[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      float p = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int j = 8 * ww + 4 * lhi + i;
+        if (j < H && valid) p = fmaf(was[i], HS[(size_t)((d * 3 + t) * H + j) * npad + node], p);
+      }
+      p += __shfl_xor(p, 32);
+      if (lhi == 0) Sx[(wave * 3 + t) * 32 + l31] = p;
+    }
+#pragma unroll
+    for (int q = 0; q < XG; ++q) {
+      if (valid && (8 * q + 4 * lhi < C)) {
+        const float4 dy = *reinterpret_cast<const float4*>(dout + (size_t)node * C + 8 * q + 4 * lhi);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          const float4 x = *reinterpret_cast<const float4*>(xrow + t * C + 8 * q);
+          da[t] += dy.x * x.x + dy.y * x.y + dy.z * x.z + dy.w * x.w;
+        }
+      }
+    }
+    __syncthreads();
+    float a3[3], ds3[3];
+    {
+      float sc[3];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        float a = lds[U::A_OFF + 64];
+#pragma unroll
+        for (int v = 0; v < 8; ++v) a += Sx[(v * 3 + t) * 32 + l31];
+        sc[t] = a;
+      }
+      const float m = fmaxf(sc[0], fmaxf(sc[1], sc[2]));
+      float den = 0.f, mean = 0.f;
+#pragma unroll
+      for (int t = 0; t < 3; ++t) { a3[t] = JK_EXP(sc[t] - m); den += a3[t]; }
+      const float inv = 1.f / den;
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        da[t] += __shfl_xor(da[t], 32);
+        a3[t] *= inv;
+        mean = fmaf(a3[t], da[t], mean);
+      }
+#pragma unroll
+      for (int t = 0; t < 3; ++t) ds3[t] = valid ? a3[t] * (da[t] - mean) : 0.f;
+    }
+    float dhc[4] = {0.f, 0.f, 0.f, 0.f}, dcc[4] = {0.f, 0.f, 0.f, 0.f};
+    float4 dxs0 = make_float4(0.f, 0.f, 0.f, 0.f), dxs1 = dxs0, dxs2 = dxs0;       // d x_t pieces by recurrence step
+
+    // (recurrence rolled: unrolled, the scheduler hoists the loads of all three steps and spills 81 registers)
+#pragma unroll 1
+    for (int s = 2; s >= 0; --s) {
+      const int t = d ? 2 - s : s, tprev = d ? t + 1 : t - 1;
+      const float dst = t == 0 ? ds3[0] : (t == 1 ? ds3[1] : ds3[2]);
+      float4 xt[XG];
+#pragma unroll
+      for (int q = 0; q < XG; ++q)
+        xt[q] = (valid && (8 * q + 4 * lhi < C)) ? *reinterpret_cast<const float4*>(xrow + t * C + 8 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 hq[HG];
+      float cprev[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < HG; ++q) {
+        float hv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (s > 0) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int j = 8 * q + 4 * lhi + i;
+            if (j < H && valid) hv[i] = HS[(size_t)((d * 3 + tprev) * H + j) * npad + node];
+          }
+        }
+        hq[q] = make_float4(hv[0], hv[1], hv[2], hv[3]);
+      }
+      if (s > 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int j = 8 * ww + 4 * lhi + i;
+          if (j < H && valid) cprev[i] = CS[(size_t)((d * 3 + tprev) * H + j) * npad + node];
+        }
+      }
+      if (ww == 0) {      // the step's cell inputs, node-major: tile 0 = h_{t-1} (+ 1.0 at column 31: the bias column), tile 1 = x_t
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (q < HG) v = hq[q < HG ? q : 0];
+          if (q == 3 && lhi == 1) v.w = 1.f;
+          *reinterpret_cast<float4*>(Iw + l31 * 36 + 8 * q + 4 * lhi) = v;
+          float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (q < XG) xv = xt[q < XG ? q : 0];
+          *reinterpret_cast<float4*>(Iw + 1152 + l31 * 36 + 8 * q + 4 * lhi) = xv;
+        }
+      }
+      // ---- gate pre-activations again
+      floatx16 acc;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 b = *reinterpret_cast<const float4*>(Bl + 8 * g);
+        acc[4 * g + 0] = b.x; acc[4 * g + 1] = b.y; acc[4 * g + 2] = b.z; acc[4 * g + 3] = b.w;
+      }
+#pragma unroll
+      for (int q = 0; q < XG; ++q) {
+        const float4 a = Wl[q * 64];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, xt[q].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, xt[q].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, xt[q].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, xt[q].w, acc, 0, 0, 0);
+      }
+      if (s > 0) {
+#pragma unroll
+        for (int q = 0; q < HG; ++q) {
+          const float4 a = Wl[(XG + q) * 64];
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, hq[q].x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, hq[q].y, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, hq[q].z, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, hq[q].w, acc, 0, 0, 0);
+        }
+      }
+      // ---- cell backward for the own (node, unit) pairs; acc becomes d loss / d pre-activation
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float gi = fast_sigmoid(acc[i]), gf = fast_sigmoid(acc[4 + i]);
+        const float gg = fast_tanh(acc[8 + i]), go = fast_sigmoid(acc[12 + i]);
+        const float c = gf * cprev[i] + gi * gg;
+        const float th = fast_tanh(c);
+        const float dh = fmaf(dst, was[i], dhc[i]);
+        const float dc = fmaf(dh * go, 1.f - th * th, dcc[i]);
+        dcc[i] = dc * gf;
+        acc[i] = dc * gg * gi * (1.f - gi);
+        acc[4 + i] = dc * cprev[i] * gf * (1.f - gf);
+        acc[8 + i] = dc * gi * (1.f - gg * gg);
+        acc[12 + i] = dh * th * go * (1.f - go);
+        wacc[i] = fmaf(dst, go * th, wacc[i]);          // d w_att[j] += ds_t * h_t[j]
+      }
+      if (wave == 0 && lhi == 0) bacc += dst;            // d b_att
+      // q transposed through the wave's tile: rows (gate, unit) become the lane index, node pairs the MFMA k index
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(Qw + l31 * 36 + 8 * g + 4 * lhi) = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+      __builtin_amdgcn_wave_barrier();
+      float af[16];
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) af[kk] = Qw[(2 * kk + lhi) * 36 + l31];
+      __builtin_amdgcn_wave_barrier();
+      // ---- this wave's share of d[h_{t-1} | x_t]^T = W^T q (contraction over its 32 (gate, unit) rows)
+      floatx16 dh2, dx2;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dh2[r] = 0.f; dx2[r] = 0.f; }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float ax = WtX[(r >> 2) * 64 + (r & 3) * 8];
+        dx2 = __builtin_amdgcn_mfma_f32_32x32x2f32(ax, acc[r], dx2, 0, 0, 0);
+        if (s > 0) {
+          const float ah = WtH[(r >> 2) * 64 + (r & 3) * 8];
+          dh2 = __builtin_amdgcn_mfma_f32_32x32x2f32(ah, acc[r], dh2, 0, 0, 0);
+        }
+      }
+      float4* Pw = reinterpret_cast<float4*>(Qw);       // the transposed tile is consumed (af): its space takes the dh partials
+      if (s > 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Pw[q * 64 + lane] = make_float4(dh2[4 * q], dh2[4 * q + 1], dh2[4 * q + 2], dh2[4 * q + 3]);
+      }
+#pragma unroll
+      for (int q = 0; q < XG; ++q) Dx[(wave * XG + q) * 64 + lane] = make_float4(dx2[4 * q], dx2[4 * q + 1], dx2[4 * q + 2], dx2[4 * q + 3]);
+      __syncthreads();
+      // ---- parameter gradients of the own rows: dW[(g,u)][kin] += sum_node q . in
+      {
+        float bf0[16], bf1[16];
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+          bf0[kk] = Iw[(2 * kk + lhi) * 36 + l31];
+          bf1[kk] = Iw[1152 + (2 * kk + lhi) * 36 + l31];
+        }
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+          dW0 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk], bf0[kk], dW0, 0, 0, 0);
+          dW1 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk], bf1[kk], dW1, 0, 0, 0);
+        }
+      }
+      if (s > 0) {         // d h_{t-1} of the own units: the four waves' partials, added in wave order
+        const float4* P0 = reinterpret_cast<const float4*>(lds + U::Q_OFF) + ww * 64 + lane;
+        float4 a = P0[(0 * 2 + d) * 288];
+        const float4 b = P0[(1 * 2 + d) * 288], c2 = P0[(2 * 2 + d) * 288], e = P0[(3 * 2 + d) * 288];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        a.x += c2.x; a.y += c2.y; a.z += c2.z; a.w += c2.w;
+        a.x += e.x; a.y += e.y; a.z += e.z; a.w += e.w;
+        dhc[0] = a.x; dhc[1] = a.y; dhc[2] = a.z; dhc[3] = a.w;
+      }
+      if (ww < XG) {       // d x_t piece q = ww of this direction
+        float4 a = Dx[((0 * 2 + d) * XG + ww) * 64 + lane];
+#pragma unroll
+        for (int v = 1; v < 4; ++v) {
+          const float4 b = Dx[((v * 2 + d) * XG + ww) * 64 + lane];
+          a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        if (s == 2) dxs2 = a;
+        else if (s == 1) dxs1 = a;
+        else dxs0 = a;
+      }
+      __syncthreads();
+    }
+    // ---- input gradient: attention term + both directions' LSTM terms
+    if (ww < XG) {
+      Dx[((d * XG + ww) * 3 + (d ? 2 : 0)) * 64 + lane] = dxs0;
+      Dx[((d * XG + ww) * 3 + 1) * 64 + lane] = dxs1;
+      Dx[((d * XG + ww) * 3 + (d ? 0 : 2)) * 64 + lane] = dxs2;
+    }
+    __syncthreads();
+    if (d == 0 && ww < XG && valid && 8 * ww + 4 * lhi < C) {
+      const int q = ww;
+      const float4 dy = *reinterpret_cast<const float4*>(dout + (size_t)node * C + 8 * q + 4 * lhi);
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const float4 p0 = Dx[((0 * XG + q) * 3 + t) * 64 + lane], p1 = Dx[((1 * XG + q) * 3 + t) * 64 + lane];
+        float4 v;
+        v.x = fmaf(a3[t], dy.x, p0.x + p1.x); v.y = fmaf(a3[t], dy.y, p0.y + p1.y);
+        v.z = fmaf(a3[t], dy.z, p0.z + p1.z); v.w = fmaf(a3[t], dy.w, p0.w + p1.w);
+        *reinterpret_cast<float4*>(dxs + (size_t)node * 3 * C + t * C + 8 * q + 4 * lhi) = v;
+      }
+    }
+    // (no barrier needed here: the next tile's first barrier comes before anything above is overwritten -- the score partials
+    // are rewritten, but they were last read before the first step's barriers)
+  }
+  float* pw = PART + (size_t)blockIdx.x * U::PG_FLOATS + (size_t)wave * U::PG_SLOTS * 64 + lane;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { pw[r * 64] = dW0[r]; pw[(16 + r) * 64] = dW1[r]; }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) pw[(32 + i) * 64] = wacc[i];
+  pw[36 * 64] = bacc;
+}
+
+// element (d, row = g H + j, col) of G [2][4H+1][C+2H+1] / attention entry `att` (0..H-1: d w_att[d H + att]; H: d b_att) out of
+// the folded partials of the unit-split backward
+template <int C>
+__device__ __forceinline__ float jku_gather(const float* __restrict__ tmp, int P2, int d, int row, int col, int att) {
+  using U = JkU<C>;
+  constexpr int H = U::H, per = U::PG_FLOATS;
+  float a = 0.f;
+  if (att < 0) {
+    const int g = row / H, j = row - g * H, ww = j >> 3, u = j & 7, lhi = u >> 2, r = 4 * g + (u & 3);
+    const int m = col < C ? 1 : 0;                 // tile: 1 = the x part, 0 = the h part with the bias column at lane 31
+    const int kin = col < C ? col : (col == C + H ? 31 : col - C);
+    const int e = ((ww * 2 + d) * U::PG_SLOTS + m * 16 + r) * 64 + lhi * 32 + kin;
+    for (int k = 0; k < P2; ++k) a += tmp[(size_t)k * per + e];
+  } else if (att < H) {
+    const int j = att, ww = j >> 3, u = j & 7, lhi = u >> 2;
+    const int e = ((ww * 2 + d) * U::PG_SLOTS + 32 + (u & 3)) * 64 + lhi * 32;
+    for (int k = 0; k < P2; ++k)
+      for (int l = 0; l < 32; ++l) a += tmp[(size_t)k * per + e + l];
+  } else {
+    for (int k = 0; k < P2; ++k)
+      for (int l = 0; l < 32; ++l) a += tmp[(size_t)k * per + 36 * 64 + l];
+  }
+  return a;
+}
+
+template <int C>
+__global__ void k_jku_finish_flat(const float* __restrict__ tmp, int P2, float* __restrict__ flat) {
+  constexpr int H = JkU<C>::H;
+  constexpr int per_dir = 4 * H * C + 4 * H * H + 8 * H, total = 2 * per_dir + 2 * H + 1;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int d, row = 0, col = 0, att = -1;
+  if (i < 2 * per_dir) {
+    d = i / per_dir;
+    int e = i - d * per_dir;
+    if (e < 4 * H * C) { row = e / C; col = e % C; }
+    else if ((e -= 4 * H * C) < 4 * H * H) { row = e / H; col = C + e % H; }
+    else { e -= 4 * H * H; row = e % (4 * H); col = C + H; }
+  } else {
+    const int e = i - 2 * per_dir;
+    if (e < 2 * H) { d = e / H; att = e % H; }
+    else { d = 0; att = H; }
+  }
+  flat[i] = jku_gather<C>(tmp, P2, d, row, col, att);
+}
+
+// the same into G [2][4H+1][C+2H+1] (every element written: rows the kernels do not produce are zero)
+template <int C>
+__global__ void k_jku_finish_G(const float* __restrict__ tmp, int P2, float* __restrict__ G) {
+  constexpr int H = JkU<C>::H, NG = 4 * H + 1, NI = C + 2 * H + 1;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * NG * NI) return;
+  const int d = i / (NG * NI), e = i - d * NG * NI, row = e / NI, col = e - row * NI;
+  float v = 0.f;
+  if (row < 4 * H) {
+    if (col <= C + H) v = jku_gather<C>(tmp, P2, d, row, col, -1);
+  } else if (col > C + H) {
+    v = jku_gather<C>(tmp, P2, d, 0, 0, col - (C + H + 1));
+  } else if (col == C + H && d == 0) {
+    v = jku_gather<C>(tmp, P2, 0, 0, 0, H);
+  }
+  G[i] = v;
+}
+
+// CGC_JK_UNITSPLIT=0: the one-wave-per-(tile, direction) kernels (A-B timing)
+static const int g_unit_split = getenv("CGC_JK_UNITSPLIT") ? atoi(getenv("CGC_JK_UNITSPLIT")) : 1;
+
+template <int C>
+static int launch_fwd_us(const float* xs, int n, int npad, const JkWeights& w, float* out, float* HS, float* CS, hipStream_t st) {
+  constexpr size_t lds = sizeof(float) * JkU<C>::FWD_TOTAL;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_jku_fwd<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  int grid = ceil_div(n, 32);
+  if (grid > 512) grid = 512;                 // persistent over the 32-node tiles
+  hipLaunchKernelGGL(k_jku_fwd<C>, dim3(grid), dim3(512), lds, st, xs, n, npad, w, out, HS, CS);
+  CGC_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}
+
+// flat != nullptr: gradients in parameter order (cgc_jk_unpack_param_grads' layout); else G [2][4H+1][C+2H+1]
+template <int C>
+static int launch_bwd_us(const float* xs, const float* dout, int n, int npad, const JkWeights& w, const float* HS, const float* CS,
+                         float* dxs, float* G, float* ws, hipStream_t st, float* flat) {
+  constexpr size_t lds = sizeof(float) * JkU<C>::BWD_TOTAL;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_jku_bwd<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  int grid = ceil_div(n, 32);
+  if (grid > 256) grid = 256;                 // one workgroup per CU (LDS), persistent over the tiles
+  hipLaunchKernelGGL(k_jku_bwd<C>, dim3(grid), dim3(512), lds, st, xs, dout, n, npad, w, HS, CS, dxs, ws);
+  CGC_RETURN_IF_LAUNCH_FAILED();
+  constexpr int per = JkU<C>::PG_FLOATS, H = JkU<C>::H;
+  const int P = grid, P2 = ceil_div(P, 16);
+  float* tmp = ws + (size_t)P * per;
+  hipLaunchKernelGGL(k_jk_pg_fold, dim3(ceil_div(per, 256), P2, 1), dim3(256), 0, st, ws, P, P2, per, tmp);
+  if (flat != nullptr) {
+    constexpr int total = 2 * (4 * H * C + 4 * H * H + 8 * H) + 2 * H + 1;
+    hipLaunchKernelGGL(k_jku_finish_flat<C>, dim3(ceil_div(total, 128)), dim3(128), 0, st, tmp, P2, flat);
+  } else {
+    constexpr int total = 2 * (4 * H + 1) * (C + 2 * H + 1);
+    hipLaunchKernelGGL(k_jku_finish_G<C>, dim3(ceil_div(total, 128)), dim3(128), 0, st, tmp, P2, G);
+  }
+  CGC_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}
+
 template <int C>
 static int launch_fwd(const float* xs, int n, int npad, const JkWeights& w, float* out, float* HS, float* CS, hipStream_t st) {
+  if (g_unit_split) return launch_fwd_us<C>(xs, n, npad, w, out, HS, CS, st);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_jk_fwd_mfma<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -668,6 +1225,7 @@ int jk_mfma_fwd(const float* xs, int n, int npad, int C, const JkWeights& w, flo
 template <int C, bool PG>
 static int launch_bwd(const float* xs, const float* dout, int n, int npad, const JkWeights& w, const float* HS, const float* CS,
                       float* dxs, float* DGT, float* INT, float* G, float* ws, hipStream_t st, float* flat = nullptr) {
+  if (PG && g_unit_split) return launch_bwd_us<C>(xs, dout, n, npad, w, HS, CS, dxs, G, ws, st, flat);
   size_t lds = sizeof(float) * (JkM<C>::TOTAL + JKB_TILES * 192) + sizeof(float4) * JKB_TILES * 2 * 3 * JkM<C>::XG * 64;
   if (PG) lds += sizeof(float) * JKB_TILES * 2 * 3 * 32 * 36;
   static bool attr_set = false;

@@ -377,6 +377,8 @@ TAIL_CASES = [
     ([300, 0, 513, 128, 77], 520, 400, False, True, 5, 1),                    # ragged M, plain cut (empty tiles in the tail)
     ([300, 0, 513, 128, 77, 900, 250, 640], 520, 0, True, False, 8, 2),      # ragged K, serpentine dealing
     ([300, 0, 513], 520, 0, True, False, 3, 2),                               # ragged K, plain cut; one empty reduction
+    (1140, 1140, 1800, True, False, 4, 0),       # 324 tiles of 57 k-tiles (S^T P of a 4-graph shard): every tile in 2 pieces
+    ([1800, 1900, 1750, 1860, 1700, 1650, 2000, 1810], 1140, 0, True, False, 8, 2),   # 288 ragged-K tiles in 2 pieces, serpentine dealing
 ]
 
 
