@@ -682,13 +682,15 @@ __device__ __forceinline__ void jku_fill(const JkWeights& w, float* lds) {
 #pragma unroll
   for (int it = 0; it < 4 * NQ; ++it) {
     const int q = it % NQ, ww = it / NQ, j = 8 * ww + u;
-    v[it] = 0.f;
+    const int jr = j < H ? j : H - 1;                  // unconditional loads from clamped addresses + select (no branch per load)
     if (q < XG) {
       const int k = 8 * q + 4 * lhi + tt;
-      if (j < H && k < C) v[it] = wih[(g * H + j) * C + k];
+      const float ld = wih[(g * H + jr) * C + (k < C ? k : C - 1)];
+      v[it] = (j < H && k < C) ? ld : 0.f;
     } else {
       const int k = 8 * (q - XG) + 4 * lhi + tt;
-      if (j < H && k < H) v[it] = whh[(g * H + j) * H + k];
+      const float ld = whh[(g * H + jr) * H + (k < H ? k : H - 1)];
+      v[it] = (j < H && k < H) ? ld : 0.f;
     }
   }
 #pragma unroll
@@ -712,7 +714,7 @@ __global__ __launch_bounds__(512) void k_jku_fwd(const float* __restrict__ xs, i
   jku_fill<C>(w, lds);
   __syncthreads();
   const int lane = threadIdx.x & 63, l31 = lane & 31, lhi = lane >> 5;
-  const int wave = threadIdx.x >> 6, d = wave & 1, ww = wave >> 1;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), d = wave & 1, ww = wave >> 1;      // (wave-uniform: SGPRs)
   const float4* Wl = reinterpret_cast<const float4*>(lds) + (size_t)(d * 4 + ww) * NQ * 64 + l31 * 2 + lhi;   // + q*64
   const float* Bl = lds + U::B_OFF + (d * 4 + ww) * 32 + 4 * lhi;                                             // + 8g
   const float4 wa4 = *reinterpret_cast<const float4*>(lds + U::A_OFF + d * 32 + 8 * ww + 4 * lhi);
@@ -740,8 +742,10 @@ __global__ __launch_bounds__(512) void k_jku_fwd(const float* __restrict__ xs, i
       }
 #pragma unroll
       for (int q = 0; q < XG; ++q) {
-        float4 xf = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (valid && (8 * q + 4 * lhi < C)) xf = *reinterpret_cast<const float4*>(xrow + t * C + 8 * q);
+        // (unconditional load from a clamped address + select: a predicated load is a branch)
+        const bool in = 8 * q + 4 * lhi < C;
+        const float4 ld = *reinterpret_cast<const float4*>(xrow + t * C + (in ? 8 * q : 8 * q - 4));
+        const float4 xf = (valid && in) ? ld : make_float4(0.f, 0.f, 0.f, 0.f);
         const float4 a = Wl[q * 64];
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, xf.x, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, xf.y, acc, 0, 0, 0);
@@ -827,7 +831,7 @@ __global__ __launch_bounds__(512) void k_jku_bwd(const float* __restrict__ xs, c
   jku_fill<C>(w, lds);
   __syncthreads();
   const int lane = threadIdx.x & 63, l31 = lane & 31, lhi = lane >> 5;
-  const int wave = threadIdx.x >> 6, d = wave & 1, ww = wave >> 1;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), d = wave & 1, ww = wave >> 1;      // (wave-uniform: SGPRs)
   const float4* Wl = reinterpret_cast<const float4*>(lds) + (size_t)(d * 4 + ww) * NQ * 64 + l31 * 2 + lhi;
   const float* Bl = lds + U::B_OFF + (d * 4 + ww) * 32 + 4 * lhi;
   const float4 wa4 = *reinterpret_cast<const float4*>(lds + U::A_OFF + d * 32 + 8 * ww + 4 * lhi);
@@ -849,6 +853,10 @@ __global__ __launch_bounds__(512) void k_jku_bwd(const float* __restrict__ xs, c
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int node = tile * 32 + l31;
     const bool valid = node < n;
+    const int nd = valid ? node : 0;
+    // saved states are read as  scalar row base + one of two lane offsets  (unit j = 8 q + 4 half + i: half 1 is dropped for the
+    // units past H, whose value is discarded anyway): no per-load address arithmetic, no predicated loads
+    const size_t off0 = (size_t)nd, off1 = (size_t)nd + (size_t)(4 * lhi) * npad;
     const float* xrow = xs + (size_t)(valid ? node : 0) * 3 * C + 4 * lhi;
     // ---- attention: score partials over this wave's units, d out . x_t per time slot
     float da[3] = {0.f, 0.f, 0.f};
@@ -857,8 +865,10 @@ __global__ __launch_bounds__(512) void k_jku_bwd(const float* __restrict__ xs, c
       float p = 0.f;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int j = 8 * ww + 4 * lhi + i;
-        if (j < H && valid) p = fmaf(was[i], HS[(size_t)((d * 3 + t) * H + j) * npad + node], p);
+        // (unconditional loads from clamped addresses + select: a predicated load is a branch per load)
+        const int j = 8 * ww + 4 * lhi + i, jr = 8 * ww + i < H ? 8 * ww + i : H - 1;
+        const float hv = (HS + (size_t)((d * 3 + t) * H + jr) * npad)[8 * ww + 4 + i < H ? off1 : off0];
+        p = fmaf(was[i], (j < H && valid) ? hv : 0.f, p);
       }
       p += __shfl_xor(p, 32);
       if (lhi == 0) Sx[(wave * 3 + t) * 32 + l31] = p;
@@ -902,36 +912,45 @@ __global__ __launch_bounds__(512) void k_jku_bwd(const float* __restrict__ xs, c
     float dhc[4] = {0.f, 0.f, 0.f, 0.f}, dcc[4] = {0.f, 0.f, 0.f, 0.f};
     float4 dxs0 = make_float4(0.f, 0.f, 0.f, 0.f), dxs1 = dxs0, dxs2 = dxs0;       // d x_t pieces by recurrence step
 
+    // operands of one recurrence step: x_t, h_{t-1} (all units: the B operand of the recurrent product), c_{t-1} (own units).
+    // Loaded for the first step here and for every later one right after the previous step's first barrier, when these
+    // registers are dead: the loads travel while the parameter-gradient MFMAs run instead of in front of the gate product.
+    float4 xt[XG], hq[HG];
+    float cprev[4];
+#define JKU_LOAD_STEP(S_)                                                                                                   \
+    {                                                                                                                       \
+      const int s_ = (S_), t_ = d ? 2 - s_ : s_, tp_ = d ? t_ + 1 : t_ - 1;                                                  \
+      _Pragma("unroll") for (int q = 0; q < XG; ++q)                                                                        \
+      {                                                                                                                     \
+        const bool in_ = 8 * q + 4 * lhi < C;                                                                               \
+        const float4 ld_ = *reinterpret_cast<const float4*>(xs + (size_t)nd * 3 * C + t_ * C + (in_ ? 8 * q + 4 * lhi : 0)); \
+        xt[q] = (valid && in_) ? ld_ : make_float4(0.f, 0.f, 0.f, 0.f);                                                     \
+      }                                                                                                                     \
+      _Pragma("unroll") for (int q = 0; q < HG; ++q) {                                                                      \
+        float hv[4] = {0.f, 0.f, 0.f, 0.f};                                                                                 \
+        if (s_ > 0) {                                                                                                       \
+          _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                   \
+            const int j = 8 * q + 4 * lhi + i;                                                                              \
+            const float ld_ = (HS + (size_t)((d * 3 + tp_) * H + (8 * q + i < H ? 8 * q + i : H - 1)) * npad)               \
+                [8 * q + 4 + i < H ? off1 : off0];                                                                          \
+            hv[i] = (j < H && valid) ? ld_ : 0.f;                                                                           \
+          }                                                                                                                 \
+        }                                                                                                                   \
+        hq[q] = make_float4(hv[0], hv[1], hv[2], hv[3]);                                                                    \
+      }                                                                                                                     \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                       \
+        const int j = 8 * ww + 4 * lhi + i;                                                                                 \
+        const int jr_ = 8 * ww + i < H ? 8 * ww + i : H - 1;                                                                \
+        const float ld_ = (CS + (size_t)((d * 3 + (s_ > 0 ? tp_ : t_)) * H + jr_) * npad)[8 * ww + 4 + i < H ? off1 : off0]; \
+        cprev[i] = (s_ > 0 && j < H && valid) ? ld_ : 0.f;                                                                  \
+      }                                                                                                                     \
+    }
+    JKU_LOAD_STEP(2)
     // (recurrence rolled: unrolled, the scheduler hoists the loads of all three steps and spills 81 registers)
 #pragma unroll 1
     for (int s = 2; s >= 0; --s) {
-      const int t = d ? 2 - s : s, tprev = d ? t + 1 : t - 1;
+      const int t = d ? 2 - s : s;
       const float dst = t == 0 ? ds3[0] : (t == 1 ? ds3[1] : ds3[2]);
-      float4 xt[XG];
-#pragma unroll
-      for (int q = 0; q < XG; ++q)
-        xt[q] = (valid && (8 * q + 4 * lhi < C)) ? *reinterpret_cast<const float4*>(xrow + t * C + 8 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-      float4 hq[HG];
-      float cprev[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int q = 0; q < HG; ++q) {
-        float hv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (s > 0) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int j = 8 * q + 4 * lhi + i;
-            if (j < H && valid) hv[i] = HS[(size_t)((d * 3 + tprev) * H + j) * npad + node];
-          }
-        }
-        hq[q] = make_float4(hv[0], hv[1], hv[2], hv[3]);
-      }
-      if (s > 0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int j = 8 * ww + 4 * lhi + i;
-          if (j < H && valid) cprev[i] = CS[(size_t)((d * 3 + tprev) * H + j) * npad + node];
-        }
-      }
       if (ww == 0) {      // the step's cell inputs, node-major: tile 0 = h_{t-1} (+ 1.0 at column 31: the bias column), tile 1 = x_t
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -944,6 +963,7 @@ __global__ __launch_bounds__(512) void k_jku_bwd(const float* __restrict__ xs, c
           *reinterpret_cast<float4*>(Iw + 1152 + l31 * 36 + 8 * q + 4 * lhi) = xv;
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
       // ---- gate pre-activations again
       floatx16 acc;
 #pragma unroll
@@ -969,6 +989,7 @@ __global__ __launch_bounds__(512) void k_jku_bwd(const float* __restrict__ xs, c
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, hq[q].w, acc, 0, 0, 0);
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
       // ---- cell backward for the own (node, unit) pairs; acc becomes d loss / d pre-activation
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -986,6 +1007,7 @@ __global__ __launch_bounds__(512) void k_jku_bwd(const float* __restrict__ xs, c
         wacc[i] = fmaf(dst, go * th, wacc[i]);          // d w_att[j] += ds_t * h_t[j]
       }
       if (wave == 0 && lhi == 0) bacc += dst;            // d b_att
+      __builtin_amdgcn_sched_barrier(0);
       // q transposed through the wave's tile: rows (gate, unit) become the lane index, node pairs the MFMA k index
 #pragma unroll
       for (int g = 0; g < 4; ++g)
@@ -995,6 +1017,7 @@ __global__ __launch_bounds__(512) void k_jku_bwd(const float* __restrict__ xs, c
 #pragma unroll
       for (int kk = 0; kk < 16; ++kk) af[kk] = Qw[(2 * kk + lhi) * 36 + l31];
       __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_sched_barrier(0);
       // ---- this wave's share of d[h_{t-1} | x_t]^T = W^T q (contraction over its 32 (gate, unit) rows)
       floatx16 dh2, dx2;
 #pragma unroll
@@ -1008,6 +1031,7 @@ __global__ __launch_bounds__(512) void k_jku_bwd(const float* __restrict__ xs, c
           dh2 = __builtin_amdgcn_mfma_f32_32x32x2f32(ah, acc[r], dh2, 0, 0, 0);
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
       float4* Pw = reinterpret_cast<float4*>(Qw);       // the transposed tile is consumed (af): its space takes the dh partials
       if (s > 0) {
 #pragma unroll
@@ -1016,6 +1040,8 @@ __global__ __launch_bounds__(512) void k_jku_bwd(const float* __restrict__ xs, c
 #pragma unroll
       for (int q = 0; q < XG; ++q) Dx[(wave * XG + q) * 64 + lane] = make_float4(dx2[4 * q], dx2[4 * q + 1], dx2[4 * q + 2], dx2[4 * q + 3]);
       __syncthreads();
+      if (s > 0) JKU_LOAD_STEP(s - 1)
+      __builtin_amdgcn_sched_barrier(0);
       // ---- parameter gradients of the own rows: dW[(g,u)][kin] += sum_node q . in
       {
         float bf0[16], bf1[16];
@@ -1030,6 +1056,7 @@ __global__ __launch_bounds__(512) void k_jku_bwd(const float* __restrict__ xs, c
           dW1 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk], bf1[kk], dW1, 0, 0, 0);
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
       if (s > 0) {         // d h_{t-1} of the own units: the four waves' partials, added in wave order
         const float4* P0 = reinterpret_cast<const float4*>(lds + U::Q_OFF) + ww * 64 + lane;
         float4 a = P0[(0 * 2 + d) * 288];
@@ -1074,9 +1101,18 @@ __global__ __launch_bounds__(512) void k_jku_bwd(const float* __restrict__ xs, c
     // (no barrier needed here: the next tile's first barrier comes before anything above is overwritten -- the score partials
     // are rewritten, but they were last read before the first step's barriers)
   }
+#undef JKU_LOAD_STEP
   float* pw = PART + (size_t)blockIdx.x * U::PG_FLOATS + (size_t)wave * U::PG_SLOTS * 64 + lane;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { pw[r * 64] = dW0[r]; pw[(16 + r) * 64] = dW1[r]; }
+  // per-node sums of the attention gradients: folded over the 32 nodes of the lane half here (fixed butterfly order), so that the
+  // finishing kernel adds one value per workgroup instead of 32
+#pragma unroll
+  for (int o = 16; o >= 1; o >>= 1) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wacc[i] += __shfl_xor(wacc[i], o);
+    bacc += __shfl_xor(bacc, o);
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) pw[(32 + i) * 64] = wacc[i];
   pw[36 * 64] = bacc;
@@ -1097,12 +1133,10 @@ __device__ __forceinline__ float jku_gather(const float* __restrict__ tmp, int P
     for (int k = 0; k < P2; ++k) a += tmp[(size_t)k * per + e];
   } else if (att < H) {
     const int j = att, ww = j >> 3, u = j & 7, lhi = u >> 2;
-    const int e = ((ww * 2 + d) * U::PG_SLOTS + 32 + (u & 3)) * 64 + lhi * 32;
-    for (int k = 0; k < P2; ++k)
-      for (int l = 0; l < 32; ++l) a += tmp[(size_t)k * per + e + l];
+    const int e = ((ww * 2 + d) * U::PG_SLOTS + 32 + (u & 3)) * 64 + lhi * 32;     // (already summed over the lane half)
+    for (int k = 0; k < P2; ++k) a += tmp[(size_t)k * per + e];
   } else {
-    for (int k = 0; k < P2; ++k)
-      for (int l = 0; l < 32; ++l) a += tmp[(size_t)k * per + 36 * 64 + l];
+    for (int k = 0; k < P2; ++k) a += tmp[(size_t)k * per + 36 * 64];
   }
   return a;
 }
@@ -1158,7 +1192,8 @@ static int launch_fwd_us(const float* xs, int n, int npad, const JkWeights& w, f
     attr_set = true;
   }
   int grid = ceil_div(n, 32);
-  if (grid > 512) grid = 512;                 // persistent over the 32-node tiles
+  static const int fgrid = getenv("CGC_JKU_FGRID") ? atoi(getenv("CGC_JKU_FGRID")) : 512;
+  if (grid > fgrid) grid = fgrid;             // persistent over the 32-node tiles
   hipLaunchKernelGGL(k_jku_fwd<C>, dim3(grid), dim3(512), lds, st, xs, n, npad, w, out, HS, CS);
   CGC_RETURN_IF_LAUNCH_FAILED();
   return 0;
