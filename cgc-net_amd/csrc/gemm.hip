@@ -911,7 +911,12 @@ static int launch_cfg(const GemmArgs& a0, int transA, int transB, int batch, int
   // tail split: pipelined kernel only, long reductions only (a piece keeps >= 3 k-tiles), slabs must fit the workspace
   static const int split_on = getenv("CGC_GEMM_SPLIT") ? atoi(getenv("CGC_GEMM_SPLIT")) : 1;
   int extra = 0;
-  if (!short_k && ws != nullptr && split_on) {
+  // the smaller tile shapes hold more workgroups per CU than the 512 the split is sized for: they only split when the launch is
+  // clearly under-filled (the thin level-2 products of a 4-graph shard: 72 workgroups walking 36 k-tiles each = 36 us of pure
+  // latency; as 504 pieces of 5 k-tiles + fix-up: 14 us)
+  static const int small_max = getenv("CGC_GEMM_SMALL_SPLIT") ? atoi(getenv("CGC_GEMM_SMALL_SPLIT")) : 384;
+  const bool big = BM == 128 && BN == 128;
+  if (!short_k && ws != nullptr && split_on && (big || split_on >= 2 || tiles <= small_max)) {
     long long kt = ceil_div(k_extent, BK);
     for (int i = 0; i < a.nx; ++i) kt += ceil_div(a.xK[i], BK);
     const int s_max = (int)(kt / 3 < 12 ? kt / 3 : 12);
@@ -970,9 +975,9 @@ static int gemm_dispatch(GemmArgs& a, int transA, int transB, int batch, int max
 #ifdef CGC_GEMM_ONLY_128   // compile-time experiments on the dominant kernel alone (not part of the build)
   return launch_cfg<2, 2, 2, 2>(a, transA, transB, batch, ragged == 1 ? max_ragged : M, ragged >= 2 ? max_ragged : K, false, ws, ws_floats, stream);
 #endif
-  // the tail split is tuned for the 128 x 128 tile (512 resident workgroups); CGC_GEMM_SPLIT=2 lets every pipelined tile shape use it
-  static const int split_all = getenv("CGC_GEMM_SPLIT") ? atoi(getenv("CGC_GEMM_SPLIT")) >= 2 : 0;
-  float* const ws_any = split_all ? ws : nullptr;
+  // the tail split is tuned for the 128 x 128 tile (512 resident workgroups); the other pipelined tile shapes use it for under-filled
+  // launches only (launch_cfg; CGC_GEMM_SPLIT=2: always)
+  float* const ws_any = ws;
   if (ragged == 1 && (transA || a.gptr == nullptr)) return CGC_EINVAL;
   if (ragged == 2 && (!transA || transB || a.gptr == nullptr || a.nx > 0)) return CGC_EINVAL;
   if (ragged == 3 && (!transA || transB || a.nx > 0 || max_ragged <= 0 || K <= 0 || batch % ceil_div(K, max_ragged) != 0)) return CGC_EINVAL;

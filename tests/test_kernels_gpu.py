@@ -366,6 +366,39 @@ def test_gemm_extra_k_segments():
     close(want, manual, 2e-5, 'twin vs explicit formula')
 
 
+@pytest.mark.parametrize('cfg', [12, 13, 14, 15, 16])
+@pytest.mark.parametrize('tA,tB', [(False, False), (True, False), (False, True)])
+def test_gemm_small_tiles_split_when_underfilled(cfg, tA, tB):
+    """The smaller pipelined tile shapes (128x64, 64x128, 64x64, 128x32, 32x128) cut the tiles of an under-filled launch along K as
+    the 128 x 128 kernel does for its tail (the thin level-2 products of a small shard).  Against fp64, against the unsplit launch,
+    bitwise repeatable; beta / bias through the fix-up's epilogue; N = 40 leaves a ragged column tile."""
+    k = hip()
+    old = k.lib.cgc_gemm_tuning(cfg)
+    try:
+        batch, M, N, K = 3, 333, 40, 1140
+        A = rnd(batch, *((K, M) if tA else (M, K)), seed=1)
+        B = rnd(batch, *((N, K) if tB else (K, N)), seed=2)
+        C0, bias = rnd(batch, M, N, seed=3), rnd(N, seed=4)
+        want = torch.bmm(A.double().transpose(1, 2) if tA else A.double(), B.double().transpose(1, 2) if tB else B.double())
+        want = want + 0.5 * C0.double() + bias.double()
+        gA, gB = g(A), g(B)
+        lda, ldb = A.shape[2], B.shape[2]
+        outs = []
+        for split in (True, True, False):
+            k.tail_split = split
+            got = g(C0.clone())
+            k.gemm(gA, gB, got, M, N, K, tA, tB, lda, ldb, N, 1.0, 0.5, g(bias), batch, A.shape[1] * lda, B.shape[1] * ldb, M * N)
+            outs.append(got.cpu())
+    finally:
+        k.tail_split = True
+        k.lib.cgc_gemm_tuning(old)
+    assert torch.equal(outs[0], outs[1])
+    scale = float(want.abs().max())
+    for o in (outs[0], outs[2]):
+        assert float((o.double() - want).abs().max()) <= 2e-5 * scale
+    assert float((outs[0] - outs[2]).abs().max()) <= 1e-5 * scale
+
+
 TAIL_CASES = [
     # (M or rows/graph list, N, K, tA, tB, batch, ragged)  -- with the 128 x 128 pipelined kernel forced (cgc_gemm_tuning(11))
     (1000, 700, 500, False, False, 1, 0),        # 48 tiles < 512: every tile is a tail tile, 5 pieces
