@@ -219,9 +219,9 @@ def main():
     # ONE kernel over all parameters instead of ~16 multi-tensor launches (host-side cost matters at small per-GPU batches)
     if args.plain_adam:
         opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
-    else:       # torch's fused Adam kernel behind cgc_net_amd.optim.Adam: the same update, the parameter lists built once
+    else:       # the same update as torch's fused Adam, as ONE launch of the library's cgc_adam_step on the sequencer's flat gradient buffers
         from cgc_net_amd.optim import Adam
-        opt = Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
+        opt = Adam(model.parameters(), lr=1e-3, weight_decay=1e-4, model=model)
     torch.autograd.set_multithreading_enabled(False)     # backward on the calling thread: no engine-thread hand-off per node
 
     def step(b):

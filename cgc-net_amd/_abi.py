@@ -64,6 +64,7 @@ PROTOTYPES = {
     'cgc_adj_prep_bwd': [P, P, P, P, P, P, I, I, F, P, P],
     'cgc_head_fwd': [P, I, I, I, I, I, I, P, P, P, P, P, F, C.c_uint64, P, P, P, P],
     'cgc_head_bwd': [P, I, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P],
+    'cgc_adam_step': [P, P, I, P, D, D, D, D, D, F, F, P],
     'cgc_timing_create': [I],
     'cgc_timing_attach': [P],
     'cgc_timing_count': [P],

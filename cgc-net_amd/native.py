@@ -255,7 +255,7 @@ class _Level(Function):
         dev = saved.device
         stream = kernels.get()._stream()
         _, n_scratch, lay = _sizes(d)
-        grads = torch.empty(int(lay.total), dtype=torch.float32, device=dev)
+        grads = _grad_buffer(cfg.get('owner'), d.level, int(lay.total), dev)
         scratch = torch.empty(n_scratch, dtype=torch.float32, device=dev)
         D = d.H if d.jk else 2 * d.H + d.E
         d_readout = d_readout.contiguous().float()
@@ -269,6 +269,9 @@ class _Level(Function):
                                _p(scratch), _p(d_readout), _p(d_x_out), _p(d_A_out), _p(grads), _p(d_x_in), _p(d_A_in), stream)
         if rc != 0:
             raise RuntimeError('cgc_level_bwd failed with code %d' % rc)
+        owner = cfg.get('owner')
+        if owner is not None:            # the flat buffer of this level's gradients, for the one-launch optimiser (optim.Adam)
+            owner._flat_grads[d.level] = grads
         out = []
         offs = _param_offsets(d, lay)
         for present, shape, off in zip(ctx.mask, ctx.shapes, offs):
@@ -306,13 +309,45 @@ def _param_offsets(d, lay):
 
 def level(enc, desc, emb, pool, jk, g, gptr, x_in, A_in, assign=None, prep=None):
     """Run one level through the sequencer.  Returns (readout, x_out, A_out) (x_out / A_out None at the last level)."""
-    cfg = dict(desc=desc, emb=emb, pool=pool, jk=jk, graph=g, gptr=gptr, assign=assign, structs=prep['structs'] if prep else None)
+    cfg = dict(desc=desc, emb=emb, pool=pool, jk=jk, graph=g, gptr=gptr, assign=assign, structs=prep['structs'] if prep else None,
+               owner=enc)
     params = prep['params'] if prep else (_block_tensors(emb) + (_block_tensors(pool) if pool is not None else []) +
                                           (_jk_tensors(jk) if jk is not None else []))
+    _register_flat(enc, desc.level, params, lambda: _param_offsets(desc, _sizes(desc)[2]), lambda: _sizes(desc)[2].total)
     out = _Level.apply(cfg, x_in, A_in, *params)
     if desc.C:
         return out
     return out, None, None
+
+
+def _grad_buffer(owner, slot, n, dev):
+    """The flat gradient buffer of one level / of the head.  With an owner whose four sizes are known, the four are slices of ONE
+    buffer per backward pass (head first, level 1 last; each slice starts on a 256-byte boundary): data parallelism all-reduces that
+    one buffer in place and the optimiser reads it where it is.  A slot asked for twice means a new backward pass has begun."""
+    sizes = getattr(owner, '_flat_sizes', None) if owner is not None else None
+    if not sizes or len(sizes) != 4 or sizes.get(slot) != n:
+        return torch.empty(n, dtype=torch.float32, device=dev)
+    st = owner.__dict__.get('_step_flat')
+    if st is None or slot in owner._step_taken or st.device != dev:
+        total = sum(-(-sizes[s_] // 64) * 64 for s_ in range(4))
+        st = owner._step_flat = torch.empty(total, dtype=torch.float32, device=dev)
+        owner._step_taken = set()
+    owner._step_taken.add(slot)
+    o = sum(-(-sizes[s_] // 64) * 64 for s_ in range(slot))
+    return st[o:o + n]
+
+
+def _register_flat(enc, slot, params, offsets, total=None):
+    """Where the gradient of every parameter of this level (slot 1..3) / of the head (slot 0) will be found: (slot, element offset
+    into the slot's flat buffer).  Static for the life of the model -- the layout depends on widths only -- so it is recorded once."""
+    if enc is None:
+        return
+    if not hasattr(enc, '_flat_index'):
+        enc._flat_index, enc._flat_grads, enc._flat_sizes = {}, {}, {}
+    if slot in enc._flat_index:
+        return
+    enc._flat_index[slot] = [(p, int(off)) for p, off in zip(params, offsets()) if p is not None and off >= 0]
+    enc._flat_sizes[slot] = int(total())
 
 
 def dense_gptr(B, Cn, device):
@@ -357,7 +392,7 @@ class _Head(Function):
         xs = ctx.saved_tensors[4:]
         dev = ws.device
         Kin = nseg * D
-        grads = torch.empty(H1 * Kin + H1 + L_ * H1 + L_, dtype=torch.float32, device=dev)
+        grads = _grad_buffer(cfg.get('owner'), 0, H1 * Kin + H1 + L_ * H1 + L_, dev)
         scratch = torch.empty(B * L_ + B * H1, dtype=torch.float32, device=dev)
         dxs = [torch.empty(B, D, dtype=torch.float32, device=dev) for _ in range(nseg)]
         d_loss = d_loss.contiguous().float() if d_loss is not None else None
@@ -368,6 +403,9 @@ class _Head(Function):
                               _p(d_logits), _p(scratch), _p(grads), pdx, K._stream())
         if rc != 0:
             raise RuntimeError('cgc_head_bwd failed with code %d' % rc)
+        owner = cfg.get('owner')
+        if owner is not None:
+            owner._flat_grads[0] = grads
         o = 0
         dW1 = grads[o:o + H1 * Kin].view(H1, Kin)
         o += H1 * Kin
@@ -379,7 +417,7 @@ class _Head(Function):
         return (None, dW1, db1, dW2, db2) + tuple(dxs)
 
 
-def head(pred_model, readouts, labels, training):
+def head(pred_model, readouts, labels, training, owner=None):
     """``pred_model(cat(readouts))`` + mean cross-entropy through the fused head kernels; None when the head is not the
     Linear -> activation -> [Dropout] -> Linear stack they cover (the caller then runs the modules one by one)."""
     import torch.nn as nn
@@ -401,5 +439,8 @@ def head(pred_model, readouts, labels, training):
         return None
     # the mask is a function of (seed, element): the seed comes from torch's CPU generator (no device work; torch.manual_seed governs it)
     seed = int(torch.empty((), dtype=torch.int64).random_().item()) if drop_p > 0.0 else 0
-    cfg = dict(act=ACT_CODES[act], drop_p=drop_p, seed=seed, labels=labels.view(-1).contiguous())
+    cfg = dict(act=ACT_CODES[act], drop_p=drop_p, seed=seed, labels=labels.view(-1).contiguous(), owner=owner)
+    H1, Kin, L_ = l1.out_features, l1.in_features, l2.out_features
+    _register_flat(owner, 0, [l1.weight, l1.bias, l2.weight, l2.bias], lambda: [0, H1 * Kin, H1 * Kin + H1, H1 * Kin + H1 + L_ * H1],
+                   lambda: H1 * Kin + H1 + L_ * H1 + L_)
     return _Head.apply(cfg, l1.weight, l1.bias, l2.weight, l2.bias, *readouts)

@@ -579,7 +579,7 @@ class SoftPoolingGcnEncoder(nn.Module):
         out2, out3 = self._dense_levels(x, adj)
         if self.native_head and self.training and torch.is_grad_enabled() and out1.is_cuda and label.dtype == torch.int64:
             # head + mean cross-entropy as one kernel each way (native.head; csrc/head.hip)
-            res = native.head(self.pred_model, [out1, out2, out3], label, True)
+            res = native.head(self.pred_model, [out1, out2, out3], label, True, owner=self)
             if res is not None:
                 return res
         output = self._head([out1, out2, out3])

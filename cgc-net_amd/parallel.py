@@ -54,8 +54,30 @@ class DataParallel(nn.Module):
             self._pending = True
             Variable._execution_engine.queue_callback(self._allreduce_grads)
 
+    def _step_buffer(self):
+        """The ONE buffer the step sequencer left every gradient of this backward pass in (native._grad_buffer), or None when the
+        gradients are not (all) there: a model on the per-operator path, gradients accumulated over several passes."""
+        m = self.module
+        flat, index, taken = m.__dict__.get('_step_flat'), getattr(m, '_flat_index', None), getattr(m, '_step_taken', ())
+        if flat is None or not index or len(taken) != 4 or sum(len(v) for v in index.values()) != len(self._params):
+            return None
+        for slot, items in index.items():
+            p, off = items[0]
+            g, f = p.grad, m._flat_grads.get(slot)
+            if g is None or f is None or g.data_ptr() != f.data_ptr() + 4 * off:
+                return None
+            lo = f.data_ptr() - flat.data_ptr()
+            if lo < 0 or lo + 4 * f.numel() > 4 * flat.numel():
+                return None
+        return flat
+
     def _allreduce_grads(self):
         self._pending = False
+        step = self._step_buffer()
+        if step is not None:               # in place: no gather into a bucket, no scatter back (padding between the slices rides along)
+            dist.all_reduce(step, op=dist.ReduceOp.SUM, group=self.group)
+            step.div_(self._active)
+            return
         grads = [p.grad for p in self._params if p.grad is not None]
         if not grads:
             return

@@ -397,6 +397,25 @@ int cgc_head_bwd(const float* const* x, int nseg, int B, int D, int H1, int L, i
                  const int64_t* y, const float* ws, const float* logits, const float* dloss, const float* dlogits_ext,
                  float* scratch, float* grads, float* const* dx, cgc_stream_t stream);
 
+/* ==== The optimiser of the training step (common/utils.py:119-121: torch.optim.Adam(lr 1e-3, weight_decay 1e-4); train.py:183
+ * optimizer.step()) as ONE launch over all parameters.  The gradients of a level are one flat buffer (cgc_level_grad_layout), the
+ * head's another, so every parameter's gradient is (buffer index, offset): the caller builds two DEVICE tables once --
+ * segs[nseg] and blocks[nblocks] = (segment, chunk of 1024 elements) pairs covering every segment -- and a step passes the
+ * addresses of the (up to four) gradient buffers as a HOST array plus the scalars.  Update rule: Adam with the L2 penalty added to
+ * the gradient, bias-corrected with `step` (1, 2, ...); grad_mul scales the gradients first (1 / replicas after a summing
+ * all-reduce; 1.0 = none).  Mixed precision as torch's fused kernel (double hyper-parameters, float state). */
+typedef struct {
+  float* p;               /* parameter */
+  float* m;               /* exp_avg */
+  float* v;               /* exp_avg_sq */
+  int64_t off;            /* first element of the parameter's gradient inside its buffer */
+  int64_t n;              /* elements */
+  int32_t slot;           /* index into grad_buffers (0..3) */
+  int32_t reserved;
+} cgc_adam_seg;
+int cgc_adam_step(const void* segs, const void* blocks, int nblocks, const float* const* grad_buffers, double lr, double beta1,
+                  double beta2, double weight_decay, double eps, float step, float grad_mul, cgc_stream_t stream);
+
 /* ==== Measurement hook (csrc/timing.hip): HIP events around every launch of the dominant 128 x 128 GEMM (tag 1) and of the wide
  * SpMM (tag 2), recorded on the stream of the launch, whoever asked for it (per-operator call or step sequencer).  One observer
  * per process; nothing is recorded -- and nothing costs anything -- unless one is attached.  After the stream has been

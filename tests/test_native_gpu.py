@@ -228,24 +228,33 @@ def test_other_hidden_dims_stay_on_the_fused_jk_kernels(hidden):
         assert rel(p.grad, gr[k].grad) < 5e-4, (k, rel(p.grad, gr[k].grad))
 
 
-def test_cached_list_adam_equals_torch_fused_adam():
-    """cgc_net_amd.optim.Adam = torch.optim.Adam(fused=True) with the parameter lists built once: bitwise the same parameters and
-    optimiser state over steps, an LR change included."""
+@pytest.mark.parametrize('one_launch', [False, True])
+def test_adam_equals_torch_fused_adam(one_launch):
+    """cgc_net_amd.optim.Adam = torch.optim.Adam(fused=True): with the parameter lists built once, and -- given the model -- as one
+    launch of cgc_adam_step on the sequencer's flat gradient buffers.  Bitwise the same parameters and optimiser state over steps,
+    an LR change and a step with gradients accumulated over two backward passes (which the one-launch path must notice and leave
+    to torch's kernel) included."""
     from cgc_net_amd.optim import Adam
     ds = SyntheticCellGraphs(4, 200, num_features=16, base_seed=9)
     b = Batch.from_data_list([ds[i] for i in range(4)]).to(DEV)
     a, c = _pair((400, 16, 20, 20, True, True, 20, 3, 0.1, [50]), dict(concat=True, load_data_sparse=True, norm_adj=True, jk=True))
     c.native = True
-    oa, oc = Adam(a.parameters(), lr=1e-3, weight_decay=1e-4), torch.optim.Adam(c.parameters(), lr=1e-3, weight_decay=1e-4, fused=True)
-    for step in range(5):
+    oa = Adam(a.parameters(), lr=1e-3, weight_decay=1e-4, model=a if one_launch else None)
+    oc = torch.optim.Adam(c.parameters(), lr=1e-3, weight_decay=1e-4, fused=True)
+    fast = 0
+    for step in range(7):
         if step == 3:
             for o in (oa, oc):
                 o.param_groups[0]['lr'] = 5e-4
         for m, o in ((a, oa), (c, oc)):
-            _, loss = m(b)
             o.zero_grad()
-            loss.backward()
+            for _ in range(2 if step == 4 else 1):
+                _, loss = m(b)
+                loss.backward()
+            if o is oa and one_launch:
+                fast += int(oa._fast_ready())
             o.step()
+    assert fast == (5 if one_launch else 0)           # steps 1, 2, 3, 5, 6 (0 creates the state, 4 accumulates)
     for (k, p), (_, q) in zip(a.state_dict().items(), c.state_dict().items()):
         assert torch.equal(p, q), k
     sa, sc = oa.state_dict()['state'], oc.state_dict()['state']
