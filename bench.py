@@ -226,7 +226,8 @@ def main():
 
     def step(b):
         _, loss = dp(b)
-        loss = torch.mean(loss)
+        if loss.dim():                  # train.py:179 torch.mean(cls_loss): one loss per replica there, a scalar per process here
+            loss = torch.mean(loss)
         opt.zero_grad()
         loss.backward()
         opt.step()

@@ -350,6 +350,43 @@ def _register_flat(enc, slot, params, offsets, total=None):
     enc._flat_sizes[slot] = int(total())
 
 
+def static_flat(enc):
+    """Register the flat gradient layout of a model WITHOUT running it (it depends on widths only) and return the number of floats
+    of the per-pass gradient buffer (native._grad_buffer), or None when the step sequencer does not cover the model as configured.
+    parallel.DataParallel sizes its all-reduce by it, so that every rank issues the same collective whether its gradients came
+    out of the sequencer this step or not (a rank that idles through a step; a pass on the per-operator path)."""
+    import torch.nn as nn
+    if not getattr(enc, 'native', False) or not getattr(enc, 'native_head', False) or not enc.training:
+        return None
+    for level in (1, 2, 3):
+        emb = getattr(enc, 'GCN_embed_%d' % level, None)
+        pool = getattr(enc, 'GCN_pool_%d' % level, None) if level < 3 else None
+        jk = getattr(enc, 'jk%d' % level, None) if getattr(enc, 'jk', False) else None
+        if emb is None or not hasattr(emb, 'gcn1') or not hasattr(emb.gcn1, 'in_channels'):
+            return None
+        prep = prepared(enc, level, emb, pool, jk, emb.gcn1.in_channels)
+        if prep is None:
+            return None
+        d = LevelDesc.from_buffer_copy(prep['template'])
+        lay = _sizes(d)[2]
+        _register_flat(enc, level, prep['params'], lambda d=d, lay=lay: _param_offsets(d, lay), lambda lay=lay: lay.total)
+    layers = list(enc.pred_model) if isinstance(enc.pred_model, nn.Sequential) else [enc.pred_model]
+    if len(layers) not in (3, 4) or not isinstance(layers[0], nn.Linear) or not isinstance(layers[-1], nn.Linear):
+        return None
+    l1, l2 = layers[0], layers[-1]
+    H1, Kin, L_ = l1.out_features, l1.in_features, l2.out_features
+    _register_flat(enc, 0, [l1.weight, l1.bias, l2.weight, l2.bias], lambda: [0, H1 * Kin, H1 * Kin + H1, H1 * Kin + H1 + L_ * H1],
+                   lambda: H1 * Kin + H1 + L_ * H1 + L_)
+    if len(enc._flat_sizes) != 4:
+        return None
+    return sum(-(-enc._flat_sizes[s_] // 64) * 64 for s_ in range(4))
+
+
+def flat_slot_offset(enc, slot):
+    """First float of a slot inside the per-pass gradient buffer."""
+    return sum(-(-enc._flat_sizes[s_] // 64) * 64 for s_ in range(slot))
+
+
 def dense_gptr(B, Cn, device):
     return uniform_ptr(B, Cn, device)
 

@@ -34,6 +34,16 @@ class DataParallel(nn.Module):
         self.rank = dist.get_rank(process_group) if self.world > 1 else 0
         self._params = [p for p in module.parameters() if p.requires_grad]
         self._flat = None
+        # floats of the step sequencer's per-pass gradient buffer when it covers this model (else None): the all-reduce then has
+        # that size and layout on every rank, in place where the gradients are already there
+        self._seq_total = None
+        try:
+            from . import native
+            total = native.static_flat(module) if next(module.parameters()).is_cuda else None
+            if total is not None and sum(len(v) for v in module._flat_index.values()) == len(self._params):
+                self._seq_total = total
+        except (RuntimeError, OSError, AttributeError, StopIteration):
+            self._seq_total = None
         self._pending = False
         self._active = self.world        # ranks that received graphs in the current step (see local_chunk)
         if self.world > 1:
@@ -56,10 +66,10 @@ class DataParallel(nn.Module):
 
     def _step_buffer(self):
         """The ONE buffer the step sequencer left every gradient of this backward pass in (native._grad_buffer), or None when the
-        gradients are not (all) there: a model on the per-operator path, gradients accumulated over several passes."""
+        gradients are not (all) there: a pass on the per-operator path, gradients accumulated over several passes, an idle rank."""
         m = self.module
-        flat, index, taken = m.__dict__.get('_step_flat'), getattr(m, '_flat_index', None), getattr(m, '_step_taken', ())
-        if flat is None or not index or len(taken) != 4 or sum(len(v) for v in index.values()) != len(self._params):
+        flat, index, taken = m.__dict__.get('_step_flat'), m._flat_index, getattr(m, '_step_taken', ())
+        if flat is None or len(taken) != 4 or flat.numel() != self._seq_total:
             return None
         for slot, items in index.items():
             p, off = items[0]
@@ -73,10 +83,30 @@ class DataParallel(nn.Module):
 
     def _allreduce_grads(self):
         self._pending = False
-        step = self._step_buffer()
-        if step is not None:               # in place: no gather into a bucket, no scatter back (padding between the slices rides along)
-            dist.all_reduce(step, op=dist.ReduceOp.SUM, group=self.group)
-            step.div_(self._active)
+        if self._seq_total is not None:
+            step = self._step_buffer()
+            if step is not None:           # in place: no gather into a bucket, no scatter back (padding between the slices rides along)
+                dist.all_reduce(step, op=dist.ReduceOp.SUM, group=self.group)
+                step.div_(self._active)
+                return
+            # same collective, same layout, from wherever the gradients are (zeros where a parameter has none)
+            from . import native
+            m = self.module
+            dev = self.device
+            buf = torch.zeros(self._seq_total, dtype=torch.float32, device=dev)
+            views, grads = [], []
+            for slot, items in m._flat_index.items():
+                base = native.flat_slot_offset(m, slot)
+                for p, off in items:
+                    if p.grad is not None:
+                        views.append(buf[base + off:base + off + p.numel()].view_as(p))
+                        grads.append(p.grad)
+            if grads:
+                torch._foreach_copy_(views, grads)
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+            buf.div_(self._active)
+            if grads:
+                torch._foreach_copy_(grads, views)
             return
         grads = [p.grad for p in self._params if p.grad is not None]
         if not grads:

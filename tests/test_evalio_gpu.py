@@ -138,6 +138,22 @@ def test_data_parallel_wrapper_on_one_rank_rccl_group():
         gp = dict(plain.named_parameters())
         for k, p in wrapped_net.named_parameters():          # ... where SUM over one rank / 2 = half the plain gradient
             assert torch.allclose(p.grad * 2.0, gp[k].grad, rtol=1e-5, atol=1e-8), k
+        # the sequencer left every gradient in one buffer: that buffer was all-reduced in place
+        assert dp._seq_total is not None and dp._step_buffer() is not None and dp._step_buffer().numel() == dp._seq_total
+        # the same collective when the gradients are NOT there (a pass on the per-operator path, an idle rank): gathered into a bucket
+        # of the same layout, reduced, scattered back -- halved once more here
+        wrapped_net._step_flat = None
+        dp._allreduce_grads()
+        torch.cuda.synchronize()
+        for k, p in wrapped_net.named_parameters():
+            assert torch.allclose(p.grad * 4.0, gp[k].grad, rtol=1e-5, atol=1e-8), k
+        # a rank that received no graphs: zero loss through every parameter, zero gradients after the (bucket) all-reduce
+        for p in wrapped_net.parameters():
+            p.grad = None
+        _, idle_loss = dp._idle_step()
+        idle_loss.backward()
+        torch.cuda.synchronize()
+        assert all(p.grad is not None and float(p.grad.abs().max()) == 0.0 for p in wrapped_net.parameters())
         t = torch.ones(4, device=DEV)
         dist.all_reduce(t)
         assert float(t.sum()) == 4.0
