@@ -11,7 +11,7 @@ bash tools/prof_step.sh r03_b4 --batch 4 > /dev/null 2>&1
 bash tools/prof_gaps.sh r03_c3 > /dev/null 2>&1
 bash tools/prof_gaps.sh r03_b4 --batch 4 > /dev/null 2>&1
 PMC_PASSES=3 bash tools/pmc_run.sh r03_sq "" -- $B --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing > /dev/null 2>&1
-grep -E "^kernel|^k_gemm_f32<2, 2, 2, 2|^k_spmm_wide|^k_jk_bwd_mfma<20|^k_jk_fwd_mfma<20|^k_gemm_f32<2, 2, 1, 1|^k_gemm_f32<4, 1, 1, 1|^k_gemm_f32_shortk<2, 2, 2, 2|^k_sage_wide_fwd|^k_gemm_fixup" gpurun_out/r03_sq_pmc.txt > gpurun_out/r03_bench_c3_pmc_sq.txt
+grep -E "^kernel|^k_gemm_f32<2, 2, 2, 2|^k_spmm_wide|^k_jku_bwd<20|^k_jku_fwd<20|^k_gemm_f32<2, 2, 1, 1|^k_gemm_f32<4, 1, 1, 1|^k_gemm_f32_shortk<2, 2, 2, 2|^k_sage_wide_fwd|^k_gemm_fixup" gpurun_out/r03_sq_pmc.txt > gpurun_out/r03_bench_c3_pmc_sq.txt
 python profiles/make_counters_json.py gpurun_out/r03_bench_c3_pmc_sq.txt > gpurun_out/r03_counters.json
 bash tools/pmc_tcc.sh r03_tcc -- $B --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing > /dev/null 2>&1
 python profiles/make_traffic_json.py gpurun_out/r03_tcc_FETCH_SIZE gpurun_out/r03_tcc_WRITE_SIZE > gpurun_out/r03_traffic.json
