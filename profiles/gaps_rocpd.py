@@ -9,8 +9,8 @@ db = sqlite3.connect(sys.argv[1])
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 rows = db.execute('select s.kernel_name, d.start, d.end from rocpd_kernel_dispatch d '
                   'join rocpd_info_kernel_symbol s on d.kernel_id = s.id order by d.start').fetchall()
-marks = [i for i, r in enumerate(rows) if 'FusedOptimizerTensorListMetadata' in r[0]]
-# a step ends with the LAST fused-Adam kernel of its group (groups are consecutive multi_tensor launches)
+marks = [i for i, r in enumerate(rows) if 'FusedOptimizerTensorListMetadata' in r[0] or 'k_adam_segments' in r[0]]
+# a step ends with the LAST optimiser kernel of its group (torch: consecutive multi_tensor launches; the library: one k_adam_segments)
 ends = [i for k, i in enumerate(marks) if k + 1 == len(marks) or marks[k + 1] - i > 5]
 print('steps found:', len(ends))
 for a, b in list(zip(ends[:-1], ends[1:]))[-N:]:

@@ -21,7 +21,8 @@ kw = dict(concat=True, load_data_sparse=True)
 if '--shipped' in sys.argv:
     kw.update(norm_adj=True, jk=True, drop_out=0.2)
 model = network.SoftPoolingGcnEncoder(MAXN, 16, 20, 20, True, True, 20, 3, 0.1, [50], **kw).to(dev)
-opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4, fused=True)      # as bench.py
+from cgc_net_amd.optim import Adam  # noqa: E402
+opt = Adam(model.parameters(), lr=1e-3, weight_decay=1e-4, model=model)      # as bench.py
 torch.autograd.set_multithreading_enabled(False)                                       # backward on this thread: profiled too
 
 

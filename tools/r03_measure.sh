@@ -18,7 +18,7 @@ python profiles/make_traffic_json.py gpurun_out/r03_tcc_FETCH_SIZE gpurun_out/r0
 python profiles/summarize_pmc.py gpurun_out/r03_tcc_FETCH_SIZE gpurun_out/r03_tcc_WRITE_SIZE gpurun_out/r03_tcc_TCC --match "k_gemm_f32<2, 2, 2, 2" > gpurun_out/r03_bench_c3_pmc_traffic.txt 2>&1
 python profiles/summarize_pmc.py gpurun_out/r03_tcc_FETCH_SIZE gpurun_out/r03_tcc_WRITE_SIZE gpurun_out/r03_tcc_TCC --match "k_spmm_wide" >> gpurun_out/r03_bench_c3_pmc_traffic.txt 2>&1
 rm -rf gpurun_out/r03_tcc_FETCH_SIZE gpurun_out/r03_tcc_WRITE_SIZE gpurun_out/r03_tcc_TCC
-bash tools/prof_step.sh r03_c5 --nodes 8000 --feat 64 --maxn 16000 --steps 6 --warmup 2 --pool 2 > /dev/null 2>&1
+NSTEPS=8 bash tools/prof_step.sh r03_c5 --nodes 8000 --feat 64 --maxn 16000 --steps 6 --warmup 2 --pool 2 > /dev/null 2>&1
 CGC_NATIVE=0 python tools/gemm_time_shapes.py 32 > gpurun_out/r03_gemm_calls_by_shape.txt 2>&1
 python tools/gemm_tail_bench.py 4 8 16 32 > gpurun_out/r03_gemm_tail_split.txt 2>&1
 ls gpurun_out | grep r03_ | head -80
