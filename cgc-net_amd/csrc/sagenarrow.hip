@@ -80,16 +80,21 @@ __global__ __launch_bounds__(256) void k_sage_narrow_bwd(const SnBwdPtrs p0, con
   float db = 0.f;
   float* __restrict__ st = strip[wave];
 
+  const int fcl = fok ? f : 0, facl = f < fin ? f : 0;
   for (int tile = blockIdx.x * 4 + wave; tile < tiles; tile += gridDim.x * 4) {
     const int row0 = tile * 32;
     float dh[16], ag[16];
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
+      // (every load unconditional, from a clamped in-range address, then masked: a predicated load compiles to a branch per load
+      // and the 48 loads of a tile no longer travel together)
       const int row = row0 + 2 * s + half;
       const bool ok = row < n;
-      const float g = (ok && fok) ? dy[(size_t)row * ldy + f] : 0.f;
-      const float x = (ok && fok) ? hn[(size_t)row * F + f] : 0.f;
-      ag[s] = (ok && f < fin) ? agg[(size_t)row * lda + f] : 0.f;
+      const size_t rc = ok ? row : n - 1;
+      const float g_ = dy[rc * ldy + fcl], x_ = hn[rc * F + fcl], a_ = agg[rc * lda + facl];
+      const float g = (ok && fok) ? g_ : 0.f;
+      const float x = (ok && fok) ? x_ : 0.f;
+      ag[s] = (ok && f < fin) ? a_ : 0.f;
       float go = ca * g;
       if (mode == 2) go = go - cb - (act_fwd(x, ACT) - mu) * is * cc;
       go *= act_bwd(x, ACT);
@@ -97,7 +102,8 @@ __global__ __launch_bounds__(256) void k_sage_narrow_bwd(const SnBwdPtrs p0, con
       float o = go;
       if (normalize) {
         const float dot = half_sum(x * go);                                    // over the 32 columns of this row (inside the half)
-        const float r = ok ? rinv[row] : 1.f;
+        const float r_ = rinv[rc];
+        const float r = ok ? r_ : 1.f;
         const bool clamped = !(r < 1.f / L2_EPS);                              // ||h|| <= eps: F.normalize divided by eps
         o = clamped ? go * (1.f / L2_EPS) : r * (go - x * dot);
       }
@@ -120,10 +126,15 @@ __global__ __launch_bounds__(256) void k_sage_narrow_bwd(const SnBwdPtrs p0, con
       __builtin_amdgcn_wave_barrier();
       // D[row][k]: lane = k, register r = row (r&3) + 8(r>>2) + 4*half
       if (f < fin) {
+        if (row0 + 32 <= n) {        // whole tile inside the rows (wave-uniform): no per-store predicate
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          if (row < n) dagg[(size_t)row * ldd + f] = da[r];
+          for (int r = 0; r < 16; ++r) dagg[(size_t)(row0 + (r & 3) + 8 * (r >> 2) + 4 * half) * ldd + f] = da[r];
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (row < n) dagg[(size_t)row * ldd + f] = da[r];
+          }
         }
       }
     }
@@ -249,7 +260,8 @@ __global__ __launch_bounds__(256) void k_sage_narrow_fwd(const SnFwdPtrs p0, con
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       const int k = 2 * s + half;
-      av[s] = k < K ? a[k] : 0.f;
+      const float ld = a[k < K ? k : 0];             // (unconditional load + mask: a predicated load is a branch)
+      av[s] = k < K ? ld : 0.f;
     }
     floatx16 acc;
 #pragma unroll
@@ -257,9 +269,9 @@ __global__ __launch_bounds__(256) void k_sage_narrow_fwd(const SnFwdPtrs p0, con
 #pragma unroll
     for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bw[s], acc, 0, 0, 0);
     // lane = column f, register r = row (r&3) + 8(r>>2) + 4*half
+    float vv[16], rr[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
       float v = fok ? acc[r] : 0.f;
       float rin = 1.f;
       if (normalize) {
@@ -267,14 +279,37 @@ __global__ __launch_bounds__(256) void k_sage_narrow_fwd(const SnFwdPtrs p0, con
         rin = 1.f / fmaxf(sqrtf(q), L2_EPS);
         v *= rin;
       }
-      if (row < n) {
-        if (fok) {
-          const float o = act_fwd(v, ACT);
+      vv[r] = v;
+      rr[r] = rin;
+    }
+    if (row0 + 32 <= n) {          // whole tile inside the rows (wave-uniform): two lane predicates for 32 stores instead of 32
+      if (fok) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          const float o = act_fwd(vv[r], ACT);
           s1 += o;
           s2 = fmaf(o, o, s2);
-          hn[(size_t)row * F + f] = v;
+          hn[(size_t)row * F + f] = vv[r];
         }
-        if (f == 0) rinv_out[row] = rin;
+      }
+      if (f == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rinv_out[row0 + (r & 3) + 8 * (r >> 2) + 4 * half] = rr[r];
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (row < n) {
+          if (fok) {
+            const float o = act_fwd(vv[r], ACT);
+            s1 += o;
+            s2 = fmaf(o, o, s2);
+            hn[(size_t)row * F + f] = vv[r];
+          }
+          if (f == 0) rinv_out[row] = rr[r];
+        }
       }
     }
   }
