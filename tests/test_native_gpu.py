@@ -263,6 +263,35 @@ def test_adam_equals_torch_fused_adam(one_launch):
             assert torch.equal(sa[i][key], sc[i][key]), (i, key)
 
 
+def test_one_launch_adam_checkpoint_resume():
+    """state_dict() of the one-launch optimiser carries torch's per-parameter step counters (brought up to date from the host-side
+    count), and a fresh optimiser that loads it continues bit for bit like the uninterrupted run."""
+    from cgc_net_amd.optim import Adam
+    ds = SyntheticCellGraphs(4, 200, num_features=16, base_seed=11)
+    b = Batch.from_data_list([ds[i] for i in range(4)]).to(DEV)
+    a, c = _pair((400, 16, 20, 20, True, True, 20, 3, 0.1, [50]), dict(concat=True, load_data_sparse=True, norm_adj=True, jk=True))
+    c.native = True
+
+    def run(m, o, steps):
+        for _ in range(steps):
+            o.zero_grad()
+            _, loss = m(b)
+            loss.backward()
+            o.step()
+    oa = Adam(a.parameters(), lr=1e-3, weight_decay=1e-4, model=a)
+    run(a, oa, 5)                                              # uninterrupted: 5 steps
+    oc = Adam(c.parameters(), lr=1e-3, weight_decay=1e-4, model=c)
+    run(c, oc, 3)
+    ck = oc.state_dict()
+    assert all(float(st['step']) == 3.0 for st in ck['state'].values())
+    oc2 = Adam(c.parameters(), lr=1e-3, weight_decay=1e-4, model=c)
+    oc2.load_state_dict(ck)
+    run(c, oc2, 2)
+    for (k, p), (_, q) in zip(a.state_dict().items(), c.state_dict().items()):
+        assert torch.equal(p, q), k
+    assert all(float(st['step']) == 5.0 for st in oc2.state_dict()['state'].values())
+
+
 def test_composite_graph_build_equals_the_four_calls():
     from cgc_net_amd import kernels
     K = kernels.get()
