@@ -755,7 +755,8 @@ def test_fused_adjacency_preparation(B_, C, p, second_stream):
         close(x, y, 2e-5, 'adj_prep %d' % i)
 
 
-@pytest.mark.parametrize('C,n', [(8, 37), (20, 300), (16, 1500), (20, 2500), (4, 200), (12, 700), (6, 130), (24, 300), (32, 257)])
+@pytest.mark.parametrize('C,n', [(8, 37), (20, 300), (16, 1500), (20, 2500), (4, 200), (12, 700), (6, 130), (24, 300), (32, 257),
+                                 (20, 20011), (8, 9001)])        # (more 32-node tiles than persistent workgroups: 626 / 282 for 256)
 def test_dense_jk_kernels(C, n):
     """Fused bi-LSTM + attention (csrc/jk.hip, csrc/jk_mfma.hip) against the torch restatement, and that restatement against
     torch.nn.LSTM.  Every even channel count up to 32 is compiled in (--hidden-dim of train.py): C in 4/8/12/16/20 on the matrix-core
