@@ -26,6 +26,7 @@ class Adam(torch.optim.Adam):
         self._lists = None
         self._model = model
         self._table = None          # (segs, blocks, nblocks, sentinels) of the one-launch path
+        self._ptrs = None           # parameter addresses the table was built for
         self._t = None              # step count of the one-launch path (None: torch's step tensors are current)
         self.grad_mul = grad_mul    # parallel.DataParallel sets 1 / active replicas when it leaves the mean to the optimiser
 
@@ -43,7 +44,7 @@ class Adam(torch.optim.Adam):
         m = self._model
         index = getattr(m, '_flat_index', None)
         if not index or any(s not in (0, 1, 2, 3) for s in index):
-            return None
+            return False                  # (False: this model's gradients do not come out of the sequencer -- do not try again)
         where = {}
         for slot, items in index.items():
             for p, off in items:
@@ -51,7 +52,7 @@ class Adam(torch.optim.Adam):
         ps = self.param_groups[0]['params']
         if any(id(p) not in where or p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous() or 'exp_avg' not in self.state[p]
                for p in ps):
-            return None
+            return False
         dev = ps[0].device
         segs, blocks, sentinels, seen = [], [], {}, set()
         for i, p in enumerate(ps):
@@ -62,6 +63,7 @@ class Adam(torch.optim.Adam):
             if slot not in seen:
                 seen.add(slot)
                 sentinels[slot] = (p, off, p.data_ptr(), st['exp_avg'].data_ptr())
+        self._ptrs = [p.data_ptr() for p in ps]
         seg_t = torch.tensor(segs, dtype=torch.int64).view(-1, 6)
         packed = torch.zeros(len(ps), 6, dtype=torch.int64)        # cgc_adam_seg: 5 x 8 bytes + two int32
         packed[:, :5] = seg_t[:, :5]
@@ -70,15 +72,18 @@ class Adam(torch.optim.Adam):
         return (packed.to(dev), blk.to(dev), blk.shape[0], sentinels, dev)
 
     def _fast_ready(self):
-        if self._table is None:
+        if not self._table:
             return False
         flat = getattr(self._model, '_flat_grads', None)
         if not flat or self._table[4].index != torch.cuda.current_device():
             return False
+        # the table holds raw addresses: every parameter must still live where it did (model.to(), p.data = ..., assign=True loads)
+        if [p.data_ptr() for p in self.param_groups[0]['params']] != self._ptrs:
+            self._table = None               # rebuilt by the next step()
+            return False
         for slot, (p, off, pptr, mptr) in self._table[3].items():
             g, f = p.grad, flat.get(slot)
-            if (g is None or f is None or g.data_ptr() != f.data_ptr() + 4 * off or p.data_ptr() != pptr
-                    or self.state[p]['exp_avg'].data_ptr() != mptr):
+            if g is None or f is None or g.data_ptr() != f.data_ptr() + 4 * off or self.state[p]['exp_avg'].data_ptr() != mptr:
                 return False
         return True
 
@@ -113,6 +118,8 @@ class Adam(torch.optim.Adam):
             if self._model is not None and self._lists is not None and self._table is None:
                 self._table = self._build_table()
             return out
+        if self._model is not None and self._table is None and self._lists is not None:
+            self._table = self._build_table()          # (invalidated: parameters were moved)
         if self._model is not None and self._fast_ready():
             from . import kernels
             if self._t is None:                       # (one device read, the first time only)

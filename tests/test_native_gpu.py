@@ -292,6 +292,34 @@ def test_one_launch_adam_checkpoint_resume():
     assert all(float(st['step']) == 5.0 for st in oc2.state_dict()['state'].values())
 
 
+def test_one_launch_adam_notices_moved_parameters():
+    """The segment table holds raw parameter addresses: when the parameters move (model.to(...)) the next step must notice, fall
+    back, rebuild the table and stay bit for bit on torch's trajectory."""
+    from cgc_net_amd.optim import Adam
+    ds = SyntheticCellGraphs(4, 200, num_features=16, base_seed=12)
+    b = Batch.from_data_list([ds[i] for i in range(4)]).to(DEV)
+    a, c = _pair((400, 16, 20, 20, True, True, 20, 3, 0.1, [50]), dict(concat=True, load_data_sparse=True, norm_adj=True, jk=True))
+    c.native = True
+    oa = Adam(a.parameters(), lr=1e-3, weight_decay=1e-4, model=a)
+    oc = torch.optim.Adam(c.parameters(), lr=1e-3, weight_decay=1e-4, fused=True)
+    fast = []
+    for step in range(6):
+        if step == 3:
+            for m in (a, c):
+                m.to('cpu')
+                m.to(DEV)
+        for m, o in ((a, oa), (c, oc)):
+            o.zero_grad()
+            _, loss = m(b)
+            loss.backward()
+            if o is oa:
+                fast.append(bool(oa._fast_ready()))
+            o.step()
+    assert fast == [False, True, True, False, True, True]
+    for (k, p), (_, q) in zip(a.state_dict().items(), c.state_dict().items()):
+        assert torch.equal(p, q), k
+
+
 def test_composite_graph_build_equals_the_four_calls():
     from cgc_net_amd import kernels
     K = kernels.get()
