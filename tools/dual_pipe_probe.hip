@@ -48,9 +48,9 @@ int main() {
   (void)hipMalloc(&out, 1 << 20);
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-  const int iters = 4000, grid = 256;
+  const int iters = 20000, grid = 256;      // ~20 ms per launch, after a warm-up launch of the same length (the clock ramps over ms)
   for (int mode = 0; mode < 3; ++mode) {
-    hipLaunchKernelGGL(k_probe, dim3(grid), dim3(512), 0, 0, out, 100, mode);
+    hipLaunchKernelGGL(k_probe, dim3(grid), dim3(512), 0, 0, out, iters, mode);
     (void)hipDeviceSynchronize();
     (void)hipEventRecord(e0);
     hipLaunchKernelGGL(k_probe, dim3(grid), dim3(512), 0, 0, out, iters, mode);
