@@ -54,6 +54,16 @@ struct GemmArgs {
 };
 
 #define BK 32
+#ifdef CGC_GEMM_TRACE      // experiment build (tools/gemm_wg_timeline.py): per-workgroup timestamps of the 128 x 128 kernel's phases
+__device__ unsigned long long g_gemm_trace[65536][6];
+#define GT_MARK(slot_) \
+  if (TM == 2 && TN == 2 && threadIdx.x == 0 && blockIdx.x < 65536) g_gemm_trace[blockIdx.x][slot_] = wall_clock64();
+extern "C" int cgc_gemm_trace_read(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_gemm_trace), sizeof(unsigned long long) * 6 * (size_t)n);
+}
+#else
+#define GT_MARK(slot_)
+#endif
 enum { PH_FULL = 0, PH_MASK = 1, PH_ANY = 4 };   // flavours of a k-loop phase (k_gemm_f32)
 #define KC_LD 36   // LDS row stride (words) of a row-major [mn][k] tile: 16-byte aligned rows, conflict-free ds_read_b128
 
@@ -479,6 +489,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, float* __restri
 // contains no guarded loader and no conditional inside a k-loop phase.  !FAST: the guarded element-wise loaders throughout.
 template <int WGM, int WGN, int TM, int TN, bool TA, bool TB, bool FAST>
 __global__ __launch_bounds__(256, 2) void k_gemm_f32(const GemmArgs a) {   // 2 waves per SIMD = 2 workgroups per CU (the LDS budget)
+  GT_MARK(0)
   constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
   constexpr int LDA_S = TA ? BM + 4 : KC_LD;   // TA: A stored [K,M] -> k-major tile; else row-major [m][k]
   constexpr int LDB_S = TB ? KC_LD : BN + 4;   // TB: B stored [N,K] -> row-major [n][k]; else k-major
@@ -510,6 +521,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const GemmArgs a) {   // 2 
   if (m0 >= M) return;
   const int N = a.N;
 
+#ifdef CGC_GEMM_TRACE
+  if (TM == 2 && TN == 2 && threadIdx.x == 0 && blockIdx.x < 65536)
+    g_gemm_trace[blockIdx.x][5] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 4);
+#endif
   const bool vecA = (a.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) & 15u) == 0);
   const bool vecB = (a.ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(B) & 15u) == 0);
 
@@ -663,6 +678,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const GemmArgs a) {   // 2 
       if (kbeg + 1 < kend) fetch_seg(la0, lb0, seg, kbeg + 1, m0, a_last, n0, b_last);
     }
     __syncthreads();
+    GT_MARK(1)
     int kt = kbeg;
     const int fast_end = nk_full < kend ? nk_full : kend;
     for (; kt + 3 < fast_end; kt += 2) {     // both phases prefetch full tiles of the main pair (kt+2, kt+3 < nk_full)
@@ -696,6 +712,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const GemmArgs a) {   // 2 
     }
   }
 
+  GT_MARK(2)
   if (S > 1) {
     // piece of a tail tile: the raw accumulators go to this piece's slab (k_gemm_fixup adds the S slabs of the tile and applies
     // alpha / beta / bias).  Slab order = register order, 16 bytes per lane: every store instruction writes 1 KiB contiguous.
@@ -713,6 +730,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const GemmArgs a) {   // 2 
   // epilogue (the last phase ended with a barrier: nobody reads operand tiles any more, the LDS is free for the parking strips)
   static_assert(4 * 32 * (TN * 32 + 4) <= 2 * A_SZ + 2 * B_SZ, "epilogue parking region exceeds the operand LDS");
   gemm_epilogue<TM, TN>(a, C, M, N, m0 + wm * TM * 32, n0 + wn * TN * 32, acc, lds + wave * 32 * (TN * 32 + 4), lane);
+  GT_MARK(3)
 }
 
 // Second half of the tail split: the S slabs of a tail tile are added in piece order (fixed: the result does not depend on which
