@@ -213,3 +213,24 @@ def test_evaluate_protocol(torch_kernels):
     assert set(res) == {'patch_acc', 'img_acc', 'binary_acc'} and all(0.0 <= v <= 1.0 for v in res.values())
     assert sum(len(v) for v in vote.prediction.values()) == 12 and loader.dataset.epoch == 1     # 6 patches x 2 passes
     assert model.training                                                                     # mode restored
+
+
+def test_optimiser_wrapper_on_host_tensors():
+    """cgc_net_amd.optim.Adam without the step sequencer behind it (CPU tensors, an arbitrary module passed as ``model``): torch's
+    own Adam trajectory through the cached-list path; the one-launch path is never taken (there are no flat gradient buffers)."""
+    import torch
+    from cgc_net_amd.optim import Adam
+    torch.manual_seed(0)
+    a, b = torch.nn.Linear(5, 3), torch.nn.Linear(5, 3)
+    b.load_state_dict(a.state_dict())
+    oa = Adam(a.parameters(), lr=1e-2, weight_decay=1e-4, model=a)
+    ob = torch.optim.Adam(b.parameters(), lr=1e-2, weight_decay=1e-4)
+    x = torch.randn(7, 5)
+    for _ in range(4):
+        for m, o in ((a, oa), (b, ob)):
+            o.zero_grad()
+            m(x).pow(2).sum().backward()
+            o.step()
+    assert not oa._fast_ready()
+    assert torch.allclose(a.weight, b.weight, atol=1e-7) and torch.allclose(a.bias, b.bias, atol=1e-7)
+    assert all(float(st['step']) == 4.0 for st in oa.state_dict()['state'].values())
