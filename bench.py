@@ -276,7 +276,8 @@ def main():
                                       args.maxn, c1, int(c1 * 0.1), args.flags),
                        'global_batch': args.batch * (1 if strong else world), 'nodes_per_batch': round(nodes),
                        'parallelism': 'dp%d' % world, 'includes': 'CSR build + fwd + loss + bwd + grad all-reduce + Adam',
-                       'step_sequencer': bool(getattr(model, 'native', False)) and not args.graph, 'hipgraph_dense_levels': bool(args.graph), 'node_order': 'grid cells' if args.spatial else 'draw order', 'fused_adam': not args.plain_adam},
+                       'step_sequencer': bool(getattr(model, 'native', False)) and not args.graph, 'hipgraph_dense_levels': bool(args.graph), 'node_order': 'grid cells' if args.spatial else 'draw order', 'fused_adam': not args.plain_adam,
+                       'optimiser': 'torch.optim.Adam' if args.plain_adam else 'cgc_adam_step (one launch; torch fused Adam arithmetic)'},
         }
         if timer is not None:
             recs = timer.records()
