@@ -234,3 +234,29 @@ def test_optimiser_wrapper_on_host_tensors():
     assert not oa._fast_ready()
     assert torch.allclose(a.weight, b.weight, atol=1e-7) and torch.allclose(a.bias, b.bias, atol=1e-7)
     assert all(float(st['step']) == 4.0 for st in oa.state_dict()['state'].values())
+
+
+def test_per_pass_gradient_buffer_slices():
+    """native._grad_buffer: the head's and the three levels' flat gradient buffers are 256-byte-aligned slices of ONE buffer per
+    backward pass (what DataParallel all-reduces in place and cgc_adam_step reads); a slot asked for twice starts a new pass; an owner
+    without the four sizes, or an unexpected size, gets a private buffer."""
+    import torch
+    from cgc_net_amd import native
+
+    class Owner(object):
+        pass
+    o = Owner()
+    o._flat_sizes = {0: 9203, 1: 1500001, 2: 70000, 3: 333}
+    dev = torch.device('cpu')
+    bufs = [native._grad_buffer(o, s, o._flat_sizes[s], dev) for s in (0, 3, 2, 1)]      # the order backward visits them
+    base = o._step_flat
+    pad = lambda n: -(-n // 64) * 64
+    assert base.numel() == sum(pad(n) for n in o._flat_sizes.values()) and o._step_taken == {0, 1, 2, 3}
+    for s, b in zip((0, 3, 2, 1), bufs):
+        off = (b.data_ptr() - base.data_ptr()) // 4
+        assert off == sum(pad(o._flat_sizes[t]) for t in range(s)) and off % 64 == 0 and b.numel() == o._flat_sizes[s]
+    again = native._grad_buffer(o, 0, 9203, dev)                                         # the next backward pass
+    assert o._step_flat is not base and again.data_ptr() == o._step_flat.data_ptr() and o._step_taken == {0}
+    private = native._grad_buffer(o, 1, 123, dev)                                        # not the registered size
+    assert private.numel() == 123 and not (o._step_flat.data_ptr() <= private.data_ptr() < o._step_flat.data_ptr() + 4 * o._step_flat.numel())
+    assert native._grad_buffer(None, 0, 10, dev).numel() == 10
