@@ -87,6 +87,13 @@ class Adam(torch.optim.Adam):
                 return False
         return True
 
+    def _scale_grads(self):
+        """grad_mul on the paths that end in torch's kernels (the one-launch kernel applies it itself)."""
+        if self.grad_mul != 1.0:
+            grads = [p.grad for gr in self.param_groups for p in gr['params'] if p.grad is not None]
+            if grads:
+                torch._foreach_mul_(grads, self.grad_mul)
+
     def _flush_steps(self):
         """Bring torch's per-parameter ``step`` tensors up to date with the one-launch path's counter."""
         if self._t is not None:
@@ -110,9 +117,12 @@ class Adam(torch.optim.Adam):
         if (closure is not None or len(self.param_groups) != 1 or g.get('amsgrad') or g.get('maximize') or g.get('capturable')
                 or g.get('differentiable') or not isinstance(g['lr'], float)):
             self._flush_steps()
+            if closure is None:
+                self._scale_grads()
             return super().step(closure)
         if self._lists is None or self._lists[4] != len(g['params']):
             self._flush_steps()
+            self._scale_grads()
             out = super().step()                      # torch's own path creates the state on the first step
             self._lists = self._cache()
             if self._model is not None and self._lists is not None and self._table is None:
@@ -140,6 +150,7 @@ class Adam(torch.optim.Adam):
         grads = [p.grad for p in ps]
         if any(x is None for x in grads):
             self._lists = None
+            self._scale_grads()
             return super().step()
         if self.grad_mul != 1.0:
             torch._foreach_mul_(grads, self.grad_mul)

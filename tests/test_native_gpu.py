@@ -320,6 +320,32 @@ def test_one_launch_adam_notices_moved_parameters():
         assert torch.equal(p, q), k
 
 
+def test_one_launch_adam_gradient_scale():
+    """grad_mul (the 1 / replicas of a summing all-reduce folded into the optimiser): the one-launch kernel scales the gradient before
+    the weight decay is added, exactly as multiplying the gradients beforehand does."""
+    from cgc_net_amd.optim import Adam
+    ds = SyntheticCellGraphs(4, 200, num_features=16, base_seed=13)
+    b = Batch.from_data_list([ds[i] for i in range(4)]).to(DEV)
+    a, c = _pair((400, 16, 20, 20, True, True, 20, 3, 0.1, [50]), dict(concat=True, load_data_sparse=True, norm_adj=True, jk=True))
+    c.native = True
+    oa = Adam(a.parameters(), lr=1e-3, weight_decay=1e-4, model=a, grad_mul=0.25)
+    oc = torch.optim.Adam(c.parameters(), lr=1e-3, weight_decay=1e-4, fused=True)
+    used = 0
+    for step in range(4):
+        for m, o in ((a, oa), (c, oc)):
+            o.zero_grad()
+            _, loss = m(b)
+            loss.backward()
+            if o is oc:
+                torch._foreach_mul_([p.grad for p in c.parameters()], 0.25)
+            else:
+                used += int(oa._fast_ready())
+            o.step()
+    assert used == 3
+    for (k, p), (_, q) in zip(a.state_dict().items(), c.state_dict().items()):
+        assert torch.equal(p, q), k
+
+
 def test_composite_graph_build_equals_the_four_calls():
     from cgc_net_amd import kernels
     K = kernels.get()
