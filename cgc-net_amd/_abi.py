@@ -3,6 +3,8 @@ import ctypes as C
 
 P, I, F, D, L = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_int64
 
+ABI_VERSION = 2      # = CGC_ABI_VERSION of include/cgc_hip.h these prototypes were written against (tests compare the two)
+
 PROTOTYPES = {
     'cgc_abi_version': [],
     'cgc_csr_bad_edges_offset': [L, I, I],
@@ -83,7 +85,13 @@ PROTOTYPES = {
 
 
 def declare(lib):
-    """Attach argtypes/restype to every symbol; raises AttributeError if the library lacks one."""
+    """Attach argtypes/restype to every symbol; raises AttributeError if the library lacks one and RuntimeError if the library
+    was built from another revision of the header than these prototypes (a stale libcgc_hip.so next to newer Python)."""
+    lib.cgc_abi_version.argtypes, lib.cgc_abi_version.restype = [], C.c_int
+    got = lib.cgc_abi_version()
+    if got != ABI_VERSION:
+        raise RuntimeError('libcgc_hip.so reports ABI version %d, the bindings were written for %d: rebuild it (make -C cgc-net_amd/csrc)'
+                           % (got, ABI_VERSION))
     for name, argtypes in PROTOTYPES.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes

@@ -1,2 +1,2 @@
 #include "common.hpp"
-extern "C" int cgc_abi_version(void) { return 1; }
+extern "C" int cgc_abi_version(void) { return CGC_ABI_VERSION; }

@@ -20,6 +20,18 @@
 int cgc_timing_begin(int tag, int d0, int d1, int d2, int d3, int d4, int d5, int d6, hipStream_t stream);
 void cgc_timing_end(int idx, hipStream_t stream);
 
+// A kernel that needs more dynamic LDS than the 64 KB default has the limit raised once per DEVICE (function attributes are per
+// device; a process may drive several).  `done` = a zero-initialised static array of CGC_MAX_DEVICES flags owned by the call site.
+#define CGC_MAX_DEVICES 64
+static inline void cgc_allow_lds(const void* fn, int bytes, bool* done) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= CGC_MAX_DEVICES) dev = 0;
+  if (!done[dev]) {
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    done[dev] = true;
+  }
+}
+
 static inline hipStream_t as_stream(cgc_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }

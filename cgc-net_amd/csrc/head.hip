@@ -26,6 +26,19 @@ __device__ __forceinline__ float head_keep(unsigned long long seed, unsigned i, 
   return u < p ? 0.f : 1.f / (1.f - p);
 }
 
+// A label outside [0, L) contributes neither loss nor gradient and the mean runs over the remaining samples: F.cross_entropy's
+// ignore_index = -100 behaviour (model/network.py:289 passes no ignore_index, so -100 is the ignored value there too).  torch raises a
+// device-side assertion for any OTHER out-of-range label; here those are ignored as well rather than read out of bounds.
+__device__ __forceinline__ bool head_label_ok(const HeadArgs& a, int b) {
+  const long long y = a.y[b];
+  return y >= 0 && y < (long long)a.L;
+}
+__device__ __forceinline__ float head_valid_count(const HeadArgs& a) {
+  int valid = 0;
+  for (int b = 0; b < a.B; ++b) valid += head_label_ok(a, b) ? 1 : 0;
+  return (float)valid;
+}
+
 // z [B,H1] pre-activation, keep [B,H1] dropout scale, h [B,H1] = act(z) * keep, logits [B,L], loss [1]
 __global__ __launch_bounds__(256) void k_head_fwd_simple(HeadArgs a, float* __restrict__ z, float* __restrict__ keep, float* h,
                                                   float* logits, float* __restrict__ loss, float* lse) {
@@ -53,13 +66,17 @@ __global__ __launch_bounds__(256) void k_head_fwd_simple(HeadArgs a, float* __re
     for (int l = 0; l < a.L; ++l) m = fmaxf(m, logits[(size_t)b * a.L + l]);
     float s = 0.f;
     for (int l = 0; l < a.L; ++l) s += expf(logits[(size_t)b * a.L + l] - m);
-    lse[b] = m + logf(s) - logits[(size_t)b * a.L + (int)a.y[b]];
+    lse[b] = head_label_ok(a, b) ? m + logf(s) - logits[(size_t)b * a.L + (int)a.y[b]] : 0.f;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
     float s = 0.f;
-    for (int b = 0; b < a.B; ++b) s += lse[b];
-    loss[0] = s / (float)a.B;
+    int valid = 0;
+    for (int b = 0; b < a.B; ++b) {
+      s += lse[b];
+      valid += head_label_ok(a, b) ? 1 : 0;
+    }
+    loss[0] = s / (float)valid;
   }
 }
 
@@ -71,7 +88,7 @@ __global__ __launch_bounds__(256) void k_head_bwd_simple(HeadArgs a, const float
                                                   float* __restrict__ db1, float* __restrict__ dW2, float* __restrict__ db2, float* dx0,
                                                   float* dx1, float* dx2) {
   const int K = a.nseg * a.D;
-  const float g = (dloss != nullptr && a.y != nullptr) ? dloss[0] / (float)a.B : 0.f;
+  const float g = (dloss != nullptr && a.y != nullptr) ? dloss[0] / head_valid_count(a) : 0.f;
   for (int b = threadIdx.x; b < a.B; b += blockDim.x) {
     float m = -INFINITY;
     for (int l = 0; l < a.L; ++l) m = fmaxf(m, logits[(size_t)b * a.L + l]);
@@ -80,7 +97,7 @@ __global__ __launch_bounds__(256) void k_head_bwd_simple(HeadArgs a, const float
     const float inv = 1.f / s;
     for (int l = 0; l < a.L; ++l) {
       float v = 0.f;
-      if (a.y != nullptr) v = g * (expf(logits[(size_t)b * a.L + l] - m) * inv - ((int)a.y[b] == l ? 1.f : 0.f));
+      if (a.y != nullptr && head_label_ok(a, b)) v = g * (expf(logits[(size_t)b * a.L + l] - m) * inv - ((int)a.y[b] == l ? 1.f : 0.f));
       if (dlogits_ext != nullptr) v += dlogits_ext[(size_t)b * a.L + l];
       dl[(size_t)b * a.L + l] = v;
     }
@@ -172,7 +189,7 @@ __global__ __launch_bounds__(HEAD_THREADS) void k_head_fwd(HeadArgs a, float* __
     for (int l = 0; l < a.L; ++l) m = fmaxf(m, xs[b * a.L + l]);
     float s = 0.f;
     for (int l = 0; l < a.L; ++l) s += expf(xs[b * a.L + l] - m);
-    const float v = m + logf(s) - xs[b * a.L + (int)a.y[b]];
+    const float v = head_label_ok(a, b) ? m + logf(s) - xs[b * a.L + (int)a.y[b]] : 0.f;
     lse[b] = v;
     hs[b] = v;
   }
@@ -180,7 +197,7 @@ __global__ __launch_bounds__(HEAD_THREADS) void k_head_fwd(HeadArgs a, float* __
   if (threadIdx.x == 0) {
     float s = 0.f;
     for (int b = 0; b < a.B; ++b) s += hs[b];
-    loss[0] = s / (float)a.B;
+    loss[0] = s / head_valid_count(a);
   }
 }
 
@@ -194,7 +211,7 @@ __global__ __launch_bounds__(HEAD_THREADS) void k_head_bwd(HeadArgs a, const flo
   float* xs = sm;                          // [B][K]
   float* dzs = xs + (size_t)a.B * K;       // [B][H1]
   float* dls = dzs + (size_t)a.B * H1;     // [B][L]
-  const float g = (dloss != nullptr && a.y != nullptr) ? dloss[0] / (float)a.B : 0.f;
+  const float g = (dloss != nullptr && a.y != nullptr) ? dloss[0] / head_valid_count(a) : 0.f;
   for (int i = threadIdx.x; i < a.B * K; i += blockDim.x) xs[i] = head_x(a, i / K, i % K);
   for (int b = threadIdx.x; b < a.B; b += blockDim.x) {
     float m = -INFINITY;
@@ -204,7 +221,7 @@ __global__ __launch_bounds__(HEAD_THREADS) void k_head_bwd(HeadArgs a, const flo
     const float inv = 1.f / s;
     for (int l = 0; l < a.L; ++l) {
       float v = 0.f;
-      if (a.y != nullptr) v = g * (expf(logits[(size_t)b * a.L + l] - m) * inv - ((int)a.y[b] == l ? 1.f : 0.f));
+      if (a.y != nullptr && head_label_ok(a, b)) v = g * (expf(logits[(size_t)b * a.L + l] - m) * inv - ((int)a.y[b] == l ? 1.f : 0.f));
       if (dlogits_ext != nullptr) v += dlogits_ext[(size_t)b * a.L + l];
       dls[b * a.L + l] = v;
     }
@@ -270,11 +287,8 @@ extern "C" int cgc_head_fwd(const float* const* x, int nseg, int B, int D, int H
   const size_t m = (size_t)B * H1;
   const size_t lds = sizeof(float) * head_fwd_lds_floats(B, nseg * D, H1);
   if (lds <= 150 * 1024 && L <= nseg * D) {
-    static bool attr = false;
-    if (!attr) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_head_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-      attr = true;
-    }
+    static bool attr[CGC_MAX_DEVICES] = {};
+    cgc_allow_lds(reinterpret_cast<const void*>(&k_head_fwd), 150 * 1024, attr);
     hipLaunchKernelGGL(k_head_fwd, dim3(1), dim3(HEAD_THREADS), lds, as_stream(stream), a, ws, ws + m, ws + 2 * m, logits, loss, ws + 3 * m);
   } else {
     hipLaunchKernelGGL(k_head_fwd_simple, dim3(1), dim3(256), 0, as_stream(stream), a, ws, ws + m, ws + 2 * m, logits, loss, ws + 3 * m);
@@ -297,11 +311,8 @@ extern "C" int cgc_head_bwd(const float* const* x, int nseg, int B, int D, int H
   float* db2 = dW2 + (size_t)L * H1;
   const size_t lds = sizeof(float) * head_bwd_lds_floats(B, nseg * D, H1, L);
   if (lds <= 150 * 1024) {
-    static bool attr = false;
-    if (!attr) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_head_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-      attr = true;
-    }
+    static bool attr[CGC_MAX_DEVICES] = {};
+    cgc_allow_lds(reinterpret_cast<const void*>(&k_head_bwd), 150 * 1024, attr);
     hipLaunchKernelGGL(k_head_bwd, dim3(1), dim3(HEAD_THREADS), lds, as_stream(stream), a, ws, ws + m, ws + 2 * m, logits, dloss, dlogits_ext,
                        dW1, db1, dW2, db2, dx[0], nseg > 1 ? dx[1] : nullptr, nseg > 2 ? dx[2] : nullptr);
   } else {

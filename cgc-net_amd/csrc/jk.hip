@@ -309,12 +309,9 @@ extern "C" int cgc_jk_matrix_core(int C) { return C == 4 || C == 8 || C == 12 ||
 
 template <int C>
 static void jk_allow_lds() {      // the LDS image of the weights exceeds the 64 KB default for C >= 24
-  static bool done = false;
-  if (!done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_jk_fwd<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)JkDims<C>::lds_bytes);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_jk_bwd<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)JkDims<C>::lds_bytes);
-    done = true;
-  }
+  static bool done_f[CGC_MAX_DEVICES] = {}, done_b[CGC_MAX_DEVICES] = {};
+  cgc_allow_lds(reinterpret_cast<const void*>(&k_jk_fwd<C>), (int)JkDims<C>::lds_bytes, done_f);
+  cgc_allow_lds(reinterpret_cast<const void*>(&k_jk_bwd<C>), (int)JkDims<C>::lds_bytes, done_b);
 }
 
 template <int C>

@@ -1186,11 +1186,8 @@ static const int g_unit_split = getenv("CGC_JK_UNITSPLIT") ? atoi(getenv("CGC_JK
 template <int C>
 static int launch_fwd_us(const float* xs, int n, int npad, const JkWeights& w, float* out, float* HS, float* CS, hipStream_t st) {
   constexpr size_t lds = sizeof(float) * JkU<C>::FWD_TOTAL;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_jku_fwd<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  static bool attr_set[CGC_MAX_DEVICES] = {};
+  cgc_allow_lds(reinterpret_cast<const void*>(&k_jku_fwd<C>), (int)lds, attr_set);
   int grid = ceil_div(n, 32);
   static const int fgrid = getenv("CGC_JKU_FGRID") ? atoi(getenv("CGC_JKU_FGRID")) : 512;
   if (grid > fgrid) grid = fgrid;             // persistent over the 32-node tiles
@@ -1204,11 +1201,8 @@ template <int C>
 static int launch_bwd_us(const float* xs, const float* dout, int n, int npad, const JkWeights& w, const float* HS, const float* CS,
                          float* dxs, float* G, float* ws, hipStream_t st, float* flat) {
   constexpr size_t lds = sizeof(float) * JkU<C>::BWD_TOTAL;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_jku_bwd<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  static bool attr_set[CGC_MAX_DEVICES] = {};
+  cgc_allow_lds(reinterpret_cast<const void*>(&k_jku_bwd<C>), (int)lds, attr_set);
   int grid = ceil_div(n, 32);
   if (grid > 256) grid = 256;                 // one workgroup per CU (LDS), persistent over the tiles
   hipLaunchKernelGGL(k_jku_bwd<C>, dim3(grid), dim3(512), lds, st, xs, dout, n, npad, w, HS, CS, dxs, ws);
@@ -1231,12 +1225,8 @@ static int launch_bwd_us(const float* xs, const float* dout, int n, int npad, co
 template <int C>
 static int launch_fwd(const float* xs, int n, int npad, const JkWeights& w, float* out, float* HS, float* CS, hipStream_t st) {
   if (g_unit_split) return launch_fwd_us<C>(xs, n, npad, w, out, HS, CS, st);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_jk_fwd_mfma<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)JkM<C>::lds_bytes);
-    attr_set = true;
-  }
+  static bool attr_set[CGC_MAX_DEVICES] = {};
+  cgc_allow_lds(reinterpret_cast<const void*>(&k_jk_fwd_mfma<C>), (int)JkM<C>::lds_bytes, attr_set);
   const int ntiles = ceil_div(n, 32);
   int grid = ceil_div(ntiles, 2);
   if (grid > 512) grid = 512;                 // 2 workgroups per CU (LDS), persistent over the 64-node tile pairs
@@ -1263,11 +1253,8 @@ static int launch_bwd(const float* xs, const float* dout, int n, int npad, const
   if (PG && g_unit_split) return launch_bwd_us<C>(xs, dout, n, npad, w, HS, CS, dxs, G, ws, st, flat);
   size_t lds = sizeof(float) * (JkM<C>::TOTAL + JKB_TILES * 192) + sizeof(float4) * JKB_TILES * 2 * 3 * JkM<C>::XG * 64;
   if (PG) lds += sizeof(float) * JKB_TILES * 2 * 3 * 32 * 36;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_jk_bwd_mfma<C, PG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  static bool attr_set[CGC_MAX_DEVICES] = {};
+  cgc_allow_lds(reinterpret_cast<const void*>(&k_jk_bwd_mfma<C, PG>), (int)lds, attr_set);
   int grid = ceil_div(PG ? ceil_div(n, 32) : npad / 32, JKB_TILES);
   if (grid > 256) grid = 256;                 // one workgroup per CU
   hipLaunchKernelGGL((k_jk_bwd_mfma<C, PG>), dim3(grid), dim3(JKB_THREADS), lds, st, xs, dout, n, npad, w, HS, CS, dxs, DGT, INT, ws);

@@ -382,11 +382,8 @@ static int launch_slab(const int* rowptr, const int* col, const int* perm, const
                        const float* x, float* out, const int* gptr, int B, int nmax, int W, hipStream_t stream) {
   const int n_ctiles = ceil_div(W, T);
   const size_t lds = sizeof(float) * (size_t)nmax * T;
-  static bool attr_set = false;      // per instantiation; idempotent
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmm_slab<T, NTHR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  static bool attr_set[CGC_MAX_DEVICES] = {};      // per instantiation and device
+  cgc_allow_lds(reinterpret_cast<const void*>(&k_spmm_slab<T, NTHR>), 160 * 1024, attr_set);
   const int nb = ceil_div(B * n_ctiles, 8) * 8;
   hipLaunchKernelGGL((k_spmm_slab<T, NTHR>), dim3(nb), dim3(NTHR), lds, stream, rowptr, col, perm, val, pre, post, x, out, gptr, B, W, n_ctiles);
   CGC_RETURN_IF_LAUNCH_FAILED();

@@ -414,6 +414,8 @@ class _Head(Function):
         if rc != 0:
             raise RuntimeError('cgc_head_fwd failed with code %d' % rc)
         ctx.cfg, ctx.dims = cfg, (B, D, H1, L_, len(xs))
+        if cfg.get('owner') is not None:       # the workspace of the last head call (z | keep | h | per-sample losses): last_dropout_mask()
+            cfg['owner'].__dict__['_last_head'] = (ws, B, H1)
         ctx.save_for_backward(W1, W2, ws, logits, *xs)
         ctx.has_bias = (b1 is not None, b2 is not None)
         ctx.mark_non_differentiable()
@@ -452,6 +454,18 @@ class _Head(Function):
         o += L_ * H1
         db2 = grads[o:o + L_] if ctx.has_bias[1] else None
         return (None, dW1, db1, dW2, db2) + tuple(dxs)
+
+
+def last_dropout_mask(enc):
+    """The dropout keep-scale plane [B, H1] the fused head applied in ``enc``'s most recent training forward: 0 where a hidden unit
+    was dropped, 1 / (1 - p) where it was kept (all ones without dropout).  A view of the head's saved workspace (csrc/head.hip:
+    ``keep``): the mask-exact parity tests apply THIS mask to the module stack and to the oracle."""
+    ws, B, H1 = enc.__dict__['_last_head']
+    return ws[B * H1:2 * B * H1].view(B, H1)
+
+
+# per-encoder caches that must not travel with copy.deepcopy / pickle (ctypes structs hold raw pointers; the rest is rebuilt on use)
+TRANSIENT = ('_native_prepared', '_flat_index', '_flat_grads', '_flat_sizes', '_step_flat', '_step_taken', '_last_head')
 
 
 def head(pred_model, readouts, labels, training, owner=None):

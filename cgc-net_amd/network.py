@@ -331,6 +331,15 @@ class SoftPoolingGcnEncoder(nn.Module):
         self.reorder_large = os.environ.get('CGC_REORDER', '1') != '0'       # see _spatially_ordered
         self._unorder = None
 
+    def __getstate__(self):
+        """copy.deepcopy / pickle (EMA or best-model snapshots, torch.save(model)): the sequencer's per-encoder caches hold ctypes
+        structs with raw device pointers and views of one step's buffers -- they stay behind and are rebuilt on first use."""
+        state = self.__dict__.copy()
+        for k in native.TRANSIENT + ('last_graph',):
+            state.pop(k, None)
+        state['last_graph'] = None
+        return state
+
     def build_readout_module(self, pred_input_dim, pred_hidden_dims, label_dim, activation):
         if len(pred_hidden_dims) == 0:
             return nn.Linear(pred_input_dim, label_dim)

@@ -28,7 +28,10 @@ class Adam(torch.optim.Adam):
         self._table = None          # (segs, blocks, nblocks, sentinels) of the one-launch path
         self._ptrs = None           # parameter addresses the table was built for
         self._t = None              # step count of the one-launch path (None: torch's step tensors are current)
-        self.grad_mul = grad_mul    # parallel.DataParallel sets 1 / active replicas when it leaves the mean to the optimiser
+        self._uneven = False        # per-parameter step counts differ: the one-launch kernel (one count for all) is not used
+        # every gradient is multiplied by grad_mul inside the update (p.grad itself is left as it is).  For callers that keep SUMMED
+        # gradients and want the mean taken here; parallel.DataParallel does NOT use it -- it hands over averaged gradients
+        self.grad_mul = grad_mul
 
     # ---- torch's fused kernel on cached lists
     def _cache(self):
@@ -77,6 +80,10 @@ class Adam(torch.optim.Adam):
         flat = getattr(self._model, '_flat_grads', None)
         if not flat or self._table[4].index != torch.cuda.current_device():
             return False
+        # torch.optim.Adam skips a parameter without a gradient (frozen after the first step: requires_grad = False + zero_grad());
+        # the sequencer still writes that parameter's slice of the flat buffer, so the one-launch kernel must not run then
+        if any(p.grad is None for p in self.param_groups[0]['params']):
+            return False
         # the table holds raw addresses: every parameter must still live where it did (model.to(), p.data = ..., assign=True loads)
         if [p.data_ptr() for p in self.param_groups[0]['params']] != self._ptrs:
             self._table = None               # rebuilt by the next step()
@@ -87,12 +94,20 @@ class Adam(torch.optim.Adam):
                 return False
         return True
 
-    def _scale_grads(self):
-        """grad_mul on the paths that end in torch's kernels (the one-launch kernel applies it itself)."""
-        if self.grad_mul != 1.0:
-            grads = [p.grad for gr in self.param_groups for p in gr['params'] if p.grad is not None]
-            if grads:
-                torch._foreach_mul_(grads, self.grad_mul)
+    def _scaled_step(self, closure=None):
+        """torch's own step with grad_mul applied (the one-launch kernel applies it itself).  The caller's p.grad tensors are left
+        untouched: scaled copies stand in for them during the call."""
+        if self.grad_mul == 1.0 or closure is not None:
+            return super().step(closure)
+        ps = [p for gr in self.param_groups for p in gr['params'] if p.grad is not None]
+        keep = [p.grad for p in ps]
+        for p, g in zip(ps, torch._foreach_mul(keep, self.grad_mul) if keep else []):
+            p.grad = g
+        try:
+            return super().step()
+        finally:
+            for p, g in zip(ps, keep):
+                p.grad = g
 
     def _flush_steps(self):
         """Bring torch's per-parameter ``step`` tensors up to date with the one-launch path's counter."""
@@ -108,7 +123,7 @@ class Adam(torch.optim.Adam):
         return super().state_dict()
 
     def load_state_dict(self, state_dict):
-        self._t, self._table, self._lists = None, None, None
+        self._t, self._table, self._lists, self._uneven = None, None, None, False
         return super().load_state_dict(state_dict)
 
     @torch.no_grad()
@@ -117,23 +132,31 @@ class Adam(torch.optim.Adam):
         if (closure is not None or len(self.param_groups) != 1 or g.get('amsgrad') or g.get('maximize') or g.get('capturable')
                 or g.get('differentiable') or not isinstance(g['lr'], float)):
             self._flush_steps()
-            if closure is None:
-                self._scale_grads()
-            return super().step(closure)
-        if self._lists is None or self._lists[4] != len(g['params']):
+            return self._scaled_step(closure)
+        # (a parameter that gets its first gradient on a later step, or loses it: the cached lists are rebuilt)
+        if self._lists is not None and (self._lists[4] != len(g['params'])
+                                        or sum(p.grad is not None for p in g['params']) != len(self._lists[0])):
+            self._lists = None
+        if self._lists is None:
             self._flush_steps()
-            self._scale_grads()
-            out = super().step()                      # torch's own path creates the state on the first step
+            out = self._scaled_step()                 # torch's own path creates the state on the first step
             self._lists = self._cache()
             if self._model is not None and self._lists is not None and self._table is None:
                 self._table = self._build_table()
             return out
         if self._model is not None and self._table is None and self._lists is not None:
             self._table = self._build_table()          # (invalidated: parameters were moved)
-        if self._model is not None and self._fast_ready():
+        if self._model is not None and not self._uneven and self._t is None and self._fast_ready():
+            # (one device read, the first time only)  The kernel takes ONE step count for all parameters: if they differ -- a
+            # parameter sat out some steps without a gradient -- the bias corrections differ per parameter and torch's kernel stays
+            st = torch.stack([self.state[p]['step'] for p in g['params']])
+            lo, hi = float(st.min()), float(st.max())
+            if lo != hi:
+                self._uneven = True
+            else:
+                self._t = int(hi)
+        if self._model is not None and not self._uneven and self._fast_ready():
             from . import kernels
-            if self._t is None:                       # (one device read, the first time only)
-                self._t = int(self.state[g['params'][0]]['step'].item())
             self._t += 1
             flat = self._model._flat_grads
             segs, blocks, nblocks, _, dev = self._table
@@ -150,10 +173,9 @@ class Adam(torch.optim.Adam):
         grads = [p.grad for p in ps]
         if any(x is None for x in grads):
             self._lists = None
-            self._scale_grads()
-            return super().step()
+            return self._scaled_step()
         if self.grad_mul != 1.0:
-            torch._foreach_mul_(grads, self.grad_mul)
+            grads = list(torch._foreach_mul(grads, self.grad_mul))
         torch._foreach_add_(steps, 1)
         torch._fused_adam_(ps, grads, m, v, [], steps, amsgrad=False, lr=g['lr'], beta1=g['betas'][0], beta2=g['betas'][1],
                            weight_decay=g['weight_decay'], eps=g['eps'], maximize=False, grad_scale=None, found_inf=None)

@@ -10,9 +10,11 @@ broadcast all parameters, run replicas on threads, gather, reduce_add gradients 
   * the list of graphs is split with the same cumulative-node-count rule (data.partition_by_nodes) and each
     rank collates only its chunk (or, with ``shard_input=False``, the loader already hands each rank its own list),
   * graphs are independent, so the forward/backward data path needs no collective,
-  * at the end of backward ONE flat fp32 bucket holding every gradient is all-reduced (sum) over RCCL/xGMI and
-    divided by the world size -- the equal-weight mean the reference takes with ``torch.mean(cls_loss)``
-    (train.py:179).  BatchNorm statistics stay per rank, as they are per replica in the reference.
+  * at the end of backward ONE flat fp32 bucket holding every gradient is all-reduced over RCCL/xGMI into the equal-weight
+    mean over the replicas that ran -- what the reference takes with ``torch.mean(cls_loss)`` (train.py:179).  On RCCL that
+    is ONE collective (``ReduceOp.AVG``: the division happens inside the reduction kernel); a sum followed by a division
+    only where AVG does not exist (gloo) or where fewer replicas than ranks ran (the last partial batch of an epoch).
+    BatchNorm statistics stay per rank, as they are per replica in the reference.
 """
 import torch
 import torch.distributed as dist
@@ -46,6 +48,10 @@ class DataParallel(nn.Module):
             self._seq_total = None
         self._pending = False
         self._active = self.world        # ranks that received graphs in the current step (see local_chunk)
+        # ReduceOp.AVG exists on the nccl (= RCCL) backend only
+        self._has_avg = self.world > 1 and dist.get_backend(process_group) == 'nccl'
+        # time_allreduce(True): a HIP event pair on the current stream around every gradient exchange (bench.py's allreduce_ms)
+        self._events = None
         if self.world > 1:
             with torch.no_grad():                      # replicas start from rank 0's weights and buffers
                 for t in list(module.parameters()) + list(module.buffers()):
@@ -81,13 +87,42 @@ class DataParallel(nn.Module):
                 return None
         return flat
 
+    def time_allreduce(self, enabled=True):
+        """Record a HIP event pair around every gradient exchange from now on (on torch's current stream: the collective's own
+        stream is joined to it before the call returns).  allreduce_ms() reads them back."""
+        self._events = [] if enabled else None
+        return self
+
+    def allreduce_ms(self):
+        """Durations (ms) of the exchanges recorded since time_allreduce(); synchronises."""
+        if not self._events:
+            return []
+        torch.cuda.synchronize()
+        out = [a.elapsed_time(b) for a, b in self._events]
+        self._events = []
+        return out
+
+    def _mean_over_replicas(self, buf):
+        """buf <- sum over ranks / active replicas, in place."""
+        ev = None
+        if self._events is not None and buf.is_cuda:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        if self._has_avg and self._active == self.world:
+            dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=self.group)
+        else:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+            buf.div_(self._active)      # mean over the replicas that ran (train.py:179 torch.mean(cls_loss))
+        if ev is not None:
+            ev[1].record()
+            self._events.append(ev)
+
     def _allreduce_grads(self):
         self._pending = False
         if self._seq_total is not None:
             step = self._step_buffer()
             if step is not None:           # in place: no gather into a bucket, no scatter back (padding between the slices rides along)
-                dist.all_reduce(step, op=dist.ReduceOp.SUM, group=self.group)
-                step.div_(self._active)
+                self._mean_over_replicas(step)
                 return
             # same collective, same layout, from wherever the gradients are (zeros where a parameter has none)
             from . import native
@@ -103,8 +138,7 @@ class DataParallel(nn.Module):
                         grads.append(p.grad)
             if grads:
                 torch._foreach_copy_(views, grads)
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
-            buf.div_(self._active)
+            self._mean_over_replicas(buf)
             if grads:
                 torch._foreach_copy_(grads, views)
             return
@@ -119,8 +153,7 @@ class DataParallel(nn.Module):
             views.append(self._flat[off:off + g.numel()].view_as(g))
             off += g.numel()
         torch._foreach_copy_(views, grads)
-        dist.all_reduce(self._flat, op=dist.ReduceOp.SUM, group=self.group)
-        self._flat.div_(self._active)      # mean over the replicas that ran (train.py:179 torch.mean(cls_loss))
+        self._mean_over_replicas(self._flat)
         torch._foreach_copy_(grads, views)
 
     # ---- forward

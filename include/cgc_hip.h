@@ -9,7 +9,12 @@
  *   - all pointers are DEVICE pointers; float = fp32, int = int32 unless stated; matrices row-major with an
  *     explicit leading dimension ("ld", in elements) where one is taken, contiguous otherwise
  *   - every call enqueues kernels on `stream` and returns immediately: no allocation, no synchronisation,
- *     no ownership taken (workspaces are passed in); safe for concurrent callers and for hipGraph capture
+ *     no ownership taken (workspaces are passed in); safe for concurrent callers and for hipGraph capture.
+ *     The library keeps NO state between calls, with two stated exceptions: (1) the measurement hook at the end of
+ *     this header (cgc_timing_*): one process-wide observer pointer, NULL unless a benchmark attaches one -- while one is
+ *     attached the GEMM / SpMM launches additionally record HIP events on their stream (do not attach during hipGraph
+ *     capture); (2) per-device "dynamic LDS limit already raised" flags for the kernels that need more than 64 KB
+ *     (idempotent hipFuncSetAttribute, set on first use per device)
  *   - return value: 0 on success, a hipError_t (>0) from the launch, or a negative CGC_E* argument error
  */
 #ifndef CGC_HIP_H
@@ -30,6 +35,11 @@ typedef void* cgc_stream_t; /* hipStream_t */
 #define CGC_ACT_ELU 2
 #define CGC_ACT_LEAKYRELU 3  /* slope 0.01 */
 
+/* Bumped whenever an entry point is added, removed or changes its signature / semantics.  Bindings compare their own copy
+ * (cgc-net_amd/_abi.py: ABI_VERSION) with cgc_abi_version() of the library they loaded and refuse a mismatch.
+ *   1: rounds 1-3 (operators, step sequencer, head, optimiser, measurement hook)
+ *   2: round 4 (head: labels outside [0, L) are ignored like F.cross_entropy's ignore_index; additions listed in DESIGN.md) */
+#define CGC_ABI_VERSION 2
 int cgc_abi_version(void);
 
 /* ---- A1: graph structure.  Replaces to_dense_adj (model/utils.py:3-36, called at model/network.py:241).

@@ -1,0 +1,116 @@
+#!/usr/bin/env python
+"""Generate tests/golden/<case>_fp64.npz  (BUILD CONTAINER ONLY): the REFERENCE evaluated in float64.
+
+The fp32 fixtures (make_golden.py) carry the reference's own fp32 gradients; a gradient bar of 1e-4 cannot be held against
+those, because the reference's fp32 arithmetic is itself 2e-5 .. 6e-4 away from the exact value on some parameters and takes
+ReLU signs / max-readout winners that another fp32 evaluation may take differently (tests/discrete.py).  This script pins the
+yardstick of that bar to data the REFERENCE produced: it imports ``/root/reference/model/network.py`` (same stand-in package as
+make_golden.py), casts the module to float64 and runs it through its dense tuple input form
+``(x[B,N,F], adj[B,N,N], num_nodes, label)`` (model/network.py:253-256) -- adjacency from the reference's own
+``to_dense_adj`` (model/utils.py:3-36) -- on the inputs and the initial ``state_dict`` stored in ``<case>.npz``.  Stored:
+
+  out64/logits, out64/loss        float64 forward
+  grad64/<parameter>              float64 d loss / d parameter
+  pre64/<block>.gcn<k>            the value each block activation is applied to (model/network.py:114-116: the convolution
+                                  output, [B, N, F] in the dense layout) -- recorded by a forward-pre-hook on ``active<k>``
+  embed64/<level>                 the tensor each readout maximises over (model/network.py:264,275,284), [B, N, D]
+  win64/<level>                   its argmax over the node axis, [B, D]
+
+and asserts oracle/dense_ref.py (float64) == reference (float64) to 1e-11 on all of them.  Only the .npz files travel.
+"""
+import copy
+import json
+import os
+import sys
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path[:0] = [os.path.join(HERE, 'pyg_standin'), ROOT, os.path.join(ROOT, 'tests')]
+REF = os.environ.get('CGC_REFERENCE', '/root/reference')
+sys.path.append(REF)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+torch.Tensor.cuda = lambda self, *a, **k: self   # model/network.py:180
+
+from model import network as refnet  # noqa: E402  (the reference)
+from model.utils import to_dense_adj as ref_to_dense_adj  # noqa: E402
+from torch_geometric.utils import to_dense_batch  # noqa: E402  (stand-in; PyG 1.2.1 semantics: returns counts)
+from oracle import dense_ref  # noqa: E402
+from make_golden import build  # noqa: E402
+from util import CASES, load_case  # noqa: E402
+
+
+def run_reference64(ref, inp):
+    pre, embeds, hooks = {}, {}, []
+    for bname, blk in ref.named_children():
+        if not hasattr(blk, 'gcn1'):
+            continue
+        for k in (1, 2, 3):
+            def rec(mod, args, name='%s.gcn%d' % (bname, k)):
+                pre[name] = args[0].detach().clone()          # (the activation is in place: copy before it runs)
+            hooks.append(getattr(blk, 'active%d' % k).register_forward_pre_hook(rec))
+    for level in (1, 2, 3):
+        src = getattr(ref, 'jk%d' % level) if ref.jk else getattr(ref, 'GCN_embed_%d' % level)
+
+        def rec_out(mod, args, out, level=level):
+            embeds[level] = out.detach().clone()
+        hooks.append(src.register_forward_hook(rec_out))
+    try:
+        ref.train()
+        ref.zero_grad()
+        logits, loss = ref(inp)
+        loss.backward()
+    finally:
+        for h in hooks:
+            h.remove()
+    return logits.detach(), loss.detach(), pre, embeds
+
+
+def main():
+    worst = 0.0
+    for name in CASES:
+        cfg, batch, sd, _out, _grad, _sd3 = load_case(name)
+        ref = build(refnet.SoftPoolingGcnEncoder, cfg)
+        ref.load_state_dict(sd)
+        ref = ref.double()
+        ref.load_data_sparse = False
+        adj = ref_to_dense_adj(batch.edge_index, batch.batch).double()
+        x, counts = to_dense_batch(batch.x, batch.batch)
+        inp = (x.double(), adj.clone(), counts, batch.y.view(-1))
+        logits, loss, pre, embeds = run_reference64(ref, inp)
+        assert logits.dtype == torch.float64 and loss.dtype == torch.float64
+        fix = {'out64/logits': logits.numpy(), 'out64/loss': loss.numpy(), 'counts': np.asarray([int(c) for c in counts])}
+        for k, p in ref.named_parameters():
+            assert p.grad.dtype == torch.float64
+            fix['grad64/' + k] = p.grad.numpy().copy()
+        for k, v in pre.items():
+            fix['pre64/' + k] = v.numpy()
+        for level, e in embeds.items():
+            fix['embed64/%d' % level] = e.numpy()
+            fix['win64/%d' % level] = e.max(dim=1)[1].numpy()
+        # the oracle in float64 must be the same function
+        ora = build(dense_ref.SoftPoolingGcnEncoder, cfg)
+        ora.load_state_dict(sd)
+        ora = ora.double()
+        ora.load_data_sparse = False
+        ora.train()
+        ol, oloss = ora((x.double(), adj.clone(), counts, batch.y.view(-1)))
+        oloss.backward()
+        errs = [float((ol - logits).abs().max() / logits.abs().max()), float((oloss - loss).abs() / loss.abs())]
+        og = dict(ora.named_parameters())
+        for k, p in ref.named_parameters():
+            errs.append(float((og[k].grad - p.grad).abs().max() / max(float(p.grad.abs().max()), 1e-30)) if float(p.grad.abs().max()) > 1e-12 else 0.)
+        assert max(errs) < 1e-11, (name, max(errs))
+        worst = max(worst, max(errs))
+        path = os.path.join(HERE, name + '_fp64.npz')
+        np.savez_compressed(path, **fix)
+        print('%-16s loss64 %.12f  pre-activation layers %d  -> %s (%.1f KB)' % (name, float(loss), len(pre), os.path.relpath(path, ROOT),
+                                                                           os.path.getsize(path) / 1024))
+    print('oracle(fp64) vs reference(fp64): worst relative difference %.2e' % worst)
+
+
+if __name__ == '__main__':
+    main()

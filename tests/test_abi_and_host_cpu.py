@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(kernels.lib_path())
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.cgc_abi_version() == 1
+    assert lib.cgc_abi_version() == _abi.ABI_VERSION == int(re.search(r'#define CGC_ABI_VERSION (\d+)', header).group(1))
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason='only meaningful on a host without a GPU')
@@ -234,6 +234,45 @@ def test_optimiser_wrapper_on_host_tensors():
     assert not oa._fast_ready()
     assert torch.allclose(a.weight, b.weight, atol=1e-7) and torch.allclose(a.bias, b.bias, atol=1e-7)
     assert all(float(st['step']) == 4.0 for st in oa.state_dict()['state'].values())
+
+
+def test_optimiser_wrapper_late_gradients_and_grad_mul_on_host_tensors():
+    """(i) a parameter that receives its first gradient on a LATER step must start being updated then, as with torch.optim.Adam (the
+    cached parameter lists are rebuilt when the set of parameters with a gradient changes); (ii) grad_mul on the paths that end in
+    torch's kernels scales what the update sees and leaves the caller's p.grad untouched."""
+    import torch
+    from cgc_net_amd.optim import Adam
+
+    class Two(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a, self.b = torch.nn.Linear(4, 3), torch.nn.Linear(4, 3)
+
+        def forward(self, x, use_b):
+            return self.a(x) + (self.b(x) if use_b else 0.0)
+    torch.manual_seed(0)
+    m, r = Two(), Two()
+    r.load_state_dict(m.state_dict())
+    b0 = m.b.weight.detach().clone()
+    om = Adam(m.parameters(), lr=1e-2, weight_decay=1e-4, model=m, grad_mul=0.5)
+    orr = torch.optim.Adam(r.parameters(), lr=1e-2, weight_decay=1e-4)
+    x = torch.randn(6, 4)
+    for step in range(6):
+        use_b = step >= 2 and step != 4
+        for mod, o in ((m, om), (r, orr)):
+            o.zero_grad()
+            mod(x, use_b).pow(2).sum().backward()
+        before = [p.grad.clone() if p.grad is not None else None for p in m.parameters()]
+        for p in r.parameters():
+            if p.grad is not None:
+                p.grad.mul_(0.5)
+        om.step()
+        orr.step()
+        for p, g in zip(m.parameters(), before):
+            assert (p.grad is None) == (g is None) and (g is None or torch.equal(p.grad, g))       # the caller's gradients: untouched
+    for (k, p), (_, q) in zip(m.state_dict().items(), r.state_dict().items()):
+        assert torch.allclose(p, q, atol=1e-7), k
+    assert float((m.b.weight.detach() - b0).abs().max()) > 1e-3       # (b did move)
 
 
 def test_per_pass_gradient_buffer_slices():

@@ -370,3 +370,180 @@ def test_composite_graph_build_equals_the_four_calls():
         inv = torch.empty(n, device=DEV)
         K.csr_invdeg(s['rowptr'], val, n, inv)
         assert torch.equal(one['inv_d'][:n], inv) and int(one['bad_edges']) == 0
+
+
+class _FixedMask(torch.nn.Module):
+    """Stands in for nn.Dropout with the keep-scale plane the fused head actually applied (0 or 1/(1-p) per element)."""
+
+    def __init__(self, keep):
+        super().__init__()
+        self.keep = keep
+
+    def forward(self, h):
+        return h * self.keep.to(h.dtype)
+
+
+@pytest.mark.parametrize('p', [0.2, 0.5])
+def test_fused_head_dropout_is_mask_exact(p):
+    """The benchmarked arithmetic (parallel_train.sh:3 ``--drop 0.2``; model/network.py:230-231 nn.Dropout between the head's two
+    Linear layers), checked where it differs from drop_out = 0: the keep plane of the fused head (csrc/head.hip ``keep``) is read
+    back and (1) holds exactly 0 or fp32 1/(1-p), (2) keeps a fraction 1-p of the B x 50 hidden units within a 4-sigma binomial
+    band, (3) applied as a fixed mask to the registered module stack AND to the CPU oracle reproduces logits, loss and every
+    gradient, (4) the backward is zero exactly where the forward was dropped."""
+    from cgc_net_amd import native
+    from oracle import dense_ref
+    B = 32
+    ds = SyntheticCellGraphs(B, 60, num_features=16, base_seed=31)
+    cpu_batch = Batch.from_data_list([ds[i] for i in range(B)])
+    b = cpu_batch.to(DEV)
+    args = (128, 16, 20, 20, True, True, 20, 3, 0.1, [50])
+    kw = dict(concat=True, load_data_sparse=True, norm_adj=True, jk=True, drop_out=p)
+    nat, ref = _pair(args, kw, head=True)
+    ref.native, ref.native_head = True, False          # same levels (bitwise); the head through the registered modules
+    assert isinstance(nat.pred_model[2], torch.nn.Dropout) and nat.pred_model[2].p == p
+    torch.manual_seed(7)
+    ln, lossn = nat(b)
+    keep = native.last_dropout_mask(nat).clone()
+    lossn.backward()
+    # (1) values, (2) kept fraction
+    scale = (torch.ones((), dtype=torch.float32) / (torch.ones((), dtype=torch.float32) - torch.tensor(p, dtype=torch.float32))).item()
+    assert keep.shape == (B, 50)
+    vals = set(keep.unique().tolist())
+    assert vals == {0.0, scale}, (vals, scale)
+    n = keep.numel()
+    frac = float((keep != 0).float().mean())
+    assert abs(frac - (1 - p)) <= 4 * (p * (1 - p) / n) ** 0.5, (frac, p)
+    # (3a) the module stack with THIS mask
+    ref.pred_model[2] = _FixedMask(keep)
+    lr, lossr = ref(b)
+    lossr.backward()
+    rel = lambda x, y: float((x.double() - y.double()).abs().max() / (y.double().abs().max() + 1e-30))
+    assert rel(ln, lr) < 2e-6 and rel(lossn, lossr) < 2e-6, (rel(ln, lr), rel(lossn, lossr))
+    gr = dict(ref.named_parameters())
+    for k, q in nat.named_parameters():
+        if k.endswith('att.bias'):
+            assert float(q.grad.abs().max()) < 1e-6, k
+            continue
+        assert rel(q.grad, gr[k].grad) < (5e-6 if k.startswith('pred_model') else 1e-4), (k, rel(q.grad, gr[k].grad))
+    # (3b) the CPU oracle (the reference's algorithm) with THIS mask
+    ora = dense_ref.SoftPoolingGcnEncoder(*args, **dict(kw, gcn_name='SAGE'))
+    ora.load_state_dict({k: v.cpu() for k, v in nat.state_dict().items()})     # (weights unchanged so far: no optimiser step;
+    # the BatchNorm buffers advanced by one forward do not enter a training-mode forward)
+    ora.train()
+    ora.pred_model[2] = _FixedMask(keep.cpu())
+    ol, oloss = ora(cpu_batch)
+    oloss.backward()
+    assert rel(ln.cpu(), ol) < 1e-4 and rel(lossn.cpu(), oloss) < 1e-4
+    go = dict(ora.named_parameters())
+    for k, q in nat.named_parameters():
+        if k.endswith('att.bias'):
+            continue
+        assert rel(q.grad.cpu(), go[k].grad) < 5e-4, (k, rel(q.grad.cpu(), go[k].grad))
+    # (4) one graph: d loss / d b1[j] IS the hidden unit's upstream gradient -- exactly zero where the unit was dropped (and the whole
+    # row j of d W1 with it), non-zero for kept units with a positive pre-activation
+    one = Batch.from_data_list([ds[0]]).to(DEV)
+    nat.zero_grad()
+    torch.manual_seed(11)
+    _, l1 = nat(one)
+    k1 = native.last_dropout_mask(nat).clone()[0]
+    ws, _, H1 = nat.__dict__['_last_head']
+    z = ws[:H1].clone()
+    l1.backward()
+    db1, dW1 = nat.pred_model[0].bias.grad, nat.pred_model[0].weight.grad
+    dropped = k1 == 0
+    assert bool(dropped.any()) and bool((~dropped).any())
+    assert bool((db1[dropped] == 0).all()) and bool((dW1[dropped] == 0).all())
+    live = (~dropped) & (z > 0)
+    assert bool(live.any()) and bool((db1[live] != 0).all())
+
+
+def test_one_launch_adam_skips_a_parameter_frozen_mid_training():
+    """torch.optim.Adam does not touch a parameter without a gradient.  The sequencer still writes a frozen parameter's slice of the
+    flat gradient buffer, so the one-launch path must notice (p.grad is None after zero_grad()) and leave the step to torch's
+    kernel: bitwise torch's trajectory, frozen parameter and its moments unchanged."""
+    from cgc_net_amd.optim import Adam
+    ds = SyntheticCellGraphs(4, 200, num_features=16, base_seed=14)
+    b = Batch.from_data_list([ds[i] for i in range(4)]).to(DEV)
+    a, c = _pair((400, 16, 20, 20, True, True, 20, 3, 0.1, [50]), dict(concat=True, load_data_sparse=True, norm_adj=True, jk=True))
+    c.native = True
+    oa = Adam(a.parameters(), lr=1e-3, weight_decay=1e-4, model=a)
+    oc = torch.optim.Adam(c.parameters(), lr=1e-3, weight_decay=1e-4, fused=True)
+    fast, frozen_before = [], None
+    for step in range(8):
+        if step == 3:
+            for m in (a, c):
+                m.GCN_embed_2.gcn2.weight.requires_grad_(False)
+            frozen_before = a.GCN_embed_2.gcn2.weight.detach().clone()
+        if step == 5:
+            for m in (a, c):
+                m.GCN_embed_2.gcn2.weight.requires_grad_(True)
+        for m, o in ((a, oa), (c, oc)):
+            o.zero_grad()
+            _, loss = m(b)
+            loss.backward()
+            if o is oa:
+                fast.append(bool(oa._fast_ready()))
+            o.step()
+        if step == 4:
+            assert torch.equal(a.GCN_embed_2.gcn2.weight, frozen_before)
+    # (after the thaw the parameters' step counts differ -- one sat out two steps --, so torch's per-parameter bias corrections
+    # apply and the one-count kernel must stay out: oa._uneven)
+    assert fast[:6] == [False, True, True, False, False, True] and oa._uneven, fast
+    for (k, p), (_, q) in zip(a.state_dict().items(), c.state_dict().items()):
+        assert torch.equal(p, q), k
+
+
+def test_encoder_survives_deepcopy_and_pickle_after_native_steps():
+    """EMA / best-model snapshots: copy.deepcopy(model) and torch.save(model) after training steps on the sequencer (whose
+    per-encoder caches hold ctypes pointer structs) and after DataParallel-style static_flat()."""
+    import copy
+    import io
+    from cgc_net_amd import native
+    ds = SyntheticCellGraphs(3, 150, num_features=16, base_seed=15)
+    b = Batch.from_data_list([ds[i] for i in range(3)]).to(DEV)
+    m = network.SoftPoolingGcnEncoder(300, 16, 20, 20, True, True, 20, 3, 0.1, [50], concat=True, load_data_sparse=True, norm_adj=True,
+                                      jk=True, drop_out=0.2).to(DEV).train()
+    assert native.static_flat(m) is not None
+    _, loss = m(b)
+    loss.backward()
+    assert '_native_prepared' in m.__dict__
+    snap = copy.deepcopy(m)
+    buf = io.BytesIO()
+    torch.save(m, buf)
+    buf.seek(0)
+    loaded = torch.load(buf, weights_only=False)
+    for other in (snap, loaded):
+        assert '_native_prepared' not in other.__dict__
+        for (k, p), (_, q) in zip(m.state_dict().items(), other.state_dict().items()):
+            assert torch.equal(p, q), k
+        torch.manual_seed(3)
+        (lo, losso), calls = _used_native(other.train(), b)
+        assert calls == 3
+        torch.manual_seed(3)
+        lm, lossm = m(b)
+        assert torch.equal(lo, lm) and torch.equal(losso, lossm)
+
+
+def test_fused_head_ignores_labels_like_cross_entropy():
+    """F.cross_entropy (model/network.py:289) skips labels equal to ignore_index = -100 and averages over the others; the fused
+    head must do the same (it used to index its logits with the raw label)."""
+    B = 6
+    ds = SyntheticCellGraphs(B, 80, num_features=16, base_seed=41)
+    items = [ds[i] for i in range(B)]
+    b = Batch.from_data_list(items).to(DEV)
+    b.y = b.y.clone()
+    b.y.view(-1)[1] = -100
+    b.y.view(-1)[4] = -100
+    kw = dict(concat=True, load_data_sparse=True, norm_adj=True, jk=True, drop_out=0.)
+    nat, ref = _pair((160, 16, 20, 20, True, True, 20, 3, 0.1, [50]), kw, head=True)
+    ref.native, ref.native_head = True, False
+    ln, lossn = nat(b)
+    lr, lossr = ref(b)
+    lossn.backward()
+    lossr.backward()
+    rel = lambda x, y: float((x.double() - y.double()).abs().max() / (y.double().abs().max() + 1e-30))
+    assert torch.isfinite(lossn) and rel(ln, lr) < 2e-6 and rel(lossn, lossr) < 2e-6
+    gr = dict(ref.named_parameters())
+    for k, q in nat.named_parameters():
+        if k.startswith('pred_model'):
+            assert rel(q.grad, gr[k].grad) < 5e-6, (k, rel(q.grad, gr[k].grad))
