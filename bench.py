@@ -3,9 +3,16 @@
 
 Contract: ``python bench.py --gpus N --steps K --warmup W`` prints ONE JSON line on rank 0.  N>1 runs one rank per GPU over
 RCCL: either the driver starts the ranks (``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N``) or a plain
-``python bench.py --gpus N`` starts them itself.  ``--scaling weak`` (default): every GPU processes its own 32 graphs per step;
-``--scaling strong``: ONE global batch of 32 is split over the GPUs by cumulative node count, the reference's DataParallel
-scatter (train.py:276-287) -- 4 graphs per GPU at N=8.  A "step" is one pass of the hot path over one batch of synthetic
+``python bench.py --gpus N`` starts them itself.
+
+What an N>1 line measures (``--scaling both``, the default): the metric says "batch=32", and the reference's data parallelism
+is torch_geometric's DataParallel -- ONE list of ``batch_size`` graphs scattered over the GPUs by cumulative node count
+(train.py:178-179, 276-287) -- so the headline ``value`` is STRONG scaling: a global batch of 32 per step, 32/N graphs per GPU
+(4 at N=8), W warm-up + exactly K timed steps.  The same line also carries ``weak_value`` (every GPU processes its own 32
+graphs per step: a second leg of W + K steps, reported beside the headline, never instead of it), ``allreduce_ms`` (HIP events
+around the gradient exchange of the timed strong steps; mean over steps, max over ranks), ``rccl_ranks`` (the process group's
+size and backend as torch.distributed reports them) and ``ms_per_step_ranks`` (min / max over ranks of each rank's own clock).
+``--scaling strong`` / ``--scaling weak`` run one leg only.  A "step" is one pass of the hot path over one batch of synthetic
 cell graphs that is already resident in HBM: CSR build from ``edge_index`` (the reference densifies here), the full
 SoftPoolingGcnEncoder forward, cross-entropy, backward through every kernel, gradient all-reduce (N>1), Adam.
 
@@ -46,10 +53,11 @@ def parse():
     p.add_argument('--steps', type=int, default=20)
     p.add_argument('--warmup', type=int, default=5)
     p.add_argument('--batch', type=int, default=32, help="graphs per GPU per step (weak scaling) / per global step (strong scaling)")
-    p.add_argument('--scaling', choices=['weak', 'strong'], default='weak',
-                   help="'weak' (default): every GPU gets its own --batch graphs per step; 'strong': ONE global batch of --batch graphs "
-                        "per step is split over the GPUs by cumulative node count, as the reference's DataParallel scatter does "
-                        "(train.py:276-287)")
+    p.add_argument('--scaling', choices=['both', 'weak', 'strong'], default='both',
+                   help="N>1 only.  'strong': ONE global batch of --batch graphs per step is split over the GPUs by cumulative node "
+                        "count, as the reference's DataParallel scatter does (train.py:276-287); 'weak': every GPU gets its own --batch "
+                        "graphs per step; 'both' (default): the strong leg is the headline value, the weak leg is reported beside it "
+                        "(weak_value) in the same line")
     p.add_argument('--nodes', type=int, default=1800, help='mean nodes per graph')
     p.add_argument('--feat', type=int, default=16)
     p.add_argument('--maxn', type=int, default=11404, help="the reference's setting.max_num_nodes (fixes cluster counts)")
@@ -195,19 +203,20 @@ def main():
     # ---- synthetic workload: `pool` distinct batches, resident in HBM.  weak: per rank, seeded by rank; strong: the SAME
     # global batches on every rank, each rank keeping its chunk of the cumulative-node-count split (data.partition_by_nodes)
     from cgc_net_amd.data import partition_by_nodes
-    strong = args.scaling == 'strong' and world > 1
-    ds = SyntheticCellGraphs(args.pool * args.batch, args.nodes, args.feat, base_seed=0 if strong else 100000 * rank,
-                             spatial=args.spatial)
-    lists = [[ds[b * args.batch + i] for i in range(args.batch)] for b in range(args.pool)]
-    if strong:
-        chunks = [partition_by_nodes(l, world) for l in lists]
-        if any(len(c) != world for c in chunks):
-            raise SystemExit('cannot split %d graphs over %d ranks' % (args.batch, world))
-        lists = [c[rank] for c in chunks]
-    cpu_batches = [Batch.from_data_list(l) for l in lists]
-    batches = [b.to(dev) for b in cpu_batches]
-    nodes = sum(b.x.shape[0] for b in cpu_batches) / len(cpu_batches)
-    edges = sum(b.edge_index.shape[1] for b in cpu_batches) / len(cpu_batches)
+    legs = ['single'] if world == 1 else (['strong', 'weak'] if args.scaling == 'both' else [args.scaling])
+
+    def make_batches(leg):
+        strong_ = leg == 'strong'
+        ds = SyntheticCellGraphs(args.pool * args.batch, args.nodes, args.feat, base_seed=0 if (strong_ or world == 1) else 100000 * rank,
+                                 spatial=args.spatial)
+        lists_ = [[ds[b * args.batch + i] for i in range(args.batch)] for b in range(args.pool)]
+        if strong_:
+            chunks = [partition_by_nodes(l, world) for l in lists_]
+            if any(len(c) != world for c in chunks):
+                raise SystemExit('cannot split %d graphs over %d ranks' % (args.batch, world))
+            lists_ = [c[rank] for c in chunks]
+        cpu_ = [Batch.from_data_list(l) for l in lists_]
+        return lists_, cpu_, [b.to(dev) for b in cpu_]
 
     torch.manual_seed(0)
     model = make_model(args, network).to(dev)
@@ -215,6 +224,8 @@ def main():
     if args.graph:
         model.enable_graph_capture()           # levels 2-3 (fixed shapes per batch size): forward + backward as two hipGraphs
     dp = DataParallel(model) if world > 1 else model
+    if world > 1:
+        dp.time_allreduce(True)
     # the reference's optimiser (common/utils.py:119-121: Adam, lr 1e-3, weight decay 1e-4); fused=True is the same update as
     # ONE kernel over all parameters instead of ~16 multi-tensor launches (host-side cost matters at small per-GPU batches)
     if args.plain_adam:
@@ -233,34 +244,52 @@ def main():
         opt.step()
         return loss
 
-    for i in range(args.warmup):
-        step(batches[i % len(batches)])
-    kernels.get()
-    # HIP events around every launch of the dominant GEMM and of the wide SpMM (the library's measurement hook: recorded on the
-    # launch stream, also for launches issued by the step sequencer)
-    timer = None if args.no_kernel_timing else kernels.LaunchTimer(64 * args.steps + 64)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    if timer is not None:
-        timer.start()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        loss = step(batches[i % len(batches)])
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if timer is not None:
-        timer.stop()
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    if not torch.isfinite(loss).item():
-        raise SystemExit('non-finite loss')
+    def run_leg(leg, with_kernel_timing):
+        """W untimed + exactly K timed steps, bracketed by barrier + synchronize; returns the leg's measurements."""
+        lists_, cpu_, dev_ = make_batches(leg)
+        for i in range(args.warmup):
+            step(dev_[i % len(dev_)])
+        kernels.get()
+        if world > 1:
+            dp.allreduce_ms()               # (drop the warm-up steps' records)
+        # HIP events around every launch of the dominant GEMM and of the wide SpMM (the library's measurement hook: recorded on the
+        # launch stream, also for launches issued by the step sequencer)
+        timer_ = kernels.LaunchTimer(64 * args.steps + 64) if with_kernel_timing else None
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        if timer_ is not None:
+            timer_.start()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            loss_ = step(dev_[i % len(dev_)])
+        torch.cuda.synchronize()
+        own = time.perf_counter() - t0          # this rank's own clock: before it waits for the others
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if timer_ is not None:
+            timer_.stop()
+        res = dict(leg=leg, lists=lists_, cpu_batches=cpu_, timer=timer_, loss=loss_)
+        if world > 1:
+            ar = dp.allreduce_ms()
+            t = torch.tensor([el, own, -own, (sum(ar) / len(ar)) if ar else 0.0], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t[0])
+            res.update(own_max=float(t[1]), own_min=-float(t[2]), allreduce_ms=float(t[3]), allreduce_calls=len(ar))
+        res['elapsed'] = el
+        if not torch.isfinite(loss_).item():
+            raise SystemExit('non-finite loss')
+        return res
+
+    results = [run_leg(leg, (not args.no_kernel_timing) and i == 0) for i, leg in enumerate(legs)]
+    head = results[0]
+    strong = head['leg'] == 'strong'
+    elapsed, lists, cpu_batches, timer = head['elapsed'], head['lists'], head['cpu_batches'], head['timer']
+    nodes = sum(b.x.shape[0] for b in cpu_batches) / len(cpu_batches)
+    edges = sum(b.edge_index.shape[1] for b in cpu_batches) / len(cpu_batches)
 
     if rank == 0:
         graphs = args.batch * (1 if strong else world) * args.steps
@@ -279,6 +308,24 @@ def main():
                        'step_sequencer': bool(getattr(model, 'native', False)) and not args.graph, 'hipgraph_dense_levels': bool(args.graph), 'node_order': 'grid cells' if args.spatial else 'draw order', 'fused_adam': not args.plain_adam,
                        'optimiser': 'torch.optim.Adam' if args.plain_adam else 'cgc_adam_step (one launch; torch fused Adam arithmetic)'},
         }
+        if world > 1:
+            out['scaling_note'] = ("value = STRONG scaling: one global batch of %d graphs per step split over the %d ranks by cumulative node "
+                                   "count (the reference's DataParallel scatter, train.py:276-287)" % (args.batch, world)) if strong else \
+                                  'value = WEAK scaling: %d graphs per GPU per step' % args.batch
+            out['rccl_ranks'] = dist.get_world_size()
+            out['backend'] = dist.get_backend() + (' (= RCCL over xGMI on ROCm)' if dist.get_backend() == 'nccl' else '')
+            out['allreduce_ms'] = round(head['allreduce_ms'], 4)
+            out['allreduce'] = {'per_step': head['allreduce_calls'] / max(args.steps, 1), 'bytes': 4 * (getattr(dp, '_seq_total', None) or sum(p.numel() for p in model.parameters())),
+                                'op': 'AVG in place on the step sequencer\'s flat gradient buffer' if getattr(dp, '_has_avg', False) else 'SUM + divide',
+                                'timing': 'HIP events on the launch stream around dist.all_reduce, mean over the timed steps, max over ranks'}
+            out['ms_per_step_ranks'] = {'min': round(1e3 * head['own_min'] / args.steps, 3), 'max': round(1e3 * head['own_max'] / args.steps, 3)}
+            for r in results[1:]:
+                k = r['leg']
+                g_ = args.batch * (1 if k == 'strong' else world) * args.steps
+                out[k + '_value'] = round(g_ / r['elapsed'], 2)
+                out[k + '_ms_per_step'] = round(1e3 * r['elapsed'] / args.steps, 3)
+                out[k + '_allreduce_ms'] = round(r['allreduce_ms'], 4)
+                out[k + '_global_batch'] = args.batch * (1 if k == 'strong' else world)
         if timer is not None:
             recs = timer.records()
             per_step = len(recs) // args.steps if args.steps and len(recs) % max(args.steps, 1) == 0 else 0

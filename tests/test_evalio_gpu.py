@@ -161,19 +161,66 @@ def test_data_parallel_wrapper_on_one_rank_rccl_group():
         dist.destroy_process_group()
 
 
-def test_bench_self_launch_strong_scaling_two_ranks():
-    """`python bench.py --gpus 2` (no torchrun) starts its own ranks; --scaling strong splits ONE global batch.  Two ranks
-    share the one GPU of the test box over gloo (RCCL refuses duplicate devices); the 8-GPU RCCL run is the driver's."""
+def test_bench_self_launch_two_ranks_reports_strong_and_weak():
+    """`python bench.py --gpus 2` (no torchrun) starts its own ranks.  The default N>1 line says what it measures, both ways: the
+    headline ``value`` is STRONG scaling (ONE global batch split by cumulative node count, the reference's DataParallel scatter,
+    train.py:178-179,276-287) and the same line carries the weak-scaling leg, the HIP-event-timed gradient exchange, the size of the
+    process group and the per-rank clocks.  Two ranks share the one GPU of the test box over gloo (RCCL refuses duplicate
+    devices); the 8-GPU RCCL run is the driver's."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
-    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--oversubscribe', '--scaling', 'strong',
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--oversubscribe',
            '--steps', '3', '--warmup', '1', '--batch', '8', '--nodes', '300', '--maxn', '600', '--no-cpu-baseline', '--pool', '2']
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
-    line = [l for l in out.stdout.splitlines() if l.startswith('{')][-1]
-    rec = json.loads(line)
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1                                                     # ONE JSON line
+    rec = json.loads(lines[0])
     assert rec['n_gpus'] == 2 and rec['scaling'] == 'strong' and rec['config']['global_batch'] == 8
     assert rec['value'] > 0 and abs(rec['value'] - 8 * 3 / (rec['ms_per_step'] * 3e-3)) < 0.05 * rec['value']
+    assert 'STRONG' in rec['scaling_note']
+    assert rec['rccl_ranks'] == 2 and rec['backend'].startswith('gloo')
+    # the weak leg: 8 graphs per rank per step
+    assert rec['weak_global_batch'] == 16
+    assert rec['weak_value'] > 0 and abs(rec['weak_value'] - 16 * 3 / (rec['weak_ms_per_step'] * 3e-3)) < 0.05 * rec['weak_value']
+    # one gradient exchange per step, timed with events, shorter than the step it is part of
+    assert rec['allreduce']['per_step'] == 1.0 and rec['allreduce']['bytes'] > 0
+    assert 0.0 < rec['allreduce_ms'] < rec['ms_per_step'] and 0.0 < rec['weak_allreduce_ms'] < rec['weak_ms_per_step']
+    r = rec['ms_per_step_ranks']
+    assert 0.0 < r['min'] <= r['max'] <= rec['ms_per_step'] * 1.001
+
+
+def test_bench_single_leg_flags():
+    """--scaling strong / --scaling weak run one leg only (what profiles/ uses to look at one of them)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--oversubscribe', '--scaling', 'weak',
+           '--steps', '2', '--warmup', '1', '--batch', '4', '--nodes', '200', '--maxn', '400', '--no-cpu-baseline', '--pool', '2']
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+    assert rec['scaling'] == 'weak' and rec['config']['global_batch'] == 8 and 'strong_value' not in rec and 'weak_value' not in rec
+
+
+def test_one_epoch_example_runs_the_reference_training_loop():
+    """BASELINE.json configs[0]/[1] plumbing: examples/train_synthetic.py = the reference's loop (train.py:174-184: model(data) ->
+    torch.mean(cls_loss) -> zero_grad / backward / step, StepLR, evaluate) over 200 synthetic graphs of ~300 nodes, shipped flags
+    (parallel_train.sh:2-3: batch 4, --jk --norm_adj --drop 0.2), one epoch, through DataListLoader + DataParallel on the device."""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    out = subprocess.run([sys.executable, os.path.join(root, 'examples', 'train_synthetic.py')], env=env, capture_output=True, text=True,
+                         timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    m = re.search(r'epoch 0: avg loss ([0-9.]+), val acc ([0-9.]+), (\d+) graphs', out.stdout)
+    assert m, out.stdout[-2000:]
+    loss, acc, seen = float(m.group(1)), float(m.group(2)), int(m.group(3))
+    assert seen == 200 and 0.0 < loss < 2.0 and 0.0 <= acc <= 1.0          # (labels are random: the loss sits near ln 3)
