@@ -31,6 +31,7 @@ PROTOTYPES = {
     'cgc_reduce_batch_sum': [P, P, I, L, F, P],
     'cgc_reduce_batched': [P, P, I, I, I, F, P],
     'cgc_stats_blocks': [I, I],
+    'cgc_stats_ws_floats': [I, I],
     'cgc_l2norm_act_stats': [P, I, I, I, I, P, P, P, P, P],
     'cgc_bn_finalize': [P, I, D, F, F, P, P, P, P, P],
     'cgc_l2norm_act_bn': [P, I, I, I, I, P, P, P, D, F, F, P, P, P, P, P, P],

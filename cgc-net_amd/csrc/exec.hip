@@ -260,7 +260,7 @@ inline LayerP layer_params(const cgc_level_desc& d, const cgc_block_params* p, i
   return r;
 }
 
-inline size_t stats_ws_floats(int n, int F) { return (size_t)(cgc_stats_blocks(n, F) > 1 ? cgc_stats_blocks(n, F) : 1) * 2 * F + 4 * (size_t)F + 2; }
+inline size_t stats_ws_floats(int n, int F) { return (size_t)cgc_stats_ws_floats(n, F); }      // slots of doubles (rowops.hip)
 
 // y = BN(act(l2norm(agg W + b)))  (ops._SageProject.forward)
 int layer_fwd(const Ctx& c, const cgc_level_desc& d, const LayerP& p, const LayerS& s, const float* agg, int lda, int n, int fin, int F,

@@ -107,6 +107,22 @@ struct KContigLoader {
       reg[i] = *reinterpret_cast<const float4*>(base + (size_t)row * ld + k0 + (u % (BK / 4)) * 4);
     }
   }
+  // The same fetch as load_fast as a BUFFER load: the operand is described once by a resource descriptor in SGPRs (base, no bounds),
+  // a lane contributes a loop-invariant 32-bit byte offset (row clamp included) and the tile's k position is the instruction's
+  // scalar offset -- buffer_load_dwordx4 v, v_off, s[rsrc], s_k offen.  The k loop then contains no vector address arithmetic at
+  // all: on gfx950 the fp32 MFMA and the vector ALU do not overlap on a SIMD, so every v_lshl_add_u64 of the flat-address form (two
+  // per load) is time taken from the matrix pipe.
+  __device__ __forceinline__ void offsets(unsigned (&off)[PER_T], int ld, int row0, int row_last) const {
+#pragma unroll
+    for (int i = 0; i < PER_T; ++i) {
+      const int u = threadIdx.x + i * 256;
+      off[i] = (unsigned)min(row0 + u / (BK / 4), row_last) * (unsigned)ld * 4u + (unsigned)(u % (BK / 4)) * 16u;
+    }
+  }
+  static __device__ __forceinline__ unsigned tile_soffset(int /*ld*/, int k0) { return (unsigned)k0 * 4u; }   // bytes from the operand base
+  __device__ __forceinline__ void load_buf_part(int i, __amdgpu_buffer_rsrc_t rsrc, const unsigned (&off)[PER_T], unsigned soff) {
+    reg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[i], soff, 0));
+  }
   // Partial k-tile (k_lim % 4 == 0), still branch-free: units past the end of K re-read the last valid 16 bytes of their
   // row and are zeroed with a select -- the guarded loader above costs ~0.75 of a full tile's time on top of its own.
   // (k_lim need not be a multiple of 4 when the row stride is: the unit that straddles the end is read whole -- the tail of
@@ -177,6 +193,18 @@ struct MnContigLoader {
       const int c = min(col0 + (u % (COLS / 4)) * 4, col_last4);
       reg[i] = *reinterpret_cast<const float4*>(base + (size_t)(k0 + u / (COLS / 4)) * ld + c);
     }
+  }
+  // base (uniform) + per-lane 32-bit byte offset: see KContigLoader::offsets
+  __device__ __forceinline__ void offsets(unsigned (&off)[PER_T], int ld, int col0, int col_last4) const {
+#pragma unroll
+    for (int i = 0; i < PER_T; ++i) {
+      const int u = threadIdx.x + i * 256;
+      off[i] = (unsigned)(u / (COLS / 4)) * (unsigned)ld * 4u + (unsigned)min(col0 + (u % (COLS / 4)) * 4, col_last4) * 4u;
+    }
+  }
+  static __device__ __forceinline__ unsigned tile_soffset(int ld, int k0) { return (unsigned)k0 * (unsigned)ld * 4u; }
+  __device__ __forceinline__ void load_buf_part(int i, __amdgpu_buffer_rsrc_t rsrc, const unsigned (&off)[PER_T], unsigned soff) {
+    reg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[i], soff, 0));
   }
   // Partial k-tile: rows (k) past the end re-read row k_lim-1 and are zeroed.
   __device__ __forceinline__ void load_fast_masked(const float* __restrict__ base, int ld, int col0, int col_last4, int k0, int k_lim) {
@@ -619,13 +647,33 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const GemmArgs a) {   // 2 
   // (measured: the FAST kernel is 1-2 % faster on the step's big products -- the guarded tail was NOT what the K = 40 segment of
   // the assignment Linear paid for; that was round quantisation, see the tail split.  A variant with no conditional inside any
   // phase (separate STORE / LAST flavours, parity-alternating epilogue loop) compiled to 256 VGPRs + 500-800 spilled registers.)
+#ifndef CGC_GEMM_NOPIN      // (-DCGC_GEMM_NOPIN: the compiler's own order with flat-address loads, for A/B timing)
+  unsigned offA[LoaderA::PER_T], offB[LoaderB::PER_T];
+  __amdgpu_buffer_rsrc_t rsrcA, rsrcB;
+  if constexpr (FAST) {
+    la0.offsets(offA, a.lda, m0, a_last);
+    lb0.offsets(offB, a.ldb, n0, b_last);
+    // raw buffers over the main operand pair (stride 0, no range check to speak of; 0x00020000 = 32-bit data format)
+    rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, 0xffffffff, 0x00020000);
+    rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(B), 0, 0xffffffff, 0x00020000);
+  }
+#endif
   auto phase = [&](auto mode_c, int kt, auto cur_c, LoaderA& ls_a, LoaderB& ls_b, LoaderA& ll_a, LoaderB& ll_b) {
     constexpr int MODE = decltype(mode_c)::value;
     constexpr int cur = decltype(cur_c)::value;
     bool has_next = true;
     if constexpr (MODE == PH_FULL) {
-      ll_a.load_fast(A, a.lda, m0, a_last, (kt + 2) * BK);
-      ll_b.load_fast(B, a.ldb, n0, b_last, (kt + 2) * BK);
+#ifndef CGC_X_NOLOAD          // (CGC_X_*: timing experiments that break the result -- tools/variant_lib.sh; never defined in the build)
+#ifndef CGC_GEMM_NOPIN
+      if constexpr (FAST) {     // (issued inside the k groups below)
+        static_assert(LoaderA::PER_T <= BK / 8 && LoaderB::PER_T <= BK / 8, "one load per operand and k group");
+      } else
+#endif
+      {
+        ll_a.load_fast(A, a.lda, m0, a_last, (kt + 2) * BK);
+        ll_b.load_fast(B, a.ldb, n0, b_last, (kt + 2) * BK);
+      }
+#endif
     } else if constexpr (MODE == PH_MASK) {
       if (kt + 2 < kend) fetch_seg(ll_a, ll_b, seg, kt + 2, m0, a_last, n0, b_last);
       has_next = kt + 1 < kend;
@@ -644,12 +692,43 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const GemmArgs a) {   // 2 
     for (int j = 0; j < TN; ++j) fetch_frag<!TB, LDB_S>(bs + (TB ? j * 32 * KC_LD : j * 32), 0, l31, lhi, bv[0][j]);
 #pragma unroll
     for (int kb = 0; kb < BK / 8; ++kb) {
+#ifdef CGC_X_NOREAD
+      if (MODE != PH_FULL && kb + 1 < BK / 8) {
+#else
       if (kb + 1 < BK / 8) {
+#endif
 #pragma unroll
         for (int i = 0; i < TM; ++i) fetch_frag<TA, LDA_S>(as + (TA ? i * 32 : i * 32 * KC_LD), kb + 1, l31, lhi, av[(kb + 1) & 1][i]);
 #pragma unroll
         for (int j = 0; j < TN; ++j) fetch_frag<!TB, LDB_S>(bs + (TB ? j * 32 * KC_LD : j * 32), kb + 1, l31, lhi, bv[(kb + 1) & 1][j]);
       }
+#ifndef CGC_GEMM_NOPIN
+      if constexpr (MODE == PH_FULL && FAST) {
+        // pinned interleave (FULL phases): the k group's 16 MFMAs in four runs of TM*TN, and behind each run ONE kind of other work --
+        // the next group's fragment reads (issued above, in front of the first run), this group's share of the LDS writes of tile
+        // kt+1, this group's share of the global loads of tile kt+2 -- with a scheduling fence after each run, so that no more than
+        // a few non-matrix instructions ever sit between two MFMAs (the compiler's own order issues the tile's eight global loads
+        // back to back at the end of the phase)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[kb & 1][j][t], av[kb & 1][i][t], acc[i][j], 0, 0, 0);
+          if (t == 1) {
+            if (kb < LoaderA::PER_T) ls_a.store_part(kb, an);
+            if (kb < LoaderB::PER_T) ls_b.store_part(kb, bn);
+          }
+          if (t == 2) {
+            if (kb < LoaderA::PER_T) ll_a.load_buf_part(kb, rsrcA, offA, LoaderA::tile_soffset(a.lda, (kt + 2) * BK));
+            if (kb < LoaderB::PER_T) ll_b.load_buf_part(kb, rsrcB, offB, LoaderB::tile_soffset(a.ldb, (kt + 2) * BK));
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        continue;
+      }
+#endif
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -657,12 +736,20 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const GemmArgs a) {   // 2 
 #pragma unroll
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[kb & 1][j][t], av[kb & 1][i][t], acc[i][j], 0, 0, 0);   // C^T tile: see gemm_epilogue
+#ifdef CGC_X_NOWRITE
+      if (MODE != PH_FULL && has_next) {
+#else
       if (has_next) {
+#endif
         if (kb < LoaderA::PER_T) ls_a.store_part(kb, an);
         if (kb < LoaderB::PER_T) ls_b.store_part(kb, bn);
       }
     }
+#ifdef CGC_X_NOBAR
+    if (MODE != PH_FULL) __syncthreads();
+#else
     __syncthreads();
+#endif
   };
   typedef std::integral_constant<int, PH_FULL> FULL_;
   typedef std::integral_constant<int, PH_MASK> MASK_;
@@ -889,10 +976,16 @@ __global__ __launch_bounds__(256, 3) void k_gemm_f32_shortk(const GemmArgs a) {
 // floats, and rows long enough to hold the 16-byte group that straddles the end of an extent that is not a multiple of 4 (its
 // surplus elements only reach output rows / columns that are never stored, or k positions that the loader zeroes).  The ragged
 // extent (M of ragged 1, K of ragged 2) is always the ROW index of the operands it applies to, never the contiguous one.
-static bool gemm_all_fast(const GemmArgs& a, int transA, int transB, int batch) {
+static bool gemm_all_fast(const GemmArgs& a, int transA, int transB, int batch, long long max_rows, long long max_k) {
   auto up4 = [](int v) { return (v + 3) & ~3; };
   auto seg = [&](const float* A, const float* B, int lda, int ldb, long long sA, long long sB, int K) {
     if (lda % 4 != 0 || ldb % 4 != 0 || !aligned16(A) || !aligned16(B)) return false;
+    // per-lane byte offsets inside one batch item's operand are 32-bit (KContigLoader::offsets): rows x row stride must stay below 4 GiB
+    const long long rowsA = transA ? 32 : (a.ragged == 1 ? max_rows : a.M), rowsB = transB ? a.N : 32;
+    if (rowsA * lda * 4 >= (1LL << 32) || rowsB * ldb * 4 >= (1LL << 32)) return false;
+    // ... and so is the scalar k offset of a tile (k rows x row stride when k is the operand's row index)
+    const long long kmax = a.ragged >= 2 ? max_k : K;
+    if ((transA ? kmax * lda : kmax) * 4 >= (1LL << 31) || (transB ? kmax : kmax * ldb) * 4 >= (1LL << 31)) return false;
     if (batch > 1 && (sA % 4 != 0 || sB % 4 != 0)) return false;
     if (transA ? lda < up4(a.M) : lda < up4(K)) return false;      // (ragged 1: transA = 0; ragged 2: transA = 1, K is the row index)
     if (transB ? ldb < up4(K) : ldb < up4(a.N)) return false;
@@ -953,7 +1046,7 @@ static int launch_cfg(const GemmArgs& a0, int transA, int transB, int batch, int
                        ? cgc_timing_begin(CGC_TAG_GEMM_128, a.M, a.N, a.K, batch, a.ragged, a.ragged ? (a.ragged == 1 ? m_extent : k_extent) : 0, xk, stream)
                        : -1;
   static const int fast_on = getenv("CGC_GEMM_FAST") ? atoi(getenv("CGC_GEMM_FAST")) : 1;   // CGC_GEMM_FAST=0: A-B timing against the guarded kernel
-  const bool fast = fast_on && gemm_all_fast(a, transA, transB, batch);
+  const bool fast = fast_on && gemm_all_fast(a, transA, transB, batch, m_extent, k_extent);
   if (short_k) {
     if (!transA && !transB) hipLaunchKernelGGL((k_gemm_f32_shortk<WGM, WGN, TM, TN, false, false>), grid, block, 0, stream, a);
     else if (!transA) hipLaunchKernelGGL((k_gemm_f32_shortk<WGM, WGN, TM, TN, false, true>), grid, block, 0, stream, a);

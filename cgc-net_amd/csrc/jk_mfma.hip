@@ -49,7 +49,19 @@ __device__ __forceinline__ float fast_tanh(float x) { return tanhf(x); }
 #define JK_EXP expf
 #else
 __device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.f + __expf(-x)); }
-__device__ __forceinline__ float fast_tanh(float x) { return 2.f * __frcp_rn(1.f + __expf(-2.f * x)) - 1.f; }
+// tanh with a few ulp of RELATIVE error everywhere.  The one-line form 2 / (1 + exp(-2x)) - 1 has ~2e-7 of ABSOLUTE error, i.e.
+// 2e-6 relative at |x| = 0.1 and 2e-4 at 1e-3 -- cell states and gate inputs of a freshly initialised LSTM are that small, and on
+// the reference-generated medium_shipped fixture the network amplifies it a thousandfold (a one-ulp perturbation of the parameters
+// moves d loss / d GCN_embed_3.gcn1.bias by 2.5e-4 of its max-norm): 1.5e-4 against the reference in float64, 4e-5 with this form
+// (same as libm's tanhf).  |x| >= 1/4: (1 - e) / (1 + e) with e = exp(-2|x|) <= 0.61 (no cancellation); below: the odd Taylor
+// polynomial to x^9 (truncation 9e-9 relative at 1/4).  Branch-free: both are computed, six FMAs more than before.
+__device__ __forceinline__ float fast_tanh(float x) {
+  const float ax = fabsf(x), x2 = x * x;
+  const float e = __expf(-2.f * ax);
+  const float big = (1.f - e) * __frcp_rn(1.f + e);
+  const float small = ax * fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, 62.f / 2835.f, -17.f / 315.f), 2.f / 15.f), -1.f / 3.f), 1.f);
+  return copysignf(ax < 0.25f ? small : big, x);
+}
 #define JK_EXP __expf
 #endif
 

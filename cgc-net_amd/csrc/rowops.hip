@@ -53,14 +53,57 @@ __device__ __forceinline__ void col_reduce_store(float (&acc)[NQ][MAXJ][VEC], in
   }
 }
 
+// The forward BatchNorm statistics (sum of o, sum of o^2 per column) are accumulated in DOUBLE from the first addition on: the
+// variance is formed as E[o^2] - E[o]^2, and on the coarsened levels the rows of a batch are nearly identical (std << |mean|), so
+// partial sums carried in fp32 -- 1e-7 relative each -- left the variance with 1e-7 * mean^2 / var of relative error: 3e-4 on the
+// gradients of a level-2 block of the reference-generated `tiny_shipped` fixture (tools/parity_bisect.py), 20x what a one-ulp
+// perturbation of the parameters produces.  o and o^2 are exact in double; slots hold doubles (4F floats of workspace per slot).
+// One quantity at a time through LDS (3 F doubles).
+template <int VEC, int MAXJ>
+__device__ __forceinline__ void col_reduce_store_f64(double (&acc)[2][MAXJ][VEC], int F, int lpr, double* smem, double* slot) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j)
+#pragma unroll
+      for (int v = 0; v < VEC; ++v)
+        for (int o = 32; o >= lpr; o >>= 1) acc[q][j][v] += __shfl_xor(acc[q][j][v], o);
+    if (q > 0) __syncthreads();
+    if (wave > 0 && lane < lpr) {
+#pragma unroll
+      for (int j = 0; j < MAXJ; ++j)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          const int c = (lane + lpr * j) * VEC + v;
+          if (c < F) smem[(wave - 1) * F + c] = acc[q][j][v];
+        }
+    }
+    __syncthreads();
+    if (wave == 0 && lane < lpr) {
+#pragma unroll
+      for (int j = 0; j < MAXJ; ++j)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          const int c = (lane + lpr * j) * VEC + v;
+          if (c < F) {
+            double t = acc[q][j][v];
+            for (int w = 0; w < 3; ++w) t += smem[w * F + c];
+            slot[q * F + c] = t;
+          }
+        }
+    }
+  }
+}
+
 // out[c] = sum_s ws[s*width + c]   (fixed summation order: deterministic; accumulated in fp64 so that the
 // BatchNorm variance E[x^2] - E[x]^2 formed from these sums keeps ~1e-7 accuracy even when |mean| >> std).
 // 1024 threads = 32 slot groups x 32 columns, 4 independent loads in flight per thread: the kernel is a chain of dependent
 // load rounds (slots / 128 of them; it was slots / 64 with 8 groups) and little else -- 6 us -> 4 us for the ~450-slot
 // reductions of the narrow layers, of which a step has ~45.
 #define RS_GROUPS 32
-template <typename OUT>
-__global__ __launch_bounds__(32 * RS_GROUPS) void k_reduce_slots(const float* __restrict__ ws, int slots, int width, OUT* __restrict__ out) {
+template <typename OUT, typename IN = float>
+__global__ __launch_bounds__(32 * RS_GROUPS) void k_reduce_slots(const IN* __restrict__ ws, int slots, int width, OUT* __restrict__ out) {
   __shared__ double part[RS_GROUPS][32];
   const int cl = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
@@ -204,6 +247,12 @@ extern "C" int cgc_stats_blocks(int n, int F) {
   int b = ceil_div(n > 0 ? n : 1, 4);
   return b < MAX_SLOTS ? b : MAX_SLOTS;
 }
+// floats of the workspace behind the forward statistics (cgc_l2norm_act_stats / cgc_l2norm_act_bn / cgc_sage_wide_fwd /
+// cgc_sage_narrow_fwd): one slot of 2F DOUBLES per partial sum (+ 4F + 2 spare floats)
+extern "C" int64_t cgc_stats_ws_floats(int n, int F) {
+  const int b = cgc_stats_blocks(n, F);
+  return (int64_t)(b > 1 ? b : 1) * 4 * F + 4 * (int64_t)F + 2;
+}
 
 // ------------------------------------------------------------------------------------------------
 // l2norm (+ activation statistics for BatchNorm)
@@ -214,11 +263,11 @@ __global__ __launch_bounds__(256) void k_l2norm_act_stats(const float* __restric
                                                           float* __restrict__ ws) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const RowGroup rg(lpr);
-  float acc[2][MAXJ][VEC];
+  double acc[2][MAXJ][VEC];          // see col_reduce_store_f64
 #pragma unroll
   for (int j = 0; j < MAXJ; ++j)
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) acc[0][j][v] = acc[1][j][v] = 0.f;
+    for (int v = 0; v < VEC; ++v) acc[0][j][v] = acc[1][j][v] = 0.0;
 
   for (int base = rg.gwave * rg.rpw; base < n; base += rg.nwaves * rg.rpw) {
     const int row = base + rg.sub;
@@ -246,16 +295,17 @@ __global__ __launch_bounds__(256) void k_l2norm_act_stats(const float* __restric
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
           x[j].v[v] *= r;
-          const float o = act_fwd(x[j].v[v], act);
+          const double o = (double)act_fwd(x[j].v[v], act);
           acc[0][j][v] += o;
-          acc[1][j][v] += o * o;
+          acc[1][j][v] = fma(o, o, acc[1][j][v]);
         }
         x[j].store(hn + (size_t)row * F + c);
       }
     }
     if (valid && rg.sl == 0) rinv[row] = r;
   }
-  if (ws != nullptr) col_reduce_store<VEC, MAXJ, 2>(acc, F, lpr, smem, ws + (size_t)blockIdx.x * 2 * F);
+  if (ws != nullptr)
+    col_reduce_store_f64<VEC, MAXJ>(acc, F, lpr, reinterpret_cast<double*>(smem), reinterpret_cast<double*>(ws) + (size_t)blockIdx.x * 2 * F);
 }
 
 extern "C" int cgc_l2norm_act_stats(const float* h, int n, int F, int normalize, int act, float* hn, float* rinv,
@@ -273,7 +323,8 @@ extern "C" int cgc_l2norm_act_stats(const float* h, int n, int F, int normalize,
   DISPATCH_COL(k_l2norm_act_stats, cfg, smem, as_stream(stream), h, n, F, cfg.lpr, normalize, act, hn, rinv, wsp);
   CGC_RETURN_IF_LAUNCH_FAILED();
   if (stats) {
-    hipLaunchKernelGGL(k_reduce_slots<double>, REDUCE_SLOTS_GRID(2 * F), dim3(32 * RS_GROUPS), 0, as_stream(stream), ws, cfg.blocks, 2 * F, stats);
+    hipLaunchKernelGGL((k_reduce_slots<double, double>), REDUCE_SLOTS_GRID(2 * F), dim3(32 * RS_GROUPS), 0, as_stream(stream),
+                       reinterpret_cast<const double*>(ws), cfg.blocks, 2 * F, stats);
     CGC_RETURN_IF_LAUNCH_FAILED();
   }
   return 0;
@@ -313,7 +364,7 @@ extern "C" int cgc_bn_finalize(const double* stats, int F, double count, float e
 // k_reduce_slots<double>, so the same bits) and mean / istd / running statistics / num_batches_tracked of k_bn_finalize
 __global__ __launch_bounds__(32 * RS_GROUPS) void k_stats_finalize(const StatsFinPtrs p0, const StatsFinPtrs p1, int slots, int F, double count) {
   const StatsFinPtrs& p = blockIdx.y ? p1 : p0;
-  const float* __restrict__ ws = p.ws;
+  const double* __restrict__ ws = reinterpret_cast<const double*>(p.ws);      // slots of doubles: [sum o | sum o^2] per slot
   const float eps = p.eps, momentum = p.momentum;
   float* running_mean = p.running_mean;
   float* running_var = p.running_var;
@@ -328,15 +379,15 @@ __global__ __launch_bounds__(32 * RS_GROUPS) void k_stats_finalize(const StatsFi
   for (int q = 0; q < 2; ++q) {
     double s = 0.0;
     if (f < F) {
-      const float* col = ws + (size_t)q * F + f;
+      const double* col = ws + (size_t)q * F + f;
       const size_t width = 2 * (size_t)F;
       double a[4] = {0.0, 0.0, 0.0, 0.0};
       int k = grp;
       for (; k + 3 * RS_GROUPS < slots; k += 4 * RS_GROUPS) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) a[u] += (double)col[(size_t)(k + RS_GROUPS * u) * width];
+        for (int u = 0; u < 4; ++u) a[u] += col[(size_t)(k + RS_GROUPS * u) * width];
       }
-      for (; k < slots; k += RS_GROUPS) a[0] += (double)col[(size_t)k * width];
+      for (; k < slots; k += RS_GROUPS) a[0] += col[(size_t)k * width];
       s = (a[0] + a[1]) + (a[2] + a[3]);
     }
     part[q][grp][cl] = s;
@@ -374,7 +425,7 @@ int launch_stats_finalize(const float* ws, int slots, int F, double count, float
 
 // The training forward's statistics as ONE call: l2norm + activation sums, then second stage + finalize + running statistics +
 // num_batches_tracked += 1 in one kernel (two launches; one host call instead of three plus torch's counter increment).
-// ws: cgc_stats_blocks(n,F)*2F floats for the slots (+ 4F + 2 spare floats kept for ABI compatibility).
+// ws: cgc_stats_ws_floats(n, F) floats (slots of doubles), 8-byte aligned.
 extern "C" int cgc_l2norm_act_bn(const float* h, int n, int F, int normalize, int act, float* hn, float* rinv, float* ws,
                                  double count, float eps, float momentum, float* running_mean, float* running_var,
                                  int64_t* num_batches_tracked, float* mean, float* istd, cgc_stream_t stream) {

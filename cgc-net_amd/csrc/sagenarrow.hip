@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void k_sage_narrow_fwd(const SnFwdPtrs p0, con
   float* __restrict__ hn = second ? p1.hn : p0.hn;
   float* __restrict__ rinv_out = second ? p1.rinv : p0.rinv;
   float* __restrict__ ws = second ? p1.ws : p0.ws;
-  __shared__ float xch[4][2][32];
+  __shared__ double xch[4][2][32];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int f = lane & 31, half = lane >> 5;
   const bool fok = f < F;
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) void k_sage_narrow_fwd(const SnFwdPtrs p0, con
     bw[s] = (fok && k < K) ? W[(size_t)k * F + f] : 0.f;
   }
   const float bia = (fok && bias != nullptr) ? bias[f] : 0.f;
-  float s1 = 0.f, s2 = 0.f;
+  double s1 = 0.0, s2 = 0.0;     // BatchNorm statistics in double from the first addition on (rowops.hip: col_reduce_store_f64)
   for (int tile = blockIdx.x * 4 + wave; tile < tiles; tile += gridDim.x * 4) {
     const int row0 = tile * 32;
     const float* __restrict__ a = agg + (size_t)min(row0 + f, n - 1) * lda;        // A operand: lane = row
@@ -287,9 +287,9 @@ __global__ __launch_bounds__(256) void k_sage_narrow_fwd(const SnFwdPtrs p0, con
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          const float o = act_fwd(vv[r], ACT);
+          const double o = (double)act_fwd(vv[r], ACT);
           s1 += o;
-          s2 = fmaf(o, o, s2);
+          s2 = fma(o, o, s2);
           hn[(size_t)row * F + f] = vv[r];
         }
       }
@@ -303,9 +303,9 @@ __global__ __launch_bounds__(256) void k_sage_narrow_fwd(const SnFwdPtrs p0, con
         const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
         if (row < n) {
           if (fok) {
-            const float o = act_fwd(vv[r], ACT);
+            const double o = (double)act_fwd(vv[r], ACT);
             s1 += o;
-            s2 = fmaf(o, o, s2);
+            s2 = fma(o, o, s2);
             hn[(size_t)row * F + f] = vv[r];
           }
           if (f == 0) rinv_out[row] = rr[r];
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256) void k_sage_narrow_fwd(const SnFwdPtrs p0, con
   if (half == 0) { xch[wave][0][f] = s1; xch[wave][1][f] = s2; }
   __syncthreads();
   if (wave == 0 && half == 0 && fok) {
-    float* __restrict__ slot = ws + (size_t)blockIdx.x * 2 * F;
+    double* __restrict__ slot = reinterpret_cast<double*>(ws) + (size_t)blockIdx.x * 2 * F;
     slot[f] = (xch[0][0][f] + xch[1][0][f]) + (xch[2][0][f] + xch[3][0][f]);
     slot[F + f] = (xch[0][1][f] + xch[1][1][f]) + (xch[2][1][f] + xch[3][1][f]);
   }

@@ -32,7 +32,8 @@ __global__ __launch_bounds__(256, 1) void k_sage_wide_fwd(const float* __restric
   const int l31 = lane & 31, lhi = lane >> 5;
   const int c_base = wave * NTW * 32;
 
-  float bw[NTW][KS], bia[NTW], s1[NTW], s2[NTW];
+  float bw[NTW][KS], bia[NTW];
+  double s1[NTW], s2[NTW];       // BatchNorm statistics in double from the first addition on (rowops.hip: col_reduce_store_f64)
 #pragma unroll
   for (int t = 0; t < NTW; ++t) {
     const int col = c_base + t * 32 + l31;
@@ -42,7 +43,7 @@ __global__ __launch_bounds__(256, 1) void k_sage_wide_fwd(const float* __restric
       bw[t][s] = (col < F && k < K) ? W[(size_t)k * F + col] : 0.f;
     }
     bia[t] = (col < F && bias != nullptr) ? bias[col] : 0.f;
-    s1[t] = s2[t] = 0.f;
+    s1[t] = s2[t] = 0.0;
   }
 
   for (int rt = blockIdx.x; rt < row_tiles; rt += gridDim.x) {
@@ -113,9 +114,9 @@ __global__ __launch_bounds__(256, 1) void k_sage_wide_fwd(const float* __restric
           const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
           if (row < n) {
             const float v = acc[r] * rin[r];
-            const float o = act_fwd(v, act);
+            const double o = (double)act_fwd(v, act);
             s1[t] += o;
-            s2[t] = fmaf(o, o, s2[t]);
+            s2[t] = fma(o, o, s2[t]);
             hn[(size_t)row * ldh + col] = v;
           }
         }
@@ -124,10 +125,10 @@ __global__ __launch_bounds__(256, 1) void k_sage_wide_fwd(const float* __restric
     }
   }
   if (ws != nullptr) {
-    float* slot = ws + (size_t)blockIdx.x * 2 * F;
+    double* slot = reinterpret_cast<double*>(ws) + (size_t)blockIdx.x * 2 * F;
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
-      const float a = s1[t] + __shfl_xor(s1[t], 32), b = s2[t] + __shfl_xor(s2[t], 32);
+      const double a = s1[t] + __shfl_xor(s1[t], 32), b = s2[t] + __shfl_xor(s2[t], 32);
       const int col = c_base + t * 32 + l31;
       if (lhi == 0 && col < F) {
         slot[col] = a;

@@ -550,8 +550,7 @@ class HipKernels(KernelSpec):
     # -- conv epilogue
     def l2norm_act_stats(self, h, n, F, normalize, act, hn_out, rinv_out, stats_out):
         self._dev(h, hn_out, rinv_out, stats_out)
-        nblk = self.lib.cgc_stats_blocks(n, F)
-        ws = torch.empty(max(nblk, 1) * 2 * F, dtype=torch.float32, device=h.device) if stats_out is not None else None
+        ws = torch.empty(int(self.lib.cgc_stats_ws_floats(n, F)), dtype=torch.float32, device=h.device) if stats_out is not None else None
         self._chk(self.lib.cgc_l2norm_act_stats(_ptr(h), n, F, int(normalize), act, _ptr(hn_out), _ptr(rinv_out),
                                                 _ptr(stats_out), _ptr(ws), self._stream()), 'cgc_l2norm_act_stats')
 
@@ -560,8 +559,7 @@ class HipKernels(KernelSpec):
         self._dev(agg, weight, bias, hn_out, rinv_out, running_mean, running_var, num_batches_tracked, mean_out, istd_out)
         ws = None
         if stats:
-            nblk = self.lib.cgc_stats_blocks(n, F)
-            ws = torch.empty(max(nblk, 1) * 2 * F + 4 * F + 2, dtype=torch.float32, device=agg.device)
+            ws = torch.empty(int(self.lib.cgc_stats_ws_floats(n, F)), dtype=torch.float32, device=agg.device)
         tail = (int(bool(stats)), _ptr(ws), ctypes.c_double(count), ctypes.c_float(eps), ctypes.c_float(momentum), _ptr(running_mean),
                 _ptr(running_var), _ptr(num_batches_tracked), _ptr(mean_out), _ptr(istd_out), self._stream())
         if F <= 32 and hn_out.stride(0) == F:          # narrow output: one wave per 32 rows (csrc/sagenarrow.hip)
@@ -590,8 +588,7 @@ class HipKernels(KernelSpec):
     def l2norm_act_bn(self, h, n, F, normalize, act, hn_out, rinv_out, count, eps, momentum, running_mean, running_var,
                       num_batches_tracked, mean_out, istd_out):
         self._dev(h, hn_out, rinv_out, running_mean, running_var, num_batches_tracked, mean_out, istd_out)
-        nblk = self.lib.cgc_stats_blocks(n, F)
-        ws = torch.empty(max(nblk, 1) * 2 * F + 4 * F + 2, dtype=torch.float32, device=h.device)
+        ws = torch.empty(int(self.lib.cgc_stats_ws_floats(n, F)), dtype=torch.float32, device=h.device)
         assert num_batches_tracked is None or num_batches_tracked.dtype == torch.int64
         self._chk(self.lib.cgc_l2norm_act_bn(_ptr(h), n, F, int(normalize), act, _ptr(hn_out), _ptr(rinv_out), _ptr(ws),
                                              ctypes.c_double(count), ctypes.c_float(eps),

@@ -38,7 +38,8 @@ typedef void* cgc_stream_t; /* hipStream_t */
 /* Bumped whenever an entry point is added, removed or changes its signature / semantics.  Bindings compare their own copy
  * (cgc-net_amd/_abi.py: ABI_VERSION) with cgc_abi_version() of the library they loaded and refuse a mismatch.
  *   1: rounds 1-3 (operators, step sequencer, head, optimiser, measurement hook)
- *   2: round 4 (head: labels outside [0, L) are ignored like F.cross_entropy's ignore_index; additions listed in DESIGN.md) */
+ *   2: round 4 (head: labels outside [0, L) are ignored like F.cross_entropy's ignore_index; forward BatchNorm statistics in double:
+ *      cgc_stats_ws_floats; additions listed in DESIGN.md) */
 #define CGC_ABI_VERSION 2
 int cgc_abi_version(void);
 
@@ -189,14 +190,19 @@ int cgc_reduce_batched(const float* ws, float* out, int outer, int parts, int nu
 
 /* ---- A4/A5: conv epilogue.  Replaces F.normalize + activation + nn.BatchNorm1d over the padded [B*Nmax, C]
  * view (model/network.py:101-107,114-116).
- * cgc_stats_blocks(n,F): number of partial-sum slots the column reductions use; ws must hold 2*F floats per slot. */
+ * cgc_stats_blocks(n,F): number of partial-sum slots the column reductions use; ws must hold 2*F floats per slot for the
+ * backward reductions (cgc_bn_bwd_reduce, cgc_colsum, ...).  The FORWARD statistics (sum of o, sum of o^2 per column, o = act(hn))
+ * are accumulated in double from the first addition on -- the variance is a difference of the two, and on the coarsened levels
+ * std << |mean| -- and their slots hold doubles: cgc_stats_ws_floats(n,F) floats of workspace (8-byte aligned) for
+ * cgc_l2norm_act_stats / cgc_l2norm_act_bn / cgc_sage_wide_fwd / cgc_sage_narrow_fwd. */
 int cgc_stats_blocks(int n, int F);
+int64_t cgc_stats_ws_floats(int n, int F);
 int cgc_l2norm_act_stats(const float* h, int n, int F, int normalize, int act, float* hn, float* rinv,
                          double* stats /*[2,F] fp64 or NULL*/, float* ws, cgc_stream_t stream);
 int cgc_bn_finalize(const double* stats /*[2,F] fp64: the variance is a difference of these sums*/, int F, double count, float eps, float momentum,
                     float* running_mean /*NULL ok*/, float* running_var, float* mean, float* istd, cgc_stream_t stream);
 /* The two calls above as ONE (what the training forward uses): hn, rinv, batch statistics over `count` rows, mean / istd,
- * running statistics and num_batches_tracked += 1 (NULL ok).  ws: cgc_stats_blocks(n,F)*2F + 4F + 2 floats. */
+ * running statistics and num_batches_tracked += 1 (NULL ok).  ws: cgc_stats_ws_floats(n,F) floats. */
 int cgc_l2norm_act_bn(const float* h, int n, int F, int normalize, int act, float* hn, float* rinv, float* ws, double count,
                       float eps, float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked,
                       float* mean, float* istd, cgc_stream_t stream);

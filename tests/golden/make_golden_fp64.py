@@ -15,6 +15,10 @@ make_golden.py), casts the module to float64 and runs it through its dense tuple
                                   output, [B, N, F] in the dense layout) -- recorded by a forward-pre-hook on ``active<k>``
   embed64/<level>                 the tensor each readout maximises over (model/network.py:264,275,284), [B, N, D]
   win64/<level>                   its argmax over the node axis, [B, D]
+  ulp64/<parameter>               how far the reference's OWN float64 gradient of that parameter moves (max-norm, relative) when every
+                                  parameter is perturbed by one float32 rounding (relative 2^-24, random signs; worst of 8 draws): what
+                                  no float32 evaluation of this network can be expected to beat on this input -- the gradient bar of
+                                  tests/discrete.py::compare_with_reference_fp64 is max(1e-4, 2 x this)
 
 and asserts oracle/dense_ref.py (float64) == reference (float64) to 1e-11 on all of them.  Only the .npz files travel.
 """
@@ -91,6 +95,32 @@ def main():
         for level, e in embeds.items():
             fix['embed64/%d' % level] = e.numpy()
             fix['win64/%d' % level] = e.max(dim=1)[1].numpy()
+        # conditioning of every parameter gradient: the reference in float64 on parameters moved by one float32 rounding
+        g0 = {k: p.grad.clone() for k, p in ref.named_parameters()}
+        sens = {k: 0.0 for k in g0}
+        gen = torch.Generator().manual_seed(99)
+        for _draw in range(8):
+            pert = build(refnet.SoftPoolingGcnEncoder, cfg)
+            sdp = {}
+            for k, v in sd.items():
+                if v.dtype.is_floating_point:
+                    sign = torch.randint(0, 2, v.shape, generator=gen).double() * 2 - 1
+                    sdp[k] = v.double() * (1.0 + sign * 2.0 ** -24)
+                else:
+                    sdp[k] = v
+            pert = pert.double()
+            pert.load_state_dict(sdp)
+            pert.load_data_sparse = False
+            pert.train()
+            pert.zero_grad()
+            _, lp = pert((x.double(), adj.clone(), counts, batch.y.view(-1)))
+            lp.backward()
+            for k, p in pert.named_parameters():
+                m = float(g0[k].abs().max())
+                if m > 1e-12:
+                    sens[k] = max(sens[k], float((p.grad - g0[k]).abs().max()) / m)
+        for k, v in sens.items():
+            fix['ulp64/' + k] = np.float64(v)
         # the oracle in float64 must be the same function
         ora = build(dense_ref.SoftPoolingGcnEncoder, cfg)
         ora.load_state_dict(sd)
@@ -107,8 +137,9 @@ def main():
         worst = max(worst, max(errs))
         path = os.path.join(HERE, name + '_fp64.npz')
         np.savez_compressed(path, **fix)
-        print('%-16s loss64 %.12f  pre-activation layers %d  -> %s (%.1f KB)' % (name, float(loss), len(pre), os.path.relpath(path, ROOT),
-                                                                           os.path.getsize(path) / 1024))
+        top = sorted(((v, k) for k, v in sens.items()), reverse=True)[:2]
+        print('%-16s loss64 %.12f  pre-activation layers %d  -> %s (%.1f KB); most sensitive to one float32 rounding of the parameters: %s'
+              % (name, float(loss), len(pre), os.path.relpath(path, ROOT), os.path.getsize(path) / 1024, [('%.1e' % v, k) for v, k in top]))
     print('oracle(fp64) vs reference(fp64): worst relative difference %.2e' % worst)
 
 
