@@ -32,8 +32,13 @@ __global__ __launch_bounds__(256, 1) void k_sage_wide_fwd(const float* __restric
   const int l31 = lane & 31, lhi = lane >> 5;
   const int c_base = wave * NTW * 32;
 
-  float bw[NTW][KS], bia[NTW];
-  double s1[NTW], s2[NTW];       // BatchNorm statistics in double from the first addition on (rowops.hip: col_reduce_store_f64)
+  // BatchNorm statistics without the E[o^2] - E[o]^2 cancellation (rowops.hip: col_reduce_store_f64 tells why it matters).  Adding
+  // every o and o^2 in double costs this kernel its second wave per SIMD (36 more registers: 244 -> 260; 123 -> 180 us), so the
+  // sums here are SHIFTED fp32 sums: d = o - c with c = the column's mean over the workgroup's first row tile, s1 = sum d,
+  // s2 = sum d^2 -- deviations are formed directly, nothing large cancels -- and only the last step is in double: a lane's
+  // (count, mean = c + s1 / count, M2 = s2 - s1^2 / count) is turned into the slot format (sum o, sum o^2).
+  float bw[NTW][KS], bia[NTW], s1[NTW], s2[NTW], shift[NTW];
+  int seen = 0;                  // rows this lane has folded in (the same for all its column tiles)
 #pragma unroll
   for (int t = 0; t < NTW; ++t) {
     const int col = c_base + t * 32 + l31;
@@ -43,7 +48,7 @@ __global__ __launch_bounds__(256, 1) void k_sage_wide_fwd(const float* __restric
       bw[t][s] = (col < F && k < K) ? W[(size_t)k * F + col] : 0.f;
     }
     bia[t] = (col < F && bias != nullptr) ? bias[col] : 0.f;
-    s1[t] = s2[t] = 0.0;
+    s1[t] = s2[t] = shift[t] = 0.f;
   }
 
   for (int rt = blockIdx.x; rt < row_tiles; rt += gridDim.x) {
@@ -101,6 +106,8 @@ __global__ __launch_bounds__(256, 1) void k_sage_wide_fwd(const float* __restric
       }
     }
 #pragma unroll
+    for (int r = 0; r < 16; ++r) seen += (row0 + (r & 3) + 8 * (r >> 2) + 4 * lhi) < n ? 1 : 0;
+#pragma unroll
     for (int t = 0; t < NTW; ++t) {
       floatx16 acc;
 #pragma unroll
@@ -108,15 +115,22 @@ __global__ __launch_bounds__(256, 1) void k_sage_wide_fwd(const float* __restric
 #pragma unroll
       for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bw[t][s], acc, 0, 0, 0);
       const int col = c_base + t * 32 + l31;
-      if (col < F) {
+      if (col < F) {           // (both halves of the wave hold the same column: the exchange below has its partner)
+        if (rt == (int)blockIdx.x) {      // the workgroup's first row tile fixes the shift: this column's mean over the tile's rows
+          float t1 = 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) t1 += (row0 + (r & 3) + 8 * (r >> 2) + 4 * lhi) < n ? act_fwd(acc[r] * rin[r], act) : 0.f;
+          t1 += __shfl_xor(t1, 32);
+          shift[t] = t1 / (float)min(32, n - row0);
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
           if (row < n) {
             const float v = acc[r] * rin[r];
-            const double o = (double)act_fwd(v, act);
-            s1[t] += o;
-            s2[t] = fma(o, o, s2[t]);
+            const float d = act_fwd(v, act) - shift[t];
+            s1[t] += d;
+            s2[t] = fmaf(d, d, s2[t]);
             hn[(size_t)row * ldh + col] = v;
           }
         }
@@ -128,11 +142,16 @@ __global__ __launch_bounds__(256, 1) void k_sage_wide_fwd(const float* __restric
     double* slot = reinterpret_cast<double*>(ws) + (size_t)blockIdx.x * 2 * F;
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
-      const double a = s1[t] + __shfl_xor(s1[t], 32), b = s2[t] + __shfl_xor(s2[t], 32);
+      // this half's rows as (count, mean, M2) in double, then sum o = count * mean and sum o^2 = M2 + count * mean^2
+      const double cn = (double)seen, c = (double)shift[t], a1 = (double)s1[t], a2 = (double)s2[t];
+      const double mean = seen > 0 ? c + a1 / cn : 0.0, M2 = seen > 0 ? a2 - a1 * a1 / cn : 0.0;
+      double so = cn * mean, soo = M2 + cn * mean * mean;
+      so += __shfl_xor(so, 32);
+      soo += __shfl_xor(soo, 32);
       const int col = c_base + t * 32 + l31;
       if (lhi == 0 && col < F) {
-        slot[col] = a;
-        slot[F + col] = b;
+        slot[col] = so;
+        slot[F + col] = soo;
       }
     }
   }

@@ -977,3 +977,46 @@ def test_wide_spmm_and_softmax_with_padded_rows(width, ld):
     close(dx[:, :width], want_dx, what='padded softmax bwd')
     close(cs, want_dx.sum(0), what='padded softmax bwd column sums')
     assert bool((dx[:, width:] == 5.0).all())
+
+
+@pytest.mark.parametrize('path,n,Kin,F', [('rows', 3000, 0, 20), ('rows', 900, 0, 1140), ('narrow', 3000, 20, 20), ('narrow', 5000, 8, 8),
+                                          ('wide', 2500, 20, 1140), ('wide', 700, 16, 114)])
+def test_forward_bn_statistics_survive_small_variance(path, n, Kin, F):
+    """BatchNorm's batch variance where the rows are nearly identical (std ~ 1/100 of the mean per column: the coarsened levels,
+    whose clusters have near-identical content).  The statistics are a difference of sums: carried in fp32 they lose
+    eps * (mean / std)^2 of the variance (1e-3 here) and with it the gradients of the block (5e-4 on the reference-generated
+    tiny_shipped fixture before round 4).  All three producers of the statistics -- the row kernel, the fused narrow SAGE
+    forward, the fused wide SAGE forward -- must deliver var to 2e-5 and the mean to 1e-6 of a float64 evaluation."""
+    k = hip()
+    rs = np.random.RandomState(n + F)
+    if path == 'rows':
+        base = rs.standard_normal((1, F)).astype(np.float32)
+        h = torch.from_numpy(base + 0.01 * rs.standard_normal((n, F)).astype(np.float32)).to(DEV)
+    else:
+        base = rs.standard_normal((1, Kin)).astype(np.float32)
+        agg = torch.from_numpy(base + 0.01 * rs.standard_normal((n, Kin)).astype(np.float32)).to(DEV)
+        W = torch.from_numpy(rs.standard_normal((Kin, F)).astype(np.float32) * 0.3).to(DEV)
+        b = torch.from_numpy(rs.standard_normal(F).astype(np.float32) * 0.1).to(DEV)
+        h = agg @ W + b
+    count, eps = float(n + 11), 1e-5
+    ld = F if path != 'wide' else ((F + 31) // 32) * 32
+    hn = torch.empty(n, ld, device=DEV)[:, :F]
+    rinv = torch.empty(n, device=DEV)
+    rm, rv = torch.zeros(F, device=DEV), torch.ones(F, device=DEV)
+    nbt = torch.zeros((), dtype=torch.int64, device=DEV)
+    mean, istd = torch.empty(F, device=DEV), torch.empty(F, device=DEV)
+    if path == 'rows':
+        hn = torch.empty(n, F, device=DEV)
+        k.l2norm_act_bn(h, n, F, True, 1, hn, rinv, count, eps, 0.1, rm, rv, nbt, mean, istd)
+    else:
+        assert k.sage_wide_fwd(agg, Kin, W, b, n, Kin, F, True, 1, hn, rinv, True, count, eps, 0.1, rm, rv, nbt, mean, istd)
+    torch.cuda.synchronize()
+    o = torch.relu(hn.double())                               # the kernel's own normalised rows, statistics in float64
+    m_ref = o.sum(0) / count
+    v_ref = (o * o).sum(0) / count - m_ref * m_ref
+    var = 1.0 / istd.double() ** 2 - eps
+    live = v_ref > 1e-7                                       # (columns that ReLU switches off entirely have no variance to compare)
+    assert int(live.sum()) > F // 4
+    assert float(((mean.double() - m_ref).abs() / m_ref.abs().clamp_min(1e-3)).max()) < 1e-6
+    rel = float(((var - v_ref).abs() / v_ref)[live].max())
+    assert rel < 2e-5, rel
