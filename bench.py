@@ -74,9 +74,6 @@ def parse():
     p.add_argument('--cpu-warmup', type=int, default=3, help='CPU baseline: untimed warm-up steps')
     p.add_argument('--cpu-steps', type=int, default=5, help='CPU baseline: timed steps')
     p.add_argument('--no-kernel-timing', action='store_true', help='do not record per-launch HIP events')
-    p.add_argument('--graph', action='store_true',
-                   help='replay the fixed-shape dense levels (2-3) from two hipGraphs (network.enable_graph_capture); bitwise the same '
-                        'results, measured 4-5 %% SLOWER than eager launches on ROCm 7.2 (DESIGN.md), hence off by default')
     p.add_argument('--plain-adam', action='store_true', help='torch.optim.Adam without fused=True (one kernel per parameter group)')
     return p.parse_args()
 
@@ -221,8 +218,6 @@ def main():
     torch.manual_seed(0)
     model = make_model(args, network).to(dev)
     model.train()
-    if args.graph:
-        model.enable_graph_capture()           # levels 2-3 (fixed shapes per batch size): forward + backward as two hipGraphs
     dp = DataParallel(model) if world > 1 else model
     if world > 1:
         dp.time_allreduce(True)
@@ -305,7 +300,7 @@ def main():
                                       args.maxn, c1, int(c1 * 0.1), args.flags),
                        'global_batch': args.batch * (1 if strong else world), 'nodes_per_batch': round(nodes),
                        'parallelism': 'dp%d' % world, 'includes': 'CSR build + fwd + loss + bwd + grad all-reduce + Adam',
-                       'step_sequencer': bool(getattr(model, 'native', False)) and not args.graph, 'hipgraph_dense_levels': bool(args.graph), 'node_order': 'grid cells' if args.spatial else 'draw order', 'fused_adam': not args.plain_adam,
+                       'step_sequencer': bool(getattr(model, 'native', False)), 'node_order': 'grid cells' if args.spatial else 'draw order', 'fused_adam': not args.plain_adam,
                        'optimiser': 'torch.optim.Adam' if args.plain_adam else 'cgc_adam_step (one launch; torch fused Adam arithmetic)'},
         }
         if world > 1:

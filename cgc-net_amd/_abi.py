@@ -36,6 +36,7 @@ PROTOTYPES = {
     'cgc_bn_finalize': [P, I, D, F, F, P, P, P, P, P],
     'cgc_l2norm_act_bn': [P, I, I, I, I, P, P, P, D, F, F, P, P, P, P, P, P],
     'cgc_sage_wide_fwd': [P, I, P, P, I, I, I, I, I, P, I, P, I, P, D, F, F, P, P, P, P, P, P],
+    'cgc_bn_running_stats': [P, P, I, F, P, P, P],
     'cgc_bn_act_apply': [P, I, I, I, P, P, P, P, P, I, P],
     'cgc_bn_act_apply2': [P, I, I, I, P, P, P, P, P, I, P, I, P],
     'cgc_bn_bwd_reduce': [P, I, P, I, I, I, P, P, P, P, P],

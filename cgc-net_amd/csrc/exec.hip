@@ -266,26 +266,28 @@ inline size_t stats_ws_floats(int n, int F) { return (size_t)cgc_stats_ws_floats
 int layer_fwd(const Ctx& c, const cgc_level_desc& d, const LayerP& p, const LayerS& s, const float* agg, int lda, int n, int fin, int F,
               float* y, int ldy, float* y2 = nullptr, int ldy2 = 0) {
   const size_t m = c.scratch->mark();
-  float* ws = d.has_bn ? c.scratch->f(stats_ws_floats(n, F)) : nullptr;
+  const int batch_stats = d.has_bn && !d.eval;       // inference: the running statistics normalise (below), nothing is accumulated
+  float* ws = batch_stats ? c.scratch->f(stats_ws_floats(n, F)) : nullptr;
   int fused = 0;
   if ((F >= 256 || F <= 32) && fin <= 32 && !c.dry) {
     int rc;
     if (F <= 32)
-      rc = cgc_sage_narrow_fwd(agg, lda, p.W, p.b, n, fin, F, 1, d.act, s.hn, s.rinv, d.has_bn, ws, d.count, p.eps, p.mom, p.rm, p.rv, p.nbt,
+      rc = cgc_sage_narrow_fwd(agg, lda, p.W, p.b, n, fin, F, 1, d.act, s.hn, s.rinv, batch_stats, ws, d.count, p.eps, p.mom, p.rm, p.rv, p.nbt,
                                s.mean, s.istd, c.s);
     else
-      rc = cgc_sage_wide_fwd(agg, lda, p.W, p.b, n, fin, F, 1, d.act, s.hn, F, s.rinv, d.has_bn, ws, d.count, p.eps, p.mom, p.rm, p.rv, p.nbt,
+      rc = cgc_sage_wide_fwd(agg, lda, p.W, p.b, n, fin, F, 1, d.act, s.hn, F, s.rinv, batch_stats, ws, d.count, p.eps, p.mom, p.rm, p.rv, p.nbt,
                              s.mean, s.istd, c.s);
     if (rc == 0) fused = 1;
     else if (rc != CGC_EINVAL) return rc;
   }
   if (!fused) {
     TRY(gemm(c, 0, 0, n, F, fin, agg, lda, p.W, F, 0.f, s.hn, F, p.b));
-    if (d.has_bn)
+    if (batch_stats)
       CALL(cgc_l2norm_act_bn(s.hn, n, F, 1, d.act, s.hn, s.rinv, ws, d.count, p.eps, p.mom, p.rm, p.rv, p.nbt, s.mean, s.istd, c.s));
     else
       CALL(cgc_l2norm_act_stats(s.hn, n, F, 1, d.act, s.hn, s.rinv, nullptr, nullptr, c.s));
   }
+  if (d.has_bn && d.eval) CALL(cgc_bn_running_stats(p.rm, p.rv, F, p.eps, s.mean, s.istd, c.s));
   CALL(cgc_bn_act_apply2(s.hn, n, F, d.act, d.has_bn ? s.mean : nullptr, s.istd, p.gamma, p.beta, y, ldy, y2, ldy2, c.s));
   c.scratch->release(m);
   return 0;
@@ -330,13 +332,16 @@ int layer_fwd_pair(const Ctx& c, const cgc_level_desc& d, const LayerP* p, const
   SnFwdPtrs g[2];
   SnFwdBn bn[2];
   BnApplyPtrs ap[2];
+  const int batch_stats = d.has_bn && !d.eval;
   for (int i = 0; i < 2; ++i) {
-    float* ws = d.has_bn ? c.scratch->f(stats_ws_floats(n, F)) : nullptr;
+    float* ws = batch_stats ? c.scratch->f(stats_ws_floats(n, F)) : nullptr;
     g[i] = SnFwdPtrs{agg[i], p[i].W, p[i].b, s[i].hn, s[i].rinv, ws};
     bn[i] = SnFwdBn{p[i].eps, p[i].mom, p[i].rm, p[i].rv, p[i].nbt, s[i].mean, s[i].istd};
     ap[i] = BnApplyPtrs{s[i].hn, d.has_bn ? s[i].mean : nullptr, s[i].istd, p[i].gamma, p[i].beta, y[i], y2[i], ldy2[i]};
   }
-  CALL(sage_narrow_fwd_groups(g, bn, 2, lda, n, fin, F, 1, d.act, d.has_bn, d.count, as_stream(c.s)));
+  CALL(sage_narrow_fwd_groups(g, bn, 2, lda, n, fin, F, 1, d.act, batch_stats, d.count, as_stream(c.s)));
+  if (d.has_bn && d.eval)
+    for (int i = 0; i < 2; ++i) CALL(cgc_bn_running_stats(p[i].rm, p[i].rv, F, p[i].eps, s[i].mean, s[i].istd, c.s));
   CALL(bn_act_apply_groups(ap, 2, n, F, d.act, ldy, as_stream(c.s)));
   c.scratch->release(m);
   return 0;
@@ -769,7 +774,7 @@ extern "C" int64_t cgc_level_scratch_floats(const cgc_level_desc* d) {
   L.layout_saved(sv);
   L.layout_grads();
   size_t high = 0;
-  for (int pass = 0; pass < 2; ++pass) {
+  for (int pass = 0; pass < (d->eval ? 1 : 2); ++pass) {       // (an inference descriptor never runs a backward)
     Arena sc(nullptr);
     Ctx c{nullptr, true, &sc, nullptr, 0};
     sc.f((size_t)cgc_gemm_ws_floats());
@@ -808,7 +813,7 @@ extern "C" int cgc_level_bwd(const cgc_level_desc* d, const cgc_block_params* em
                              const cgc_graph* g, const int* gptr, const float* x_in, const float* A_in, const float* saved, float* scratch,
                              const float* d_readout, const float* d_x_out, const float* d_A_out, float* grads, float* d_x_in, float* d_A_in,
                              cgc_stream_t stream) {
-  if (!cgc_level_supported(d) || saved == nullptr || scratch == nullptr || grads == nullptr) return CGC_EINVAL;
+  if (!cgc_level_supported(d) || saved == nullptr || scratch == nullptr || grads == nullptr || d->eval) return CGC_EINVAL;
   if (!aligned16(saved) || !aligned16(scratch) || !aligned16(grads)) return CGC_EINVAL;
   Level L(*d);
   Arena sv(const_cast<float*>(saved)), sc(scratch);

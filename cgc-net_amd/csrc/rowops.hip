@@ -360,6 +360,22 @@ extern "C" int cgc_bn_finalize(const double* stats, int F, double count, float e
   return 0;
 }
 
+__global__ void k_bn_running_stats(const float* __restrict__ rm, const float* __restrict__ rv, int F, float eps, float* __restrict__ mean,
+                                   float* __restrict__ istd) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= F) return;
+  mean[f] = rm[f];
+  istd[f] = 1.f / sqrtf(rv[f] + eps);
+}
+extern "C" int cgc_bn_running_stats(const float* running_mean, const float* running_var, int F, float eps, float* mean, float* istd,
+                                    cgc_stream_t stream) {
+  if (F <= 0) return 0;
+  if (running_mean == nullptr || running_var == nullptr || mean == nullptr || istd == nullptr) return CGC_EINVAL;
+  hipLaunchKernelGGL(k_bn_running_stats, dim3(ceil_div(F, 256)), dim3(256), 0, as_stream(stream), running_mean, running_var, F, eps, mean, istd);
+  CGC_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}
+
 // second stage of the statistics + finalize in one kernel: the column sums of the slots (same grouping and order as
 // k_reduce_slots<double>, so the same bits) and mean / istd / running statistics / num_batches_tracked of k_bn_finalize
 __global__ __launch_bounds__(32 * RS_GROUPS) void k_stats_finalize(const StatsFinPtrs p0, const StatsFinPtrs p1, int slots, int F, double count) {

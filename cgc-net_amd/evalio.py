@@ -124,7 +124,9 @@ def evaluate(loader, model, vote, test_time=1, max_num_examples=None, batch_size
                 else:                                        # bare module: collate here
                     from .data import Batch
                     dev = next(model.parameters()).device
-                    ypred = model(Batch.from_data_list(data).to(dev))
+                    # (a CUDA model: collate on the device -- one packed copy + one kernel, data.py / csrc/collate.hip -- instead of
+                    # concatenating on the host and copying tensor by tensor)
+                    ypred = model(Batch.from_data_list(data, device=dev) if dev.type == 'cuda' else Batch.from_data_list(data))
                 names = [loader.dataset.idxlist[int(d.patch_idx)] for d in data]
                 labels.append(torch.cat([d.y.reshape(-1) for d in data]).cpu().numpy())
                 vote.batch_patch_result(names, torch.max(ypred, 1)[1].cpu().numpy())

@@ -24,7 +24,7 @@ P, I, F_, D_, L = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_int64
 class LevelDesc(C.Structure):
     _fields_ = [('level', I), ('B', I), ('n', I), ('rows_per_graph', I), ('nmax', I), ('npad', I), ('fin', I), ('H', I), ('E', I),
                 ('AH', I), ('C', I), ('has_bias', I), ('has_bn', I), ('act', I), ('jk', I), ('renorm', I), ('renorm_p', F_),
-                ('bn_eps', F_ * 6), ('bn_momentum', F_ * 6), ('count', D_)]
+                ('bn_eps', F_ * 6), ('bn_momentum', F_ * 6), ('count', D_), ('eval', I), ('reserved', I)]
 
 
 class BlockParams(C.Structure):
@@ -153,8 +153,12 @@ def describe(enc, level, emb, pool, jk, B, n, rows_per_graph, nmax, npad, fin, c
                 return None
             if blk.use_bn:
                 bn = getattr(blk, 'bn%d' % k)
-                if bn.momentum is None or not bn.affine or not blk.training:
+                if not bn.affine:
                     return None
+                if blk.training and bn.momentum is None:
+                    return None
+                if not blk.training and (not bn.track_running_stats or bn.running_mean is None):
+                    return None            # (inference without running statistics normalises with batch statistics: per-operator path)
         if blk.use_bn != emb.use_bn or blk.activation != emb.activation:
             return None
         if not _f32ok(*_block_tensors(blk)):
@@ -172,6 +176,7 @@ def describe(enc, level, emb, pool, jk, B, n, rows_per_graph, nmax, npad, fin, c
     d.has_bias, d.has_bn = int(emb.gcn1.bias is not None), int(emb.use_bn)
     d.act, d.jk = ACT_CODES[emb.activation], int(jk is not None)
     d.renorm, d.renorm_p = int(enc.norm_adj), float(RENORM_P)
+    d.eval = int(not emb.training)
     for b_i, blk in enumerate(blocks):
         if blk.use_bn:
             for k in range(3):
@@ -318,6 +323,37 @@ def level(enc, desc, emb, pool, jk, g, gptr, x_in, A_in, assign=None, prep=None)
     if desc.C:
         return out
     return out, None, None
+
+
+def level_eval(enc, desc, emb, pool, jk, g, gptr, x_in, A_in, assign=None, prep=None):
+    """Inference forward of one level through the sequencer (desc.eval = 1: BatchNorm on its running statistics, nothing kept): no
+    autograd node, two arenas that die with the call.  Returns (readout, x_out, A_out).  evaluate() (train.py:21-91) runs on this."""
+    lib = _lib()
+    K = kernels.get()
+    d = desc
+    dev = x_in.device
+    K._dev(x_in, A_in, gptr)
+    n_saved, n_scratch, _ = _sizes(d)
+    saved = torch.empty(n_saved, dtype=torch.float32, device=dev)
+    scratch = torch.empty(n_scratch, dtype=torch.float32, device=dev)
+    D = d.H if d.jk else 2 * d.H + d.E
+    readout = torch.empty(d.B, D, dtype=torch.float32, device=dev)
+    x_out = torch.empty(d.B, d.C, D, dtype=torch.float32, device=dev) if d.C else None
+    A_out = torch.empty(d.B, d.C, d.C, dtype=torch.float32, device=dev) if d.C else None
+    pe, pp, pj = prep['structs'] if prep else (_block_params(emb), _block_params(pool), _jk_params(jk))
+    gs = Graph()
+    if g is not None:
+        gs.rowptr, gs.col, gs.t_rowptr, gs.t_col = _p(g.rowptr), _p(g.col), _p(g.t_rowptr), _p(g.t_col)
+        gs.val, gs.t_val, gs.inv_d, gs.gorder = _p(g.val), _p(g.t_val), _p(g.inv_d), _p(g.gorder)
+    s_ptr, s_ld = P(), I()
+    rc = lib.cgc_level_fwd(C.byref(d), C.byref(pe), C.byref(pp), C.byref(pj), C.byref(gs), _p(gptr), _p(x_in), _p(A_in), _p(saved),
+                           _p(scratch), _p(readout), _p(x_out), _p(A_out), C.byref(s_ptr), C.byref(s_ld), K._stream())
+    if rc != 0:
+        raise RuntimeError('cgc_level_fwd (inference) failed with code %d' % rc)
+    if assign is not None and d.C:
+        off = (s_ptr.value - saved.data_ptr()) // 4
+        assign.append(torch.as_strided(saved, (d.n, d.C), (s_ld.value, 1), off).clone())
+    return readout, x_out, A_out
 
 
 def _grad_buffer(owner, slot, n, dev):

@@ -323,7 +323,6 @@ class SoftPoolingGcnEncoder(nn.Module):
             self.jk3 = DenseJK('lstm', hidden_dim, 3)
         self.pred_model = self.build_readout_module(input_dim * 3, pred_hidden_dims, label_dim, activation)
         self.last_graph = None
-        self._graphed = None          # see enable_graph_capture()
         # levels run through the step sequencer (native.py / csrc/exec.hip: one library call per level and direction) whenever it
         # covers the configuration; False (or CGC_NATIVE=0): always the per-operator path (ops.py), one autograd node per operator
         self.native = os.environ.get('CGC_NATIVE', '1') != '0'
@@ -390,8 +389,11 @@ class SoftPoolingGcnEncoder(nn.Module):
 
     # -- stages --------------------------------------------------------------------------------
     def _use_native(self, x):
-        return (self.native and self.training and torch.is_grad_enabled() and self._graphed is None and x.is_cuda
-                and x.dtype == torch.float32 and not x.requires_grad)
+        """Training steps (autograd on) and inference under no_grad both run on the sequencer; anything in between -- eval mode with
+        gradients enabled, training mode under no_grad -- stays on the per-operator path."""
+        if not (self.native and x.is_cuda and x.dtype == torch.float32 and not x.requires_grad):
+            return False
+        return torch.is_grad_enabled() if self.training else not torch.is_grad_enabled()
 
     def _native_level(self, level, x, adj, g=None):
         """One level through the sequencer; None when it does not cover this configuration."""
@@ -413,7 +415,10 @@ class SoftPoolingGcnEncoder(nn.Module):
         if desc is None:
             return None
         assign = [] if (self.collect_assign and pool is not None) else None
-        out = native.level(self, desc, emb, pool, jk, g, gptr, x.contiguous(), adj, assign, prep)
+        if self.training:
+            out = native.level(self, desc, emb, pool, jk, g, gptr, x.contiguous(), adj, assign, prep)
+        else:
+            out = native.level_eval(self, desc, emb, pool, jk, g, gptr, x.contiguous(), adj, assign, prep)
         if assign:
             s = assign[0]
             self.assign_matrix.append(self._pad_assign(s, g) if level == 1 else s.view(desc.B, desc.rows_per_graph, -1))
@@ -524,58 +529,10 @@ class SoftPoolingGcnEncoder(nn.Module):
         xn, an = ops.diff_pool_dense(embed.view(B, C, -1), adj, s.view(B, C, -1))
         return readout, xn, an
 
-    # -- hipGraph capture of the fixed-shape part ----------------------------------------------------
-    def enable_graph_capture(self, enabled=True):
-        """Levels 2 and 3 work on [B, C1, *] / [B, C2, *] tensors whose shapes depend only on the batch size -- not on the
-        graphs -- so their forward and their backward (about 60 % of a step's ~440 kernel launches) can be captured ONCE per
-        batch size into two hipGraphs and replayed: two graph launches instead of ~250 kernel launches through Python.  That
-        is what bounds the step when the per-GPU batch is small (strong scaling: 4 graphs per GPU at 8 GPUs) or the cluster
-        counts are (max_num_nodes = 1800): those steps are host-bound, not GPU-bound.  Level 1 (shapes follow the graphs)
-        stays eager.  Used in training mode with gradients enabled and ``collect_assign`` off; anything else runs eagerly.
-        Same kernels, same order, same buffers' update rules: results are bitwise those of the eager path."""
-        self._graphed = {} if enabled else None
-        return self
-
-    def _dense_levels_eager(self, x, adj):
+    def _dense_levels(self, x, adj):
         out2, x, adj = self._dense_level(2, x, adj)
         out3, _, _ = self._dense_level(3, x, adj)
         return out2, out3
-
-    def _dense_levels(self, x, adj):
-        if (self._graphed is None or not self.training or not torch.is_grad_enabled() or self.collect_assign
-                or not x.is_cuda or not (x.requires_grad and adj.requires_grad)):
-            return self._dense_levels_eager(x, adj)
-        mods = [self.GCN_embed_2, self.GCN_pool_2, self.GCN_embed_3]
-        # the capture bakes in what the host decided while it ran: BatchNorm's momentum (momentum = None means 1 / num_batches_tracked,
-        # a new value every step -> never captured), which parameters take gradients, the mode flags
-        if any(getattr(m, 'bn%d' % k).momentum is None for m in mods if m.use_bn for k in (1, 2, 3)):
-            return self._dense_levels_eager(x, adj)
-        key = (tuple(x.shape), tuple(adj.shape), x.device.index, self.jk, self.norm_adj,
-               tuple(p.requires_grad for m in mods for p in m.parameters()))
-        g = self._graphed.get(key)
-        if g is None:
-            g = self._capture_dense_levels(x, adj)
-            self._graphed[key] = g
-        if g is False:                          # capture failed once for this shape: stay eager
-            return self._dense_levels_eager(x, adj)
-        return g(x, adj)
-
-    def _capture_dense_levels(self, x, adj):
-        """Warm-up + capture (torch.cuda.make_graphed_callables: three eager warm-up passes on a side stream, then the capture
-        of forward and backward).  Those passes would advance the BatchNorm running statistics: every buffer is restored."""
-        mod = _DenseLevels(self)
-        saved = [(b, b.detach().clone()) for b in mod.buffers()]
-        sample = (x.detach().clone().requires_grad_(True), adj.detach().clone().requires_grad_(True))
-        try:
-            g = torch.cuda.make_graphed_callables(mod, sample, allow_unused_input=True)
-        except Exception as e:                  # noqa: BLE001  (any capture problem: keep training, eagerly)
-            import warnings
-            warnings.warn('hipGraph capture of the dense levels failed (%s: %s); running them eagerly' % (type(e).__name__, e))
-            g = False
-        with torch.no_grad():
-            for b, v in saved:
-                b.copy_(v)
-        return g
 
     def forward(self, data):
         self.assign_matrix = []
@@ -596,20 +553,3 @@ class SoftPoolingGcnEncoder(nn.Module):
             cls_loss = F.cross_entropy(output, label.view(-1))
             return output, cls_loss
         return output
-
-
-class _DenseLevels(nn.Module):
-    """Levels 2 and 3 of an encoder as ONE callable (x2 [B,C1,D], A2 [B,C1,C1]) -> (readout 2, readout 3) for
-    torch.cuda.make_graphed_callables: it owns (references to) exactly the sub-modules those levels use, so that their
-    parameters are the graph's static inputs.  Never registered inside the encoder (its state_dict is untouched)."""
-
-    def __init__(self, enc):
-        super().__init__()
-        self.GCN_embed_2, self.GCN_pool_2, self.GCN_embed_3 = enc.GCN_embed_2, enc.GCN_pool_2, enc.GCN_embed_3
-        if enc.jk:
-            self.jk2, self.jk3 = enc.jk2, enc.jk3
-        object.__setattr__(self, '_enc', enc)           # plain attribute: not a child module
-        self.train(enc.training)
-
-    def forward(self, x, adj):
-        return self._enc._dense_levels_eager(x, adj)

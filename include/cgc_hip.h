@@ -206,6 +206,10 @@ int cgc_bn_finalize(const double* stats /*[2,F] fp64: the variance is a differen
 int cgc_l2norm_act_bn(const float* h, int n, int F, int normalize, int act, float* hn, float* rinv, float* ws, double count,
                       float eps, float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked,
                       float* mean, float* istd, cgc_stream_t stream);
+/* Inference-mode BatchNorm constants from the running statistics: mean[f] = running_mean[f], istd[f] = 1 / sqrt(running_var[f] + eps)
+ * (IEEE division and square root), for cgc_bn_act_apply. */
+int cgc_bn_running_stats(const float* running_mean, const float* running_var, int F, float eps, float* mean, float* istd,
+                         cgc_stream_t stream);
 int cgc_bn_act_apply(const float* hn, int n, int F, int act, const float* mean /*NULL: no BN*/, const float* istd,
                      const float* gamma, const float* beta, float* y, int ldy, cgc_stream_t stream);
 /* cgc_bn_act_apply writing the same values to a second destination y2 [n, F] (row stride ldy2) as well (NULL: none) */
@@ -349,6 +353,10 @@ typedef struct {
   float renorm_p;
   float bn_eps[6], bn_momentum[6];         /* embedding block layers 0..2, assignment block layers 3..5 */
   double count;           /* rows BatchNorm statistics are taken over: B * npad (level 1, padding included), n otherwise */
+  int eval;               /* 1: inference forward (model.eval() under no_grad; train.py:21-91): BatchNorm normalises with the running
+                           * statistics and leaves them alone, nothing is kept for a backward (`saved` is working memory only);
+                           * cgc_level_bwd refuses such a descriptor */
+  int reserved;
 } cgc_level_desc;
 
 typedef struct {          /* one GNN_Module's parameters (DEVICE pointers; unused ones NULL) */

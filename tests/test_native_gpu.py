@@ -107,14 +107,70 @@ def test_sequencer_bitwise_on_the_shipped_configuration():
     assert not diff, diff
 
 
+def _used_native_eval(model, batch):
+    calls = []
+    orig = network.native.level_eval
+
+    def spy(*a, **k):
+        calls.append(1)
+        return orig(*a, **k)
+    network.native.level_eval = spy
+    try:
+        out = model(batch)
+    finally:
+        network.native.level_eval = orig
+    return out, len(calls)
+
+
+@pytest.mark.parametrize('flags', [dict(), dict(norm_adj=True, jk=True, drop_out=0.2), dict(norm_adj=True, activation='elu')],
+                         ids=['plain', 'shipped', 'elu'])
+def test_inference_runs_on_the_sequencer_and_equals_the_per_operator_path(flags):
+    """model.eval() under no_grad -- evaluate(), train.py:21-91 -- takes the sequencer too (cgc_level_desc.eval: BatchNorm on its running
+    statistics, nothing kept): three library calls per batch instead of ~260 launches issued from Python.  Logits and assignment
+    matrices equal the per-operator path's to rounding (its 1 / sqrt(running_var + eps) is torch's rsqrt, the library's an IEEE
+    division), the BatchNorm buffers are left alone, and the training path is untouched by a round of inference."""
+    ds = SyntheticCellGraphs(8, 300, num_features=16, base_seed=19)
+    train_b = Batch.from_data_list([ds[i] for i in range(4)]).to(DEV)
+    test_b = Batch.from_data_list([ds[i] for i in range(4, 8)]).to(DEV)
+    kw = dict(concat=True, load_data_sparse=True, collect_assign=True)
+    kw.update(flags)
+    nat, ref = _pair((600, 16, 20, 20, True, True, 20, 3, 0.1, [50]), kw)
+    opts = [torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=1e-4) for m in (nat, ref)]
+    for _ in range(3):                                  # move the running statistics and the weights away from their initial values
+        for m, o in zip((nat, ref), opts):
+            torch.manual_seed(1)
+            _, loss = m(train_b)
+            o.zero_grad()
+            loss.backward()
+            o.step()
+    nat.eval(), ref.eval()
+    buffers = {k: v.clone() for k, v in nat.named_buffers()}
+    with torch.no_grad():
+        ln, calls = _used_native_eval(nat, test_b)
+        assert calls == 3, 'inference did not take the sequencer'
+        an = [a.clone() for a in nat.assign_matrix]
+        lr, rcalls = _used_native_eval(ref, test_b)
+        assert rcalls == 0
+    rel = lambda x, y: float((x.double() - y.double()).abs().max() / (y.double().abs().max() + 1e-30))
+    assert ln.shape == lr.shape and rel(ln, lr) < 2e-6, rel(ln, lr)
+    for a, c in zip(an, ref.assign_matrix):
+        assert a.shape == c.shape and rel(a, c) < 2e-6
+    for k, v in nat.named_buffers():
+        assert torch.equal(v, buffers[k]), k                                   # inference leaves BatchNorm's buffers alone
+    lg, gcalls = _used_native_eval(nat, test_b)                                # eval mode WITH autograd: the per-operator path
+    assert gcalls == 0 and rel(lg, lr) < 2e-6
+    nat.train()
+    (_, loss), tcalls = _used_native(nat, train_b)
+    assert tcalls == 3 and torch.isfinite(loss)
+
+
 def test_sequencer_falls_back_outside_its_scope():
-    """Eval mode, GIN blocks and inputs that require a gradient stay on the per-operator path."""
+    """GIN blocks, eval mode with gradients enabled and inputs that require a gradient stay on the per-operator path."""
     ds = SyntheticCellGraphs(3, 200, num_features=16, base_seed=1)
     b = Batch.from_data_list([ds[i] for i in range(3)]).to(DEV)
     m = network.SoftPoolingGcnEncoder(400, 16, 20, 20, True, True, 20, 3, 0.1, [50], concat=True, load_data_sparse=True).to(DEV)
     m.eval()
-    with torch.no_grad():
-        _, calls = _used_native(m, b)
+    _, calls = _used_native(m, b)
     assert calls == 0
     g = network.SoftPoolingGcnEncoder(400, 16, 20, 20, True, True, 20, 3, 0.1, [50], concat=True, load_data_sparse=True,
                                       gcn_name='GIN').to(DEV).train()
