@@ -65,6 +65,9 @@ PROTOTYPES = {
     'cgc_dense_renorm_fwd': [P, I, I, F, P, P],
     'cgc_dense_renorm_bwd': [P, P, I, I, F, P, P],
     'cgc_adj_prep_fwd': [P, I, I, F, P, P, P, P, P],
+    'cgc_adj_prep_fwd2': [P, I, I, F, P, P, P, P, P, P],
+    'cgc_adj_grad_operands': [P, P, I, P, P, P, P, I, P, I, I, P, P, P, I, F, P, P, I, P],
+    'cgc_zero_diag': [P, I, I, P],
     'cgc_adj_prep_bwd': [P, P, P, P, P, P, I, I, F, P, P],
     'cgc_head_fwd': [P, I, I, I, I, I, I, P, P, P, P, P, F, C.c_uint64, P, P, P, P],
     'cgc_head_bwd': [P, I, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P],

@@ -24,7 +24,7 @@ P, I, F_, D_, L = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_int64
 class LevelDesc(C.Structure):
     _fields_ = [('level', I), ('B', I), ('n', I), ('rows_per_graph', I), ('nmax', I), ('npad', I), ('fin', I), ('H', I), ('E', I),
                 ('AH', I), ('C', I), ('has_bias', I), ('has_bn', I), ('act', I), ('jk', I), ('renorm', I), ('renorm_p', F_),
-                ('bn_eps', F_ * 6), ('bn_momentum', F_ * 6), ('count', D_), ('eval', I), ('reserved', I)]
+                ('bn_eps', F_ * 6), ('bn_momentum', F_ * 6), ('count', D_), ('eval', I), ('flags', I)]
 
 
 class BlockParams(C.Structure):
@@ -120,7 +120,7 @@ def prepared(enc, level, emb, pool, jk, fin):
     bn_cfg = tuple((getattr(b, 'bn%d' % k).eps, getattr(b, 'bn%d' % k).momentum, getattr(b, 'bn%d' % k).track_running_stats)
                    for b in blocks if b.use_bn for k in (1, 2, 3))
     key = (tuple(id(t) for t in params), tuple(t.data_ptr() for t in params if t is not None), emb.training, enc.norm_adj, fin, bn_cfg,
-           emb.activation)
+           emb.activation, bool(getattr(enc, 'adj_backward_fused', False)))
     cache = enc.__dict__.setdefault('_native_prepared', {})
     hit = cache.get(level)
     if hit is not None and hit[0] == key:
@@ -177,6 +177,7 @@ def describe(enc, level, emb, pool, jk, B, n, rows_per_graph, nmax, npad, fin, c
     d.act, d.jk = ACT_CODES[emb.activation], int(jk is not None)
     d.renorm, d.renorm_p = int(enc.norm_adj), float(RENORM_P)
     d.eval = int(not emb.training)
+    d.flags = 1 if getattr(enc, 'adj_backward_fused', False) else 0      # (opt-in: see cgc_level_desc.flags)
     for b_i, blk in enumerate(blocks):
         if blk.use_bn:
             for k in range(3):

@@ -328,6 +328,9 @@ class SoftPoolingGcnEncoder(nn.Module):
         self.native = os.environ.get('CGC_NATIVE', '1') != '0'
         self.native_head = os.environ.get('CGC_NATIVE_HEAD', '1') != '0'     # classification head + loss as one kernel each way
         self.reorder_large = os.environ.get('CGC_REORDER', '1') != '0'       # see _spatially_ordered
+        # levels 2-3: the adjacency gradient as one product of thin operands (cgc_level_desc.flags bit 0; -1.4 % per step at C3, up
+        # to 3x the rounding error on the coarsened levels' gradients: off unless asked for)
+        self.adj_backward_fused = os.environ.get('CGC_ADJ_FUSED', '0') == '1'
         self._unorder = None
 
     def __getstate__(self):
