@@ -367,9 +367,14 @@ def main():
         # (sha256 over csrc/ + include/, stamped into the json); otherwise null + "stale"
         if args.flags == 'shipped' and args.maxn == 11404 and args.batch == 32 and args.nodes == 1800:
             src = source_hash()
-            for key, fname in (('traffic', 'r03_traffic.json'), ('counters', 'r03_counters.json')):
+            import glob
+            for key in ('traffic', 'counters'):
+                found = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_%s.json' % key)))      # the latest round's
+                if not found:
+                    continue
+                fname = os.path.basename(found[-1])
                 try:
-                    js = json.load(open(os.path.join(ROOT, 'profiles', fname)))
+                    js = json.load(open(found[-1]))
                 except (OSError, ValueError):
                     continue
                 fresh = js.get('source_sha256') == src
