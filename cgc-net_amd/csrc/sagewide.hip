@@ -17,6 +17,8 @@
 //     the extra address arithmetic costs the second wave per SIMD, 186 us instead of 125 us).
 //   * persistent workgroups stride over the row tiles; at the end each leaves one slot row [2, F] of column sums, folded in a
 //     fixed order in fp64 by k_stats_finalize (rowops.hip): deterministic.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 #define L2_EPS 1e-12f
@@ -157,6 +159,215 @@ __global__ __launch_bounds__(256, 1) void k_sage_wide_fwd(const float* __restric
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Round 4: the same operator as ONE pass of the matrix cores.  Timing ablations of the kernel above (tools/variant_lib.sh,
+// -DCGC_X_SW_*): 149 us with everything, 133 without the stores, 126 without the statistics, 103 without either -- it is bound by
+// its own arithmetic: two rank-K passes of dependent 10-MFMA chains with one accumulator live (W in 90 registers leaves room for
+// no more), not by the 263 MB it writes.  Here W lives in LDS instead ([K][F] k-major: the B fragment of MFMA step s is one
+// conflict-free ds_read_b32), EIGHT waves share it and a 32-row tile (wave w owns NTW column tiles; two waves per SIMD inside one
+// workgroup, one workgroup per CU), and the freed registers hold ALL of the wave's NTW accumulators: the product is computed once,
+// the NTW chains are independent (MFMAs issue back to back), the row norms come from the kept accumulators, and the scaled values are
+// stored from them.  Statistics as above (shifted fp32 sums, the last step in double).
+template <int KS, int NTW, int ACT>      // ACT: activation code at compile time (a run-time switch per element splits every basic block)
+__global__ __launch_bounds__(512, 1) void k_sage_wide_fwd8(const float* __restrict__ agg, int lda, const float* __restrict__ W,
+                                                           const float* __restrict__ bias, int n, int K, int F, int Fp, int normalize,
+                                                           int /*act*/, float* __restrict__ hn, int ldh, float* __restrict__ rinv_out,
+                                                           float* __restrict__ ws, int row_tiles) {
+  extern __shared__ __attribute__((aligned(16))) float sm8[];
+  float* __restrict__ Wl = sm8;                          // [2 KS][Fp]: rows k >= K and columns >= F are zero
+  float* __restrict__ red = sm8 + (size_t)2 * KS * Fp;   // [2][8][32]: squared-norm partials, double buffered over row tiles
+  float* __restrict__ rstrip = red + 512;                // [8][32]: 1 / ||h|| of the tile's rows, one private copy per wave
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int c_base = wave * NTW * 32;
+  if ((F & 3) == 0 && (reinterpret_cast<uintptr_t>(W) & 15u) == 0) {
+    // W -> LDS with every load of a thread in flight at once (a load -> store loop of 50 dependent L2 round trips per thread was
+    // a third of the kernel): 16-byte units, then the zero padding (columns F..Fp, rows K..2 KS)
+    constexpr int MAXU = (2 * KS * 8 * NTW * 8 + 511) / 512;      // ceil(2 KS * Fp / 4 / 512)
+    const int F4 = F >> 2, U = K * F4;
+    float4 tmp[MAXU];
+#pragma unroll
+    for (int j = 0; j < MAXU; ++j) {
+      const int u = min((int)threadIdx.x + j * 512, U - 1);
+      tmp[j] = reinterpret_cast<const float4*>(W)[u];
+    }
+#pragma unroll
+    for (int j = 0; j < MAXU; ++j) {
+      const int u = threadIdx.x + j * 512;
+      if (u < U) {
+        const int k = u / F4, c = u - k * F4;
+        *reinterpret_cast<float4*>(&Wl[(size_t)k * Fp + 4 * c]) = tmp[j];
+      }
+    }
+    for (int i = threadIdx.x; i < 2 * KS * (Fp - F); i += 512) {
+      const int k = i / (Fp - F), c = F + i - k * (Fp - F);
+      Wl[(size_t)k * Fp + c] = 0.f;
+    }
+    for (int i = threadIdx.x; i < (2 * KS - K) * F; i += 512) Wl[(size_t)(K + i / F) * Fp + i % F] = 0.f;
+  } else {
+    for (int i = threadIdx.x; i < 2 * KS * Fp; i += 512) {
+      const int k = i / Fp, c = i - k * Fp;
+      Wl[i] = (k < K && c < F) ? W[(size_t)k * F + c] : 0.f;
+    }
+  }
+  float bia[NTW], s1[NTW], s2[NTW], shift[NTW];
+#pragma unroll
+  for (int t = 0; t < NTW; ++t) {
+    const int col = c_base + t * 32 + l31;
+    bia[t] = (col < F && bias != nullptr) ? bias[col] : 0.f;
+    s1[t] = s2[t] = shift[t] = 0.f;
+  }
+  __syncthreads();
+  int seen = 0, par = 0;
+  const __amdgpu_buffer_rsrc_t rsrc_hn = __builtin_amdgcn_make_buffer_rsrc(hn, 0, (int)((size_t)n * ldh * 4), 0x00020000);
+  float av_next[KS];           // the next row tile's A fragments travel while this one is computed
+  {
+    const float* __restrict__ a = agg + (size_t)min((int)blockIdx.x * 32 + l31, n - 1) * lda;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) av_next[s] = a[min(2 * s + lhi, K - 1)];
+  }
+  for (int rt = blockIdx.x; rt < row_tiles; rt += gridDim.x, par ^= 1) {
+    const int row0 = rt * 32;
+    float av[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) av[s] = (2 * s + lhi) < K ? av_next[s] : 0.f;
+    floatx16 acc[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = bia[t];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const float* __restrict__ wrow = Wl + (size_t)(2 * s + lhi) * Fp + c_base + l31;
+#pragma unroll
+#ifndef CGC_X8_NOMFMA
+      for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], wrow[t * 32], acc[t], 0, 0, 0);
+#else
+      for (int t = 0; t < NTW; ++t) acc[t][s] += av[s] * wrow[t * 32];
+#endif
+    }
+    // The next row tile's A fragments are requested HERE -- behind this tile's MFMAs, in front of the norm reduction -- and waited for
+    // in front of this tile's stores (the empty asm below).  vmcnt counts loads and stores in issue order: a wait for loads that
+    // were issued before ~80 conditional stores (or after them) can only be written as vmcnt(0), i.e. it drains the stores too --
+    // at the top of the next tile that exposed the whole store latency once per row tile, in this kernel and in its predecessor
+    // (whose 149 us no change to its arithmetic or to its stores would move).  Here the drain finds the previous tile's stores
+    // long retired and the fresh loads have the reduction + barrier to arrive.
+    {
+      const int nrt = rt + (int)gridDim.x < row_tiles ? rt + (int)gridDim.x : rt;
+      const float* __restrict__ a = agg + (size_t)min(nrt * 32 + l31, n - 1) * lda;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) av_next[s] = a[min(2 * s + lhi, K - 1)];
+    }
+    float rin[16];
+    if (normalize) {
+      float q[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) q[r] = 0.f;
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) {
+        const bool colok = c_base + t * 32 + l31 < F;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) q[r] = colok ? fmaf(acc[t][r], acc[t][r], q[r]) : q[r];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) q[r] = group_sum(q[r], 32);      // over the 32 columns a half wave holds (DPP + one cross-row step)
+      float* __restrict__ rd = red + par * 256;
+      if (l31 == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rd[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi] = q[r];
+      }
+      __syncthreads();                              // (one barrier per row tile: the next tile writes the other half of `red`)
+      // 1 / ||h|| once per ROW (correctly rounded sqrt and division are ~70 instructions: 16 of them per lane were a third of the
+      // kernel): lane l of every wave does row l & 31 and parks it in the wave's own strip; LDS operations of a wave are ordered
+      float* __restrict__ rs = rstrip + wave * 32;
+      {
+        const float tot = ((rd[l31] + rd[32 + l31]) + (rd[64 + l31] + rd[96 + l31])) + ((rd[128 + l31] + rd[160 + l31]) + (rd[192 + l31] + rd[224 + l31]));
+        if (lhi == 0) rs[l31] = 1.f / fmaxf(sqrtf(tot), L2_EPS);
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) rin[r] = rs[(r & 3) + 8 * (r >> 2) + 4 * lhi];
+      __builtin_amdgcn_wave_barrier();
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) rin[r] = 1.f;
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(av_next[s]));      // (the prefetch has to have landed before the first store)
+    if (wave == 0 && l31 == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        if (row < n) rinv_out[row] = rin[r];
+      }
+    }
+    // Stores: BUFFER stores off one descriptor over hn (num_records = n * ldh floats: rows past n are dropped by the bounds check, lanes
+    // whose column is past F carry an out-of-range offset) -- a lane contributes a loop-invariant byte offset, the row is the
+    // instruction's scalar offset: no per-element predicate, no branch, no 64-bit address arithmetic (the flat form cost a compare, an
+    // exec-mask branch and a 64-bit multiply-add per stored element: ~120 branches per row tile and wave).
+    const bool full = row0 + 32 <= n;            // (all but the last row tile: the statistics need no row mask either)
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+      const int col = c_base + t * 32 + l31;
+      const bool colok = col < F;
+      const unsigned voff = colok ? (unsigned)(4 * lhi * ldh + col) * 4u : 0x80000000u;
+      if (ws != nullptr && rt == (int)blockIdx.x) {     // the workgroup's first row tile fixes the shift (see k_sage_wide_fwd)
+        float t1 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t1 += (row0 + (r & 3) + 8 * (r >> 2) + 4 * lhi) < n ? act_fwd(acc[t][r] * rin[r], ACT) : 0.f;
+        t1 += __shfl_xor(t1, 32);
+        shift[t] = t1 / (float)min(32, n - row0);
+      }
+      float a1 = 0.f, a2 = 0.f;
+      if (full) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = acc[t][r] * rin[r];
+#ifndef CGC_X8_NOSTATS
+          const float d = act_fwd(v, ACT) - shift[t];
+          a1 += d;
+          a2 = fmaf(d, d, a2);
+#endif
+#ifndef CGC_X8_NOSTORE
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc_hn, voff,
+                                                (unsigned)(row0 + (r & 3) + 8 * (r >> 2)) * (unsigned)ldh * 4u, 0);
+#endif
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = acc[t][r] * rin[r];
+          const bool ok = row0 + (r & 3) + 8 * (r >> 2) + 4 * lhi < n;
+          const float d = ok ? act_fwd(v, ACT) - shift[t] : 0.f;
+          a1 += d;
+          a2 = fmaf(d, d, a2);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc_hn, voff,
+                                                (unsigned)(row0 + (r & 3) + 8 * (r >> 2)) * (unsigned)ldh * 4u, 0);
+        }
+      }
+      if (colok) { s1[t] += a1; s2[t] += a2; }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) seen += (row0 + (r & 3) + 8 * (r >> 2) + 4 * lhi) < n ? 1 : 0;
+  }
+  if (ws != nullptr) {
+    double* slot = reinterpret_cast<double*>(ws) + (size_t)blockIdx.x * 2 * F;
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+      const double cn = (double)seen, c = (double)shift[t], a1 = (double)s1[t], a2 = (double)s2[t];
+      const double mean = seen > 0 ? c + a1 / cn : 0.0, M2 = seen > 0 ? a2 - a1 * a1 / cn : 0.0;
+      double so = cn * mean, soo = M2 + cn * mean * mean;
+      so += __shfl_xor(so, 32);
+      soo += __shfl_xor(soo, 32);
+      const int col = c_base + t * 32 + l31;
+      if (lhi == 0 && col < F) {
+        slot[col] = so;
+        slot[F + col] = soo;
+      }
+    }
+  }
+}
+
 extern "C" int cgc_stats_blocks(int n, int F);
 int launch_stats_finalize(const float* ws, int slots, int F, double count, float eps, float momentum, float* running_mean,
                           float* running_var, float* mean, float* istd, int64_t* nbt, hipStream_t stream);   // rowops.hip
@@ -181,6 +392,38 @@ extern "C" int cgc_sage_wide_fwd(const float* agg, int lda, const float* W, cons
     if (stats && wgs > cap) wgs = cap > 0 ? cap : 1;
     float* wsp = stats ? ws : nullptr;
     const int ks = K <= 16 ? 8 : K <= 20 ? 10 : 16;
+    // the single-pass 8-wave kernel when W fits the LDS next to nothing else ([2 ks][Fp] floats + 2 KB): one workgroup per CU
+    static const int use8 = getenv("CGC_SAGE_WIDE8") ? atoi(getenv("CGC_SAGE_WIDE8")) : 1;
+    const int ntw8 = F <= 8 * 5 * 32 ? 5 : 7, Fp = 8 * ntw8 * 32;
+    const size_t lds8 = sizeof(float) * ((size_t)2 * ks * Fp + 512 + 256);
+    if (use8 && F <= 8 * 7 * 32 && lds8 <= 156 * 1024 && n >= 64 && (long long)n * ldh * 4 < (1LL << 31)) {
+      int wg8 = row_tiles < 256 ? row_tiles : 256;
+      if (stats && wg8 > cap) wg8 = cap > 0 ? cap : 1;
+#define SW8_ONE(KS_, NTW_, ACT_)                                                                                                       \
+  do {                                                                                                                                 \
+    static bool attr__[CGC_MAX_DEVICES] = {};                                                                                          \
+    cgc_allow_lds(reinterpret_cast<const void*>(&k_sage_wide_fwd8<KS_, NTW_, ACT_>), 156 * 1024, attr__);                              \
+    hipLaunchKernelGGL((k_sage_wide_fwd8<KS_, NTW_, ACT_>), dim3(wg8), dim3(512), lds8, st, agg, lda, W, bias, n, K, F, Fp, normalize, \
+                       act, hn, ldh, rinv, wsp, row_tiles);                                                                            \
+  } while (0)
+#define SW8_LAUNCH(KS_, NTW_)                                                                                                          \
+  do {                                                                                                                                 \
+    if (act == CGC_ACT_RELU) SW8_ONE(KS_, NTW_, CGC_ACT_RELU);                                                                         \
+    else if (act == CGC_ACT_ELU) SW8_ONE(KS_, NTW_, CGC_ACT_ELU);                                                                      \
+    else if (act == CGC_ACT_LEAKYRELU) SW8_ONE(KS_, NTW_, CGC_ACT_LEAKYRELU);                                                          \
+    else SW8_ONE(KS_, NTW_, CGC_ACT_IDENTITY);                                                                                         \
+  } while (0)
+      if (ntw8 == 5) {
+        if (ks == 8) SW8_LAUNCH(8, 5); else if (ks == 10) SW8_LAUNCH(10, 5); else SW8_LAUNCH(16, 5);
+      } else {
+        if (ks == 8) SW8_LAUNCH(8, 7); else if (ks == 10) SW8_LAUNCH(10, 7); else SW8_LAUNCH(16, 7);
+      }
+#undef SW8_LAUNCH
+#undef SW8_ONE
+      CGC_RETURN_IF_LAUNCH_FAILED();
+      if (stats) return launch_stats_finalize(ws, wg8, F, count, eps, momentum, running_mean, running_var, mean, istd, num_batches_tracked, st);
+      return 0;
+    }
     const bool narrow = F <= 4 * 9 * 32;
 #define SW_LAUNCH(KS_, NTW_)                                                                                              \
   hipLaunchKernelGGL((k_sage_wide_fwd<KS_, NTW_>), dim3(wgs), dim3(256), 0, st, agg, lda, W, bias, n, K, F, normalize, act, hn, ldh, \
