@@ -573,8 +573,8 @@ def test_fused_statistics_and_finalize(n, F):
 @pytest.mark.parametrize('n,K_,F,lda', [(1, 20, 256, 20), (37, 20, 1140, 40), (1000, 16, 1600, 16), (4100, 20, 1140, 40), (300, 7, 257, 12),
                                          (50, 32, 200, 32), (50, 20, 1700, 20), (50, 33, 512, 36),
                                          (1000, 20, 20, 40), (37, 16, 20, 16), (5, 32, 32, 32), (4100, 20, 18, 20), (1, 8, 4, 8)])
-@pytest.mark.parametrize('stats', [True, False])
-def test_fused_wide_sage_forward(n, K_, F, lda, stats):
+@pytest.mark.parametrize('stats,act', [(True, 1), (False, 1), (True, 2), (True, 3), (False, 0)])
+def test_fused_wide_sage_forward(n, K_, F, lda, stats, act):
     """cgc_sage_wide_fwd: rank-K projection + bias + L2 normalisation (+ BatchNorm statistics, running stats, batch counter) in one
     matrix-core kernel, against GEMM + l2norm_act_bn of the contract; shapes outside its envelope report False and touch nothing."""
     k = hip()
@@ -588,7 +588,7 @@ def test_fused_wide_sage_forward(n, K_, F, lda, stats):
         rm, rv = torch.zeros(F, device=dev), torch.ones(F, device=dev)
         nbt = torch.zeros((), dtype=torch.int64, device=dev)
         mean, istd = torch.zeros(F, device=dev), torch.zeros(F, device=dev)
-        ok = K__.sage_wide_fwd(agg, lda + 4, W.to(dev), bias.to(dev), n, K_, F, True, 1, hn, rinv, stats, count, 1e-5, 0.1,
+        ok = K__.sage_wide_fwd(agg, lda + 4, W.to(dev), bias.to(dev), n, K_, F, True, act, hn, rinv, stats, count, 1e-5, 0.1,
                                rm if stats else None, rv if stats else None, nbt if stats else None,
                                mean if stats else None, istd if stats else None)
         res[name] = (ok, hn, rinv, rm, rv, mean, istd, nbt.double())
