@@ -16,7 +16,7 @@
 // TERMS = 9 / 6 / 3 / 1 pairs.  Reports the launch time, the fp32-equivalent TFLOP/s and the error of sampled outputs against a
 // float64 dot product, next to a plain fp32 fma chain on the host and an fp32-MFMA kernel of the same (naive) structure -- NOT the
 // library's kernel, which does this product in 1160-1180 us.   Results: profiles/r04_bf16_split_probe.txt, DESIGN.md section 8.
-//   hipcc --offload-arch=gfx950 -O3 tools/bf16x9_probe.hip -o tools/bf16x9_probe.bin ;  tools/bf16x9_probe.bin [M N K [extra row pad]]
+//   hipcc --offload-arch=gfx950 -O3 -mllvm -unroll-threshold=100000 tools/bf16x9_probe.hip -o tools/bf16x9_probe.bin ;  tools/bf16x9_probe.bin [M N K [extra row pad]]
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdint>
@@ -290,6 +290,167 @@ __global__ __launch_bounds__(256, NW) void k_gemm_pre(const __bf16* __restrict__
     }
 }
 
+// The in-register split again, with the instruction order placed by hand (tools/pipe_overlap_probe.hip: behind a bf16 MFMA up to
+// ~6 plain vector instructions of the SAME wave cost ~1 cycle each, while a second wave's vector work does not overlap at all, and
+// packed fp32 instructions cost more than two plain ones).  A tile's split is cut into 64 micro-steps of 2-4 instructions (per float4:
+// convert / expand / subtract / convert / expand / subtract / convert / three 8-byte LDS writes) that are dealt out behind the tile's
+// MFMAs, the fragment reads of the second k step behind the first MFMAs, and the global loads behind the last; a scheduling fence
+// after every MFMA keeps the compiler from regrouping them.
+template <int TERMS>
+__global__ __launch_bounds__(256, 1) void k_gemm_split_placed(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M,
+                                                              int N, int K, int ld, int tiles_n) {
+  constexpr int ROW = BK * 2 + 16, PLANE = 128 * ROW, OPER = 3 * PLANE, STAGE = 2 * OPER;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tile = blockIdx.x;
+  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const float* pg[8];                       // units 0-3: A rows, 4-7: B rows
+  int loff[8];
+  const int kq = (threadIdx.x & 7) * 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (threadIdx.x >> 3) + 32 * i;
+    const int ra = m0 + r < M ? m0 + r : M - 1, rb = n0 + r < N ? n0 + r : N - 1;
+    pg[i] = A + (size_t)ra * ld + kq;
+    pg[4 + i] = B + (size_t)rb * ld + kq;
+    loff[i] = r * ROW + kq * 2;
+    loff[4 + i] = OPER + r * ROW + kq * 2;
+  }
+  float4 rx[2][8];                          // two register sets: tile t travels in set t & 1
+  floatx16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int nk = (K + BK - 1) / BK;
+  // prologue: tile 0 through the plain path
+#pragma unroll
+  for (int u = 0; u < 8; ++u) rx[0][u] = *reinterpret_cast<const float4*>(pg[u]);
+  if (nk > 1) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) rx[1][u] = *reinterpret_cast<const float4*>(pg[u] + BK);
+  }
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    bf16x4 h, m, l;
+    split4(rx[0][u], h, m, l);
+    unsigned char* p = lds + loff[u];
+    *reinterpret_cast<bf16x4*>(p) = h;
+    *reinterpret_cast<bf16x4*>(p + PLANE) = m;
+    *reinterpret_cast<bf16x4*>(p + 2 * PLANE) = l;
+  }
+  if (nk > 2) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) rx[0][u] = *reinterpret_cast<const float4*>(pg[u] + 2 * BK);
+  }
+  __syncthreads();
+  constexpr int PA[9] = {0, 0, 1, 0, 1, 2, 1, 2, 2};
+  constexpr int PB[9] = {0, 1, 0, 2, 1, 0, 2, 1, 2};
+  constexpr int NM = TERMS * 8;             // MFMAs per tile and wave
+  auto tile_step = [&](int kt, auto cur_c, auto last_c) {
+    constexpr int cur = decltype(cur_c)::value;
+    constexpr bool has_next = !decltype(last_c)::value;      // (compile-time: no branch behind the MFMAs)
+    const unsigned char* as = lds + cur * STAGE + (wm * 64 + l31) * ROW + lhi * 16;
+    const unsigned char* bs = lds + cur * STAGE + OPER + (wn * 64 + l31) * ROW + lhi * 16;
+    unsigned char* const wbase = lds + (cur ^ 1) * STAGE;
+    float4 (&src)[8] = rx[cur ^ 1];         // tile kt+1
+    bf16x8 fr[2][12];                       // fragments of the two k steps: [A i=0..1][plane], then B
+    // split state of the unit in flight
+    float xs[8][4], r1[8][4], r2[8][4];
+    unsigned hp[8][2], mp[8][2], lp[8][2];
+    auto frag_read = [&](int ks, int q) {   // q = 0..11
+      const int i = (q % 6) / 3, pl = q % 3;
+      fr[ks][q] = *reinterpret_cast<const bf16x8*>((q < 6 ? as : bs) + i * 32 * ROW + pl * PLANE + ks * 32);
+    };
+    auto cvt2 = [&](float a, float b) -> unsigned {
+      float2v t;
+      t[0] = a;
+      t[1] = b;
+      return __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2));
+    };
+    auto micro = [&](int sidx) {
+      const int u = sidx >> 3, st = sidx & 7;
+      if (st == 0) {
+        xs[u][0] = src[u].x; xs[u][1] = src[u].y; xs[u][2] = src[u].z; xs[u][3] = src[u].w;
+        hp[u][0] = cvt2(xs[u][0], xs[u][1]);
+        hp[u][1] = cvt2(xs[u][2], xs[u][3]);
+      } else if (st == 1 || st == 2) {       // expand + subtract, two values per step
+        const int h = st - 1;
+        const float e0 = __builtin_bit_cast(float, hp[u][h] << 16), e1 = __builtin_bit_cast(float, hp[u][h] & 0xffff0000u);
+        r1[u][2 * h] = xs[u][2 * h] - e0;
+        r1[u][2 * h + 1] = xs[u][2 * h + 1] - e1;
+        asm volatile("" : "+v"(r1[u][2 * h]), "+v"(r1[u][2 * h + 1]));
+      } else if (st == 3) {
+        mp[u][0] = cvt2(r1[u][0], r1[u][1]);
+        mp[u][1] = cvt2(r1[u][2], r1[u][3]);
+      } else if (st == 4 || st == 5) {
+        const int h = st - 4;
+        const float e0 = __builtin_bit_cast(float, mp[u][h] << 16), e1 = __builtin_bit_cast(float, mp[u][h] & 0xffff0000u);
+        r2[u][2 * h] = r1[u][2 * h] - e0;
+        r2[u][2 * h + 1] = r1[u][2 * h + 1] - e1;
+        asm volatile("" : "+v"(r2[u][2 * h]), "+v"(r2[u][2 * h + 1]));
+      } else if (st == 6) {
+        lp[u][0] = cvt2(r2[u][0], r2[u][1]);
+        lp[u][1] = cvt2(r2[u][2], r2[u][3]);
+      } else {
+        unsigned char* p = wbase + loff[u];
+        *reinterpret_cast<uint2*>(p) = make_uint2(hp[u][0], hp[u][1]);
+        *reinterpret_cast<uint2*>(p + PLANE) = make_uint2(mp[u][0], mp[u][1]);
+        *reinterpret_cast<uint2*>(p + 2 * PLANE) = make_uint2(lp[u][0], lp[u][1]);
+      }
+    };
+#pragma unroll
+    for (int q = 0; q < 12; ++q) frag_read(0, q);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma clang loop unroll(full)
+    for (int m = 0; m < NM; ++m) {
+      const int ks = m / (NM / 2), mm = m % (NM / 2);
+      const int t = mm / 4, ij = mm % 4, i = ij >> 1, j = ij & 1;
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[ks][i * 3 + PA[t]], fr[ks][6 + j * 3 + PB[t]], acc[i][j], 0, 0, 0);
+      if (m < 12) frag_read(1, m);                              // the second k step's fragments, one read behind each of the first MFMAs
+      if constexpr (has_next) {
+#pragma unroll
+        for (int sidx = (m * 64) / NM; sidx < ((m + 1) * 64) / NM; ++sidx) micro(sidx);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (kt + 3 < nk) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) src[u] = *reinterpret_cast<const float4*>(pg[u] + (kt + 3) * BK);
+    }
+    __syncthreads();
+  };
+  typedef std::integral_constant<int, 0> C0;
+  typedef std::integral_constant<int, 1> C1;
+  int kt = 0;
+  for (; kt + 2 < nk; kt += 2) {
+    tile_step(kt, C0(), std::false_type());
+    tile_step(kt + 1, C1(), std::false_type());
+  }
+  if (kt + 1 < nk) {
+    tile_step(kt, C0(), std::false_type());
+    tile_step(kt + 1, C1(), std::true_type());
+  } else if (kt < nk) {
+    tile_step(kt, C0(), std::true_type());
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        if (row < M && col < N) C[(size_t)row * N + col] = acc[i][j][r];
+      }
+    }
+}
+
 // the fp32 matrix-core chain over the same tiling, as the yardstick of both time and error (32x32x2, operands as fp32 in LDS)
 __global__ __launch_bounds__(256, 2) void k_gemm_f32ref(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M,
                                                         int N, int K, int ld, int tiles_n) {
@@ -495,6 +656,16 @@ int main(int argc, char** argv) {
   SPLIT_RUN(6, 16, "bf16 x 6 (pairs >= 2^-24), 2 wg/CU", 192);
   SPLIT_RUN(3, 16, "bf16 x 3 (pairs >= 2^-16), 2 wg/CU", 96);
   SPLIT_RUN(1, 16, "bf16 x 1 (plain bf16), 2 wg/CU", 32);
+#define PLACED_RUN(T_, name_, cyc_)                                                                                               \
+  do {                                                                                                                            \
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_split_placed<T_>), hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                           (int)lds_bytes(32)));                                                                                  \
+    run(name_, [&] { hipLaunchKernelGGL((k_gemm_split_placed<T_>), dim3(tiles), dim3(256), lds_bytes(32), 0, dA, dB, dC, M, N, K, ld, tiles_n); }, \
+        dA, dB, dC, M, N, K, samples, cyc_);                                                                                      \
+  } while (0)
+  PLACED_RUN(9, "bf16 x 9, split placed by hand", 288);
+  PLACED_RUN(6, "bf16 x 6, split placed by hand", 192);
+  PLACED_RUN(3, "bf16 x 3, split placed by hand", 96);
   // operands split ahead of the product
   __bf16 *pA, *pB;
   const long long planeA = (long long)M * ld, planeB = (long long)N * ld;
