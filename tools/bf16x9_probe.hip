@@ -451,6 +451,155 @@ __global__ __launch_bounds__(256, 1) void k_gemm_split_placed(const float* __res
     }
 }
 
+// The placed split on a 256 x 128 tile: 512 threads (4 x 2 waves of 64 x 64), 16-wide k-tiles (110 KB of LDS double-buffered, one
+// workgroup per CU), four register sets (a tile is requested four k-tiles before it is split), the three loads of a k-tile dealt
+// out behind MFMAs like everything else, no branch inside a k-tile.  A 256 x 128 tile asks L2 for 3.7 GB per launch instead of 4.9.
+template <int TERMS>
+__global__ __launch_bounds__(512, 1) void k_gemm_split_big(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M,
+                                                           int N, int K, int ld, int tiles_n) {
+  constexpr int BKb = 16, ROW = BKb * 2 + 16;
+  constexpr int PLA = 256 * ROW, PLB = 128 * ROW, STAGE = 3 * PLA + 3 * PLB;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tile = blockIdx.x;
+  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  const int m0 = tm * 256, n0 = tn * 128;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const float* pg[3];                       // units 0-1: A rows, 2: a B row
+  int loff[3];
+  const int kq = (threadIdx.x & 3) * 4;
+  {
+    const int r = threadIdx.x >> 2;         // 0..127
+    const int ra0 = m0 + r < M ? m0 + r : M - 1, ra1 = m0 + 128 + r < M ? m0 + 128 + r : M - 1, rb = n0 + r < N ? n0 + r : N - 1;
+    pg[0] = A + (size_t)ra0 * ld + kq;
+    pg[1] = A + (size_t)ra1 * ld + kq;
+    pg[2] = B + (size_t)rb * ld + kq;
+    loff[0] = r * ROW + kq * 2;
+    loff[1] = (128 + r) * ROW + kq * 2;
+    loff[2] = 3 * PLA + r * ROW + kq * 2;
+  }
+  float4 rx[4][3];                          // tile t travels in set t & 3
+  floatx16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int nk = (K + BKb - 1) / BKb;
+  auto koff = [&](int t) { return (t < nk ? t : nk - 1) * BKb; };      // past the end: the last tile again (never used)
+  float4 first[3];
+#pragma unroll
+  for (int u = 0; u < 3; ++u) first[u] = *reinterpret_cast<const float4*>(pg[u]);
+#pragma unroll
+  for (int t = 1; t <= 4; ++t)
+#pragma unroll
+    for (int u = 0; u < 3; ++u) rx[t & 3][u] = *reinterpret_cast<const float4*>(pg[u] + koff(t));
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    bf16x4 h, m, l;
+    split4(first[u], h, m, l);
+    unsigned char* p = lds + loff[u];
+    const int pl = u < 2 ? PLA : PLB;
+    *reinterpret_cast<bf16x4*>(p) = h;
+    *reinterpret_cast<bf16x4*>(p + pl) = m;
+    *reinterpret_cast<bf16x4*>(p + 2 * pl) = l;
+  }
+  __syncthreads();
+  constexpr int PA[9] = {0, 0, 1, 0, 1, 2, 1, 2, 2};
+  constexpr int PB[9] = {0, 1, 0, 2, 1, 0, 2, 1, 2};
+  constexpr int NM = TERMS * 4;             // MFMAs per k-tile and wave
+  auto tile_step = [&](int kt, auto cur_c, auto set_c) {
+    constexpr int cur = decltype(cur_c)::value;
+    constexpr int set = decltype(set_c)::value;                    // the set of tile kt + 1
+    const unsigned char* as = lds + cur * STAGE + (wm * 64 + l31) * ROW + lhi * 16;
+    const unsigned char* bs = lds + cur * STAGE + 3 * PLA + (wn * 64 + l31) * ROW + lhi * 16;
+    unsigned char* const wbase = lds + (cur ^ 1) * STAGE;
+    float4 (&src)[3] = rx[set];
+    bf16x8 fr[12];
+    float xs[3][4], r1[3][4], r2[3][4];
+    unsigned hp[3][2], mp[3][2], lp[3][2];
+    auto cvt2 = [&](float a, float b) -> unsigned {
+      float2v t;
+      t[0] = a;
+      t[1] = b;
+      return __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2));
+    };
+    auto micro = [&](int sidx) {
+      const int u = sidx >> 3, st = sidx & 7;
+      if (st == 0) {
+        xs[u][0] = src[u].x; xs[u][1] = src[u].y; xs[u][2] = src[u].z; xs[u][3] = src[u].w;
+        hp[u][0] = cvt2(xs[u][0], xs[u][1]);
+        hp[u][1] = cvt2(xs[u][2], xs[u][3]);
+      } else if (st == 1 || st == 2) {
+        const int h = st - 1;
+        const float e0 = __builtin_bit_cast(float, hp[u][h] << 16), e1 = __builtin_bit_cast(float, hp[u][h] & 0xffff0000u);
+        r1[u][2 * h] = xs[u][2 * h] - e0;
+        r1[u][2 * h + 1] = xs[u][2 * h + 1] - e1;
+        asm volatile("" : "+v"(r1[u][2 * h]), "+v"(r1[u][2 * h + 1]));
+      } else if (st == 3) {
+        mp[u][0] = cvt2(r1[u][0], r1[u][1]);
+        mp[u][1] = cvt2(r1[u][2], r1[u][3]);
+      } else if (st == 4 || st == 5) {
+        const int h = st - 4;
+        const float e0 = __builtin_bit_cast(float, mp[u][h] << 16), e1 = __builtin_bit_cast(float, mp[u][h] & 0xffff0000u);
+        r2[u][2 * h] = r1[u][2 * h] - e0;
+        r2[u][2 * h + 1] = r1[u][2 * h + 1] - e1;
+        asm volatile("" : "+v"(r2[u][2 * h]), "+v"(r2[u][2 * h + 1]));
+      } else if (st == 6) {
+        lp[u][0] = cvt2(r2[u][0], r2[u][1]);
+        lp[u][1] = cvt2(r2[u][2], r2[u][3]);
+      } else {
+        unsigned char* p = wbase + loff[u];
+        const int pl = u < 2 ? PLA : PLB;
+        *reinterpret_cast<uint2*>(p) = make_uint2(hp[u][0], hp[u][1]);
+        *reinterpret_cast<uint2*>(p + pl) = make_uint2(mp[u][0], mp[u][1]);
+        *reinterpret_cast<uint2*>(p + 2 * pl) = make_uint2(lp[u][0], lp[u][1]);
+      }
+    };
+#pragma unroll
+    for (int q = 0; q < 12; ++q) {       // (issued in the order the MFMAs want them instead: 876 vs 847 us -- no gain)
+      const int i = (q % 6) / 3, pl = q % 3;
+      fr[q] = *reinterpret_cast<const bf16x8*>((q < 6 ? as + pl * PLA : bs + pl * PLB) + i * 32 * ROW);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const int knext = koff(kt + 5);
+#pragma clang loop unroll(full)
+    for (int m = 0; m < NM; ++m) {
+      const int t = m / 4, ij = m % 4, i = ij >> 1, j = ij & 1;
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i * 3 + PA[t]], fr[6 + j * 3 + PB[t]], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int sidx = (m * 24) / NM; sidx < ((m + 1) * 24) / NM; ++sidx) micro(sidx);
+      // the set's registers are free once its three units have been picked up (micro-steps 0, 8, 16): tile kt+5 goes there
+      if (m >= NM - 3) src[m - (NM - 3)] = *reinterpret_cast<const float4*>(pg[m - (NM - 3)] + knext);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+  };
+  typedef std::integral_constant<int, 0> I0;
+  typedef std::integral_constant<int, 1> I1;
+  typedef std::integral_constant<int, 2> I2;
+  typedef std::integral_constant<int, 3> I3;
+  for (int kt = 0; kt < nk; kt += 4) {
+    tile_step(kt, I0(), I1());
+    if (kt + 1 < nk) tile_step(kt + 1, I1(), I2());
+    if (kt + 2 < nk) tile_step(kt + 2, I0(), I3());
+    if (kt + 3 < nk) tile_step(kt + 3, I1(), I0());
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        if (row < M && col < N) C[(size_t)row * N + col] = acc[i][j][r];
+      }
+    }
+}
+
 // the fp32 matrix-core chain over the same tiling, as the yardstick of both time and error (32x32x2, operands as fp32 in LDS)
 __global__ __launch_bounds__(256, 2) void k_gemm_f32ref(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M,
                                                         int N, int K, int ld, int tiles_n) {
@@ -666,6 +815,20 @@ int main(int argc, char** argv) {
   PLACED_RUN(9, "bf16 x 9, split placed by hand", 288);
   PLACED_RUN(6, "bf16 x 6, split placed by hand", 192);
   PLACED_RUN(3, "bf16 x 3, split placed by hand", 96);
+  {
+    const int tiles_big = ((M + 255) / 256) * tiles_n;
+    const size_t lds_big = (size_t)2 * (3 * 256 + 3 * 128) * 48;
+#define BIG_RUN(T_, name_, cyc_)                                                                                                  \
+  do {                                                                                                                            \
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_split_big<T_>), hipFuncAttributeMaxDynamicSharedMemorySize,      \
+                           (int)lds_big));                                                                                        \
+    run(name_, [&] { hipLaunchKernelGGL((k_gemm_split_big<T_>), dim3(tiles_big), dim3(512), lds_big, 0, dA, dB, dC, M, N, K, ld, tiles_n); }, \
+        dA, dB, dC, M, N, K, samples, cyc_);                                                                                      \
+  } while (0)
+    BIG_RUN(9, "bf16 x 9, placed, 256 x 128 tile", 288);
+    BIG_RUN(6, "bf16 x 6, placed, 256 x 128 tile", 192);
+    BIG_RUN(3, "bf16 x 3, placed, 256 x 128 tile", 96);
+  }
   // operands split ahead of the product
   __bf16 *pA, *pB;
   const long long planeA = (long long)M * ld, planeB = (long long)N * ld;
