@@ -26,17 +26,23 @@ __device__ __forceinline__ float head_keep(unsigned long long seed, unsigned i, 
   return u < p ? 0.f : 1.f / (1.f - p);
 }
 
-// A label outside [0, L) contributes neither loss nor gradient and the mean runs over the remaining samples: F.cross_entropy's
-// ignore_index = -100 behaviour (model/network.py:289 passes no ignore_index, so -100 is the ignored value there too).  torch raises a
-// device-side assertion for any OTHER out-of-range label; here those are ignored as well rather than read out of bounds.
+// F.cross_entropy's labels (model/network.py:289 passes no ignore_index, so -100 is the ignored value): a label of -100 contributes
+// neither loss nor gradient and the mean runs over the remaining samples.  torch raises a device-side assertion for any OTHER label
+// outside [0, L); a kernel cannot raise, so such a label POISONS the step instead: head_valid_count returns NaN, which makes the loss
+// and every gradient NaN (and it is never used as an index).  Silently dropping it would shrink the mean's denominator unnoticed.
 __device__ __forceinline__ bool head_label_ok(const HeadArgs& a, int b) {
   const long long y = a.y[b];
   return y >= 0 && y < (long long)a.L;
 }
 __device__ __forceinline__ float head_valid_count(const HeadArgs& a) {
   int valid = 0;
-  for (int b = 0; b < a.B; ++b) valid += head_label_ok(a, b) ? 1 : 0;
-  return (float)valid;
+  bool bad = false;
+  for (int b = 0; b < a.B; ++b) {
+    const bool ok = head_label_ok(a, b);
+    valid += ok ? 1 : 0;
+    bad = bad || (!ok && a.y[b] != -100);
+  }
+  return bad ? __builtin_nanf("") : (float)valid;
 }
 
 // z [B,H1] pre-activation, keep [B,H1] dropout scale, h [B,H1] = act(z) * keep, logits [B,L], loss [1]
@@ -71,12 +77,8 @@ __global__ __launch_bounds__(256) void k_head_fwd_simple(HeadArgs a, float* __re
   __syncthreads();
   if (threadIdx.x == 0) {
     float s = 0.f;
-    int valid = 0;
-    for (int b = 0; b < a.B; ++b) {
-      s += lse[b];
-      valid += head_label_ok(a, b) ? 1 : 0;
-    }
-    loss[0] = s / (float)valid;
+    for (int b = 0; b < a.B; ++b) s += lse[b];
+    loss[0] = s / head_valid_count(a);
   }
 }
 

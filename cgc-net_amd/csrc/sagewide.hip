@@ -341,7 +341,9 @@ __global__ __launch_bounds__(512, 1) void k_sage_wide_fwd8(const float* __restri
           const float d = ok ? act_fwd(v, ACT) - shift[t] : 0.f;
           a1 += d;
           a2 = fmaf(d, d, a2);
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc_hn, voff,
+          // (the partial last tile: rows past n are dropped by the LANE's own offset, not by the scalar row offset -- whether the
+          // bounds check of a raw buffer includes soffset is not something to rely on)
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc_hn, ok ? voff : 0x80000000u,
                                                 (unsigned)(row0 + (r & 3) + 8 * (r >> 2)) * (unsigned)ldh * 4u, 0);
         }
       }

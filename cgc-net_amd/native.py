@@ -108,6 +108,11 @@ def _f32ok(*ts):
     return all(t is None or (t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda) for t in ts)
 
 
+def _mode_modules(blk):
+    """The modules of a block whose .training flag decides what the sequencer computes (BatchNorm on batch or running statistics)."""
+    return [blk] + ([getattr(blk, 'bn%d' % k) for k in (1, 2, 3)] if blk.use_bn else [])
+
+
 def prepared(enc, level, emb, pool, jk, fin):
     """Everything about a level that does not change from batch to batch: whether the sequencer covers it, a LevelDesc template,
     the parameter tensors in the Function's order and the pointer structs -- ~0.4 ms of Python per step when it was redone for
@@ -119,8 +124,9 @@ def prepared(enc, level, emb, pool, jk, fin):
     params = _block_tensors(emb) + (_block_tensors(pool) if pool is not None else []) + (_jk_tensors(jk) if jk is not None else [])
     bn_cfg = tuple((getattr(b, 'bn%d' % k).eps, getattr(b, 'bn%d' % k).momentum, getattr(b, 'bn%d' % k).track_running_stats)
                    for b in blocks if b.use_bn for k in (1, 2, 3))
-    key = (tuple(id(t) for t in params), tuple(t.data_ptr() for t in params if t is not None), emb.training, enc.norm_adj, fin, bn_cfg,
-           emb.activation, bool(getattr(enc, 'adj_backward_fused', False)))
+    modes = (enc.training,) + tuple(m.training for b in blocks for m in _mode_modules(b))
+    key = (tuple(id(t) for t in params), tuple(t.data_ptr() for t in params if t is not None), modes, enc.norm_adj, fin, bn_cfg,
+           emb.activation, bool(getattr(enc, 'adj_backward_fused', False)), int(getattr(enc, 'gemm_mode', 0)))
     cache = enc.__dict__.setdefault('_native_prepared', {})
     hit = cache.get(level)
     if hit is not None and hit[0] == key:
@@ -144,6 +150,11 @@ def describe(enc, level, emb, pool, jk, B, n, rows_per_graph, nmax, npad, fin, c
     """LevelDesc for one level, or None when the sequencer does not cover the configuration (the caller then takes the
     per-operator path)."""
     blocks = [emb] + ([pool] if pool is not None else [])
+    # ONE train / eval decision per level, taken from the encoder (network._native_level dispatches on enc.training): a block or a
+    # BatchNorm in the other mode (a frozen block while fine-tuning) is the per-operator path's business -- the sequencer would size
+    # its scratch for one mode and normalise with the other's statistics
+    if any(m.training != enc.training for blk in blocks for m in _mode_modules(blk)):
+        return None
     for blk in blocks:
         if not blk.mean_aggregation or blk.add_loop:
             return None
@@ -176,13 +187,14 @@ def describe(enc, level, emb, pool, jk, B, n, rows_per_graph, nmax, npad, fin, c
     d.has_bias, d.has_bn = int(emb.gcn1.bias is not None), int(emb.use_bn)
     d.act, d.jk = ACT_CODES[emb.activation], int(jk is not None)
     d.renorm, d.renorm_p = int(enc.norm_adj), float(RENORM_P)
-    d.eval = int(not emb.training)
-    d.flags = 1 if getattr(enc, 'adj_backward_fused', False) else 0      # (opt-in: see cgc_level_desc.flags)
+    d.eval = int(not enc.training)
+    d.flags = (1 if getattr(enc, 'adj_backward_fused', False) else 0) | (2 if int(getattr(enc, 'gemm_mode', 0)) == 1 else 0)
     for b_i, blk in enumerate(blocks):
         if blk.use_bn:
             for k in range(3):
                 bn = getattr(blk, 'bn%d' % (k + 1))
-                d.bn_eps[3 * b_i + k], d.bn_momentum[3 * b_i + k] = bn.eps, bn.momentum
+                # (momentum None = cumulative average: refused above in training; unused in inference)
+                d.bn_eps[3 * b_i + k], d.bn_momentum[3 * b_i + k] = bn.eps, 0.0 if bn.momentum is None else bn.momentum
     d.count = float(count)
     if emb.gcn1.in_channels != fin or (pool is not None and pool.gcn1.in_channels != fin):
         return None

@@ -199,8 +199,9 @@ class GNN_Module(nn.Module):
             conv = getattr(self, 'gcn%d' % k)
             bn = getattr(self, 'bn%d' % k) if self.use_bn else None
             agg = agg0 if (k == 1 and agg0 is not None) else aggregate(h)
+            training = bn.training if bn is not None else self.training     # (nn.BatchNorm1d follows its OWN flag: model/network.py:101-107)
             if self.mean_aggregation and row_mask is None:
-                h = ops.sage_project(agg, conv.weight, conv.bias, bn, count, self.activation, conv.normalize, self.training)
+                h = ops.sage_project(agg, conv.weight, conv.bias, bn, count, self.activation, conv.normalize, training)
                 outs.append(h)
                 continue
             if self.mean_aggregation:
@@ -210,11 +211,11 @@ class GNN_Module(nn.Module):
                     agg = agg + (1 + float(conv.eps)) * h
                 z, normalize = conv.mlp(agg), False
             if row_mask is None:
-                h = ops.l2_act_bn(z, bn, count, self.activation, normalize, self.training)
+                h = ops.l2_act_bn(z, bn, count, self.activation, normalize, training)
             else:   # padded dense layout: conv output is masked BEFORE activation/BN (model/network.py:114)
                 if normalize:
-                    z = ops.l2_act_bn(z, None, count, 'identity', True, self.training)
-                h = ops.l2_act_bn(z * row_mask, bn, count, self.activation, False, self.training)
+                    z = ops.l2_act_bn(z, None, count, 'identity', True, training)
+                h = ops.l2_act_bn(z * row_mask, bn, count, self.activation, False, training)
             outs.append(h)
         if row_mask is None:
             return self._tail(outs, softmax)
@@ -276,9 +277,9 @@ def run_blocks_paired(emb, pool, x, aggregate, count, agg0):
         if k < 3 and ce.out_channels + cp.out_channels <= 256:
             # layers whose outputs are aggregated together next: both blocks write into ONE [rows, we + wp] buffer
             pair = torch.empty(x.shape[0], ce.out_channels + cp.out_channels, dtype=torch.float32, device=x.device)
-        he = ops.sage_project(ae, ce.weight, ce.bias, be, count, emb.activation, ce.normalize, emb.training,
+        he = ops.sage_project(ae, ce.weight, ce.bias, be, count, emb.activation, ce.normalize, be.training if be is not None else emb.training,
                               out=None if pair is None else (pair, 0))
-        hp = ops.sage_project(ap, cp.weight, cp.bias, bp, count, pool.activation, cp.normalize, pool.training,
+        hp = ops.sage_project(ap, cp.weight, cp.bias, bp, count, pool.activation, cp.normalize, bp.training if bp is not None else pool.training,
                               out=None if pair is None else (pair, ce.out_channels))
         outs_e.append(he)
         outs_p.append(hp)

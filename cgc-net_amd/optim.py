@@ -141,6 +141,7 @@ class Adam(torch.optim.Adam):
             self._flush_steps()
             out = self._scaled_step()                 # torch's own path creates the state on the first step
             self._lists = self._cache()
+            self._uneven = False                      # re-examined on the next step: uneven step counts can be transient
             if self._model is not None and self._lists is not None and self._table is None:
                 self._table = self._build_table()
             return out

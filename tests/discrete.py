@@ -59,11 +59,28 @@ def record_hip_decisions(model):
             dec.preact[names[id(weight)]] = y.grad_fn.saved_tensors[2]
         return y
     K.segment_max_fwd, ops.sage_project = seg_spy, sage_spy
+    # GIN blocks (model/network.py:96-99) do not go through sage_project: their block activation is applied by l2_act_bn to the
+    # output of the convolution's MLP -- recorded per block in call order (three per block and forward)
+    l2_act_bn, gin_calls = ops.l2_act_bn, {}
+    gin_blocks = {id(m): k for k, m in model.named_children() if hasattr(m, 'gcn1') and not m.mean_aggregation}
+
+    def l2_spy(z, bn, *a, **k):
+        y = l2_act_bn(z, bn, *a, **k)
+        if bn is not None:
+            for bid, bname in gin_blocks.items():
+                blk = dict(model.named_children())[bname]
+                for kk in (1, 2, 3):
+                    if getattr(blk, 'bn%d' % kk, None) is bn:
+                        dec.preact['%s.gcn%d' % (bname, kk)] = z.detach()
+        return y
+    if gin_blocks:
+        ops.l2_act_bn = l2_spy
     try:
         yield dec
     finally:
         del K.segment_max_fwd                           # the instance attribute shadowing the method
         ops.sage_project = sage_project
+        ops.l2_act_bn = l2_act_bn
 
 
 def _to_dense(flat, counts, like):
@@ -314,15 +331,13 @@ def load_reference_fp64(name):
 def oracle_fp64_on_case(name):
     """The dense oracle in float64 on a golden case through the recording machinery of this module.
     Returns (ref64 module with .grad populated, inp64, logits, loss, pre-activations, embeds)."""
-    from util import build_model, load_case
+    from util import build_model, dense_inputs, load_case
     cfg, batch, sd, _out, _grad, _sd3 = load_case(name)
     ref64 = build_model(dense_ref.SoftPoolingGcnEncoder, cfg, collect_assign=True)
     ref64.load_state_dict(sd)
     ref64 = ref64.double().train()
     ref64.load_data_sparse = False
-    adj = dense_ref.to_dense_adj(batch.edge_index, batch.batch)
-    xd, counts = dense_ref.to_dense_batch(batch.x, batch.batch)
-    inp64 = (xd.double(), adj.double(), counts, batch.y.view(-1))
+    inp64 = dense_inputs(batch, torch.float64)
     l64, loss64, pre64, embeds64 = run_oracle_recording(ref64, inp64)
     return ref64, inp64, l64, loss64, pre64, embeds64
 
@@ -365,10 +380,10 @@ def compare_with_reference_fp64(name, tol_grad=1e-4):
     3. if every decision agrees, the HIP gradients are held to 1e-4 of ``grad64`` directly.  If some undecidable point was taken
        differently, the float64 gradient for THAT choice comes from the validated oracle (run_oracle_routed) -- and is printed.
 
-    The bar per parameter is max(tol_grad, 2 x ulp64[parameter]): ``ulp64`` (also produced by the reference, in float64) is how far that
-    gradient moves when the parameters are perturbed by ONE float32 rounding -- no float32 evaluation can be closer than its own
-    input rounding allows.  On the five fixtures it exceeds 5.2e-5 for two parameters (medium_shipped: GCN_embed_3.gcn1.bias 2.5e-4, .weight 8.5e-5);
-    everywhere else the bar is the plain 1e-4."""
+    The bar is the plain ``tol_grad`` on every parameter -- round 4 widened it to 2 x ``ulp64`` (how far the reference's own float64
+    gradient moves under one float32 rounding of the parameters) where that exceeded 1e-4; the widening was never used (measured worst
+    7e-5) and is gone.  ``ulp64`` is still printed next to the error: it says how much of the margin is the input's own rounding.
+    Returns (worst error, #winner flips, #sign flips, [(error, ulp64, parameter)] sorted worst first)."""
     from util import build_model, load_case
     fix, ref64, inp64 = check_machinery_against_reference_fp64(name)
     cfg, batch, sd, out, _grad, _sd3 = load_case(name, DEV)
@@ -420,6 +435,6 @@ def compare_with_reference_fp64(name, tol_grad=1e-4):
     if os.environ.get('CGC_PARITY_REPORT'):
         for e, k in report:
             print('  %-40s %.2e' % (k, e))
-    bad = [(k, e, fix['ulp'].get(k, 0.0)) for e, k in report if not e < max(tol_grad, 2.0 * fix['ulp'].get(k, 0.0))]
+    bad = [(k, e, fix['ulp'].get(k, 0.0)) for e, k in report if not e < tol_grad]
     assert not bad, (name, bad)
-    return report[0][0], winner_flips, relu_flips
+    return report[0][0], winner_flips, relu_flips, [(e, fix['ulp'].get(k, 0.0), k) for e, k in report]

@@ -58,6 +58,23 @@ def tiny_batch(seed, feat):
     return Batch.from_data_list(graphs)
 
 
+def tiny_dense_tuple(seed, feat, pad_to):
+    """The same kind of graphs handed over in the reference's SECOND input form (model/network.py:253-256; the visualisation branch
+    of evaluate(), train.py:38-49): (x [B, N, F], adj [B, N, N] 0/1, num_nodes [B], label [B]) with N padded beyond the largest graph,
+    as the dense-dict datasets pad to a fixed size (dataflow/data.py:234,268)."""
+    b = tiny_batch(seed, feat)
+    counts = np.bincount(b.batch.numpy()).tolist()
+    B = len(counts)
+    x = torch.zeros(B, pad_to, feat)
+    adj = torch.zeros(B, pad_to, pad_to)
+    off = np.concatenate([[0], np.cumsum(counts)])
+    for g in range(B):
+        x[g, :counts[g]] = b.x[off[g]:off[g + 1]]
+    gi = b.batch[b.edge_index[0]]
+    adj[gi, b.edge_index[0] - torch.from_numpy(off)[gi], b.edge_index[1] - torch.from_numpy(off)[gi]] = 1.0
+    return (x, adj, torch.tensor(counts), b.y.view(-1))
+
+
 CASES = {
     # name: (batch builder, ctor kwargs)
     'tiny_plain': (lambda: tiny_batch(1, 4),
@@ -68,6 +85,16 @@ CASES = {
     'tiny_elu': (lambda: tiny_batch(3, 4),
                           dict(max_num_nodes=64, input_dim=4, hidden_dim=8, embedding_dim=8, assign_ratio=0.25,
                                activation='elu', norm_adj=True)),
+    # round 5: the branches the five cases above do not reach -- gcn_name != 'SAGE' (model/network.py:96-99), leaky ReLU (:90-91),
+    # the dense tuple input form (:253-256)
+    'tiny_gin': (lambda: tiny_batch(4, 4),
+                 dict(max_num_nodes=64, input_dim=4, hidden_dim=8, embedding_dim=8, assign_ratio=0.25, gcn_name='GIN')),
+    'tiny_leaky': (lambda: tiny_batch(5, 4),
+                   dict(max_num_nodes=64, input_dim=4, hidden_dim=8, embedding_dim=8, assign_ratio=0.25,
+                        activation='leakyrelu', norm_adj=True, jk=True)),
+    'tiny_tuple': (lambda: tiny_dense_tuple(6, 4, 16),
+                   dict(max_num_nodes=64, input_dim=4, hidden_dim=8, embedding_dim=8, assign_ratio=0.25,
+                        norm_adj=True, jk=True, load_data_sparse=False)),
     'medium_plain': (lambda: Batch.from_data_list([SyntheticCellGraphs(4, 300, 16, base_seed=11)[i] for i in range(4)]),
                      dict(max_num_nodes=600, input_dim=16, hidden_dim=20, embedding_dim=20, assign_ratio=0.1)),
     'medium_shipped': (lambda: Batch.from_data_list([SyntheticCellGraphs(4, 300, 16, base_seed=23)[i] for i in range(4)]),
@@ -79,14 +106,24 @@ CASES = {
 def build(cls, kw):
     # positional layout of train.py:254-261: (maxn, in, hidden, out, bias, bn, assign_hidden, classes, ratio, [50])
     return cls(kw['max_num_nodes'], kw['input_dim'], kw['hidden_dim'], kw['embedding_dim'],
-               True, True, kw['hidden_dim'], 3, kw['assign_ratio'], [50], concat=True, gcn_name='SAGE',
-               collect_assign=True, load_data_sparse=True, norm_adj=kw.get('norm_adj', False),
+               True, True, kw['hidden_dim'], 3, kw['assign_ratio'], [50], concat=True, gcn_name=kw.get('gcn_name', 'SAGE'),
+               collect_assign=True, load_data_sparse=kw.get('load_data_sparse', True), norm_adj=kw.get('norm_adj', False),
                activation=kw.get('activation', 'relu'), drop_out=0., jk=kw.get('jk', False))
 
 
-def run(model, batch, steps=3):
+def run(model, batch_in, steps=3):
     """train-mode fwd/bwd, then ``steps`` Adam steps, then an eval forward."""
     out = {}
+    if isinstance(batch_in, tuple):        # (_re_norm_adj writes the diagonal of its input in place, model/network.py:186: fresh copies)
+        class _Fresh(object):
+            def __iter__(self):
+                return iter(tuple(t.clone() for t in batch_in))
+
+            def __getitem__(self, i):
+                return batch_in[i].clone()
+        batch = _Fresh()
+    else:
+        batch = batch_in
     model.train()
     model.zero_grad()
     logits, loss = model(batch)
@@ -136,15 +173,20 @@ def main():
             tol = 1e-4 if (k.startswith('sd3/') or k == 'out/eval_logits3') else 2e-6
             worst[k.split('/')[0]] = max(worst.get(k.split('/')[0], 0.0), err)
             assert err <= tol, 'oracle != reference on %s/%s: %g' % (name, k, err)
-        fix = {'cfg': np.array(json.dumps(kw)),
-               'in/x': batch.x.numpy(), 'in/edge_index': batch.edge_index.numpy(),
-               'in/batch': batch.batch.numpy(), 'in/y': batch.y.numpy()}
+        if isinstance(batch, tuple):
+            fix = {'cfg': np.array(json.dumps(kw)), 'in/x_dense': batch[0].numpy(), 'in/adj_dense': batch[1].numpy(),
+                   'in/counts': batch[2].numpy(), 'in/y': batch[3].numpy()}
+        else:
+            fix = {'cfg': np.array(json.dumps(kw)),
+                   'in/x': batch.x.numpy(), 'in/edge_index': batch.edge_index.numpy(),
+                   'in/batch': batch.batch.numpy(), 'in/y': batch.y.numpy()}
         fix.update({'sd/' + k: v.numpy() for k, v in sd0.items()})
         fix.update(got_ref)
         path = os.path.join(HERE, name + '.npz')
         np.savez_compressed(path, **fix)
         print('%-20s nodes=%d edges=%d params=%d  loss=%.6f  -> %s (%.1f KB)' % (
-            name, batch.x.shape[0], batch.edge_index.shape[1],
+            name, int(batch[2].sum()) if isinstance(batch, tuple) else batch.x.shape[0],
+            int(batch[1].sum()) if isinstance(batch, tuple) else batch.edge_index.shape[1],
             sum(p.numel() for p in ref.parameters()), float(got_ref['out/loss']),
             os.path.relpath(path, ROOT), os.path.getsize(path) / 1024))
     print('oracle vs reference, worst scaled abs error per group:', {k: float('%.3g' % v) for k, v in worst.items()})

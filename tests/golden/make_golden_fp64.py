@@ -81,9 +81,13 @@ def main():
         ref.load_state_dict(sd)
         ref = ref.double()
         ref.load_data_sparse = False
-        adj = ref_to_dense_adj(batch.edge_index, batch.batch).double()
-        x, counts = to_dense_batch(batch.x, batch.batch)
-        inp = (x.double(), adj.clone(), counts, batch.y.view(-1))
+        if isinstance(batch, tuple):                       # a case stored in the dense tuple form already (tiny_tuple)
+            x, adj, counts, y = batch[0], batch[1].double(), batch[2], batch[3].view(-1)
+        else:
+            adj = ref_to_dense_adj(batch.edge_index, batch.batch).double()
+            x, counts = to_dense_batch(batch.x, batch.batch)
+            y = batch.y.view(-1)
+        inp = (x.double(), adj.clone(), counts, y)
         logits, loss, pre, embeds = run_reference64(ref, inp)
         assert logits.dtype == torch.float64 and loss.dtype == torch.float64
         fix = {'out64/logits': logits.numpy(), 'out64/loss': loss.numpy(), 'counts': np.asarray([int(c) for c in counts])}
@@ -113,7 +117,7 @@ def main():
             pert.load_data_sparse = False
             pert.train()
             pert.zero_grad()
-            _, lp = pert((x.double(), adj.clone(), counts, batch.y.view(-1)))
+            _, lp = pert((x.double(), adj.clone(), counts, y))
             lp.backward()
             for k, p in pert.named_parameters():
                 m = float(g0[k].abs().max())
@@ -127,7 +131,7 @@ def main():
         ora = ora.double()
         ora.load_data_sparse = False
         ora.train()
-        ol, oloss = ora((x.double(), adj.clone(), counts, batch.y.view(-1)))
+        ol, oloss = ora((x.double(), adj.clone(), counts, y))
         oloss.backward()
         errs = [float((ol - logits).abs().max() / logits.abs().max()), float((oloss - loss).abs() / loss.abs())]
         og = dict(ora.named_parameters())

@@ -601,6 +601,23 @@ def test_fused_wide_sage_forward(n, K_, F, lda, stats, act):
         close(res['hip'][i], res['ref'][i], TOL, 'sage_wide %d' % i)
 
 
+@pytest.mark.parametrize('n,F', [(1000, 200), (4100, 1140), (97, 1140), (65, 33)])
+def test_fused_wide_sage_forward_writes_nothing_past_its_rows(n, F):
+    """The partial last row tile of cgc_sage_wide_fwd (n % 32 != 0): the rows of the tile that lie past n must not be stored -- hn
+    sits inside a larger canary-filled allocation here (in the step: the next arena region)."""
+    k = hip()
+    K_ = 20
+    agg, W, bias = rnd(n, K_, seed=n).to(DEV), rnd(K_, F, seed=1).to(DEV), rnd(F, seed=2).to(DEV)
+    big = torch.full((n + 40, F), 7.0, device=DEV)
+    hn, rinv = big[:n], torch.empty(n, device=DEV)
+    mean, istd = torch.zeros(F, device=DEV), torch.zeros(F, device=DEV)
+    rm, rv, nbt = torch.zeros(F, device=DEV), torch.ones(F, device=DEV), torch.zeros((), dtype=torch.int64, device=DEV)
+    assert k.sage_wide_fwd(agg, K_, W, bias, n, K_, F, True, 1, hn, rinv, True, float(n), 1e-5, 0.1, rm, rv, nbt, mean, istd)
+    torch.cuda.synchronize()
+    assert float(big[n:].min()) == 7.0 and float(big[n:].max()) == 7.0
+    assert float((big[:n].norm(dim=1) - 1.0).abs().max()) < 1e-5          # the rows themselves were written (unit norm)
+
+
 @pytest.mark.parametrize('n,fin,F', [(1, 20, 20), (37, 16, 20), (1000, 20, 20), (4100, 20, 18), (333, 8, 32), (64, 32, 8), (50, 20, 33)])
 @pytest.mark.parametrize('mode,act,normalize', [(2, 1, True), (1, 3, True), (0, 2, False), (2, 2, True)])
 def test_fused_narrow_sage_backward(n, fin, F, mode, act, normalize):

@@ -21,8 +21,25 @@ def strict(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
 
+def _reference_fp32_distance(name):
+    """{parameter: max-norm relative distance between the reference's OWN fp32 gradient (tests/golden/<name>.npz) and its fp64
+    gradient (<name>_fp64.npz)} -- both fixtures were produced by the imported reference."""
+    import discrete
+    fix = discrete.load_reference_fp64(name)
+    _, _, _, _, grad, _ = load_case(name)
+    out = {}
+    for k, g in grad.items():
+        m = float(fix['grad'][k].abs().max())
+        out[k] = float((g.double() - fix['grad'][k]).abs().max()) / m if m > 1e-12 else 0.0
+    return out
+
+
 @pytest.mark.parametrize('name', CASES)
 def test_golden_forward_backward(name):
+    """Forward (logits, loss, assignment matrices: 1e-4, max-norm AND element-wise) against the reference's fp32 fixture.  Its fp32
+    GRADIENTS are a secondary check only: the contract for gradients is the next test (1e-4 against the reference in float64).  A
+    second fp32 evaluation cannot be held closer to the reference's fp32 numbers than those are to the truth, so the bar per parameter
+    is max(1e-4, 2.5 x the reference's own fp32-to-fp64 distance on that parameter) -- data from the two fixtures, no constant."""
     cfg, batch, sd, out, grad, sd3 = load_case(name, DEV)
     model = build_model(network.SoftPoolingGcnEncoder, cfg, collect_assign=True)
     model.load_state_dict(sd)
@@ -31,19 +48,19 @@ def test_golden_forward_backward(name):
     assert kernels.is_native()
     assert rel_err(logits, out['logits']) < TOL and elementwise_excess(logits, out['logits'], TOL) <= 1.0
     assert rel_err(loss, out['loss']) < TOL
+    assert len(model.assign_matrix) == 2
     for i, s in enumerate(model.assign_matrix):
         ref_s = out['assign%d' % (i + 1)]
+        assert tuple(s.shape) == tuple(ref_s.shape)
         assert rel_err(s, ref_s) < TOL and elementwise_excess(s, ref_s, TOL) <= 1.0, i         # measured excess <= 0.25
     loss.backward()
+    own = _reference_fp32_distance(name)
     for k, p in model.named_parameters():
         if k.endswith('att.bias') or float(grad[k].abs().max()) < 1e-9:   # mathematically zero (attention bias under the softmax): absolute
             assert float(p.grad.abs().max()) < 1e-6, k
             continue
-        # against the REFERENCE's own fp32 gradients, no absolute slack.  Measured worst per case: 9e-6 / 5.7e-4 / 1.7e-5 / 2.9e-4 /
-        # 3.7e-4 (tiny_plain / tiny_shipped / tiny_elu / medium_plain / medium_shipped): where it is above 1e-4 one column of one
-        # weight gradient carries it -- a ReLU whose sign the reference's fp32 evaluation and this one take differently (the
-        # fixture is fp32).  The fp64 yardstick with the decisions aligned is tests/discrete.py (1e-4 on every parameter).
-        assert strict(p.grad, grad[k]) < 7e-4, (k, strict(p.grad, grad[k]))
+        bar = max(1e-4, 2.5 * own[k])
+        assert strict(p.grad, grad[k]) < bar, (k, strict(p.grad, grad[k]), bar)
 
 
 @pytest.mark.parametrize('name', CASES)
@@ -57,7 +74,7 @@ def test_golden_gradients_within_1e4_of_the_reference_in_fp64(name):
     discrete.compare_with_reference_fp64(name)
 
 
-@pytest.mark.parametrize('name', ['tiny_shipped', 'medium_plain', 'medium_shipped'])
+@pytest.mark.parametrize('name', ['tiny_shipped', 'tiny_gin', 'tiny_leaky', 'tiny_tuple', 'medium_plain', 'medium_shipped'])
 def test_golden_three_adam_steps(name):
     cfg, batch, sd, out, grad, sd3 = load_case(name, DEV)
     model = build_model(network.SoftPoolingGcnEncoder, cfg)
@@ -102,6 +119,9 @@ def test_synthetic_cell_graphs_vs_oracle(flags):
     rloss.backward()
     assert rel_err(logits, rl) < TOL and rel_err(loss, rloss) < TOL
     gref = dict(ref.named_parameters())
+    # Gradients here are a sanity check against the fp32 oracle (5e-4 incl. absolute slack): the CONTRACT is 1e-4 against float64 --
+    # test_synthetic_cell_graphs_gradients_within_1e4_of_fp64 below for the SAGE variants, the reference-generated tiny_gin fixture
+    # (test_golden_gradients_within_1e4_of_the_reference_in_fp64) for GIN.
     if flags.get('gcn_name') == 'GIN':
         # GIN has no L2 normalisation and sums (not averages) neighbours: the network is ill-conditioned in fp32 -- the reference's
         # own fp32 gradients sit 6.3e-4 away from an fp64 evaluation on exactly this input.  The yardstick is therefore the fp64
@@ -126,7 +146,8 @@ def test_synthetic_cell_graphs_vs_oracle(flags):
             assert rel_err(a, rbuf[k]) < TOL, k                       # BatchNorm running statistics (count = B*Nmax)
 
 
-@pytest.mark.parametrize('flags', [dict(), dict(norm_adj=True, jk=True)], ids=['plain', 'shipped'])
+@pytest.mark.parametrize('flags', [dict(), dict(norm_adj=True, jk=True), dict(activation='leakyrelu', norm_adj=True)],
+                         ids=['plain', 'shipped', 'leaky'])
 def test_synthetic_cell_graphs_gradients_within_1e4_of_fp64(flags):
     """The same graphs with the gradient bar at the north-star 1e-4: against the fp64 evaluation of the oracle, undecidable
     ReLU signs / max-readout winners taken as the HIP path took them (tests/discrete.py)."""

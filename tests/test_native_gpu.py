@@ -607,6 +607,57 @@ def test_fused_head_ignores_labels_like_cross_entropy():
             assert rel(q.grad, gr[k].grad) < 5e-6, (k, rel(q.grad, gr[k].grad))
 
 
+@pytest.mark.parametrize('frozen', ['GCN_embed_2', 'GCN_pool_1', 'GCN_pool_1.bn2'])
+def test_a_frozen_block_during_training_takes_the_per_operator_path(frozen):
+    """Fine-tuning with one block (or one BatchNorm) in eval() while the encoder trains: the sequencer takes ONE train / eval decision
+    per level, so such a level must run on the per-operator path -- running statistics for the frozen module, batch statistics for the
+    others, its buffers untouched -- and backward must work (it used to fail with CGC_EINVAL or silently use batch statistics)."""
+    ds = SyntheticCellGraphs(4, 200, num_features=16, base_seed=29)
+    b = Batch.from_data_list([ds[i] for i in range(4)]).to(DEV)
+    kw = dict(concat=True, load_data_sparse=True, norm_adj=True, jk=True, drop_out=0.)
+    nat, ref = _pair((600, 16, 20, 20, True, True, 20, 3, 0.1, [50]), kw)
+    for m in (nat, ref):
+        m(b)                                            # one training step's worth of running statistics
+        mod = m
+        for part in frozen.split('.'):
+            mod = getattr(mod, part)
+        mod.eval()
+    level = int(frozen.split('.')[0][-1])
+    before = {k: v.clone() for k, v in nat.state_dict().items() if frozen in k and 'running' in k}
+    (ln, lossn), calls = _used_native(nat, b)
+    assert calls == 2                                   # the two other levels stay on the sequencer, level %d does not % level
+    lr, lossr = ref(b)
+    lossn.backward()
+    lossr.backward()
+    rel = lambda x, y: float((x.double() - y.double()).abs().max() / (y.double().abs().max() + 1e-30))
+    assert rel(ln, lr) < 1e-5 and rel(lossn, lossr) < 1e-5
+    for k, v in nat.state_dict().items():
+        if k in before:
+            assert torch.equal(v, before[k]), k          # the frozen module's running statistics did not move
+    gr = dict(ref.named_parameters())
+    for k, q in nat.named_parameters():
+        if not k.endswith('att.bias'):
+            assert rel(q.grad, gr[k].grad) < 2e-3, (k, rel(q.grad, gr[k].grad))
+
+
+def test_fused_head_poisons_the_step_on_a_corrupt_label():
+    """torch's F.cross_entropy (model/network.py:289) raises a device-side assertion for a label outside [0, L) that is not the
+    ignore value -100.  A kernel cannot raise: the fused head makes the loss and every gradient NaN instead of silently dropping the
+    sample from the mean (and never uses the label as an index)."""
+    B = 4
+    ds = SyntheticCellGraphs(B, 80, num_features=16, base_seed=43)
+    b = Batch.from_data_list([ds[i] for i in range(B)]).to(DEV)
+    kw = dict(concat=True, load_data_sparse=True, norm_adj=True, jk=True, drop_out=0.)
+    for bad in (3, -1, 7):
+        nat, _ = _pair((160, 16, 20, 20, True, True, 20, 3, 0.1, [50]), kw, head=True)
+        b.y = b.y.clone()
+        b.y.view(-1)[2] = bad
+        logits, loss = nat(b)
+        assert torch.isfinite(logits).all() and torch.isnan(loss), (bad, loss)
+        loss.backward()
+        assert torch.isnan(nat.pred_model[0].weight.grad).all()
+
+
 @pytest.mark.parametrize('flags', [dict(norm_adj=True, jk=True), dict(), dict(norm_adj=True, activation='leakyrelu')], ids=['shipped', 'plain', 'leaky'])
 def test_fused_adjacency_backward_equals_the_unfused_schedule(flags):
     """The opt-in schedule of levels 2-3 (adj_backward_fused: the chain through _re_norm_adj and the clamped row normalisation as ONE
