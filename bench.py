@@ -74,6 +74,10 @@ def parse():
     p.add_argument('--cpu-warmup', type=int, default=3, help='CPU baseline: untimed warm-up steps')
     p.add_argument('--cpu-steps', type=int, default=5, help='CPU baseline: timed steps')
     p.add_argument('--no-kernel-timing', action='store_true', help='do not record per-launch HIP events')
+    p.add_argument('--no-split-leg', action='store_true',
+                   help='N=1: skip the second leg that runs the same W + K steps with the six dominant products in mode CGC_GEMM_SPLIT_BF16 '
+                        '(reported beside the headline as value_split / roofline_split; the headline is always the exact fp32 kernel)')
+    p.add_argument('--gemm-mode', type=int, default=0, help='experiments: mode of the HEADLINE leg (0 exact, 1 split); the JSON says so')
     p.add_argument('--plain-adam', action='store_true', help='torch.optim.Adam without fused=True (one kernel per parameter group)')
     return p.parse_args()
 
@@ -121,6 +125,48 @@ def usable_cores():
         except (OSError, ValueError, IndexError):
             continue
     return n
+
+
+def bind_rank(rank, local, world, dev_index):
+    """N > 1: one intra-op thread per rank and a core slice of its own -- eight ranks inheriting torch's default intra-op pool would put
+    8 x (all cores) threads on the box, and the step is issued by ONE host thread per rank (train.py:276-287 runs one Python thread per
+    replica).  The slice comes from the cores this process may use; cores local to the GPU's NUMA node (sysfs local_cpulist of its PCI
+    function) are preferred, and ranks whose candidate sets coincide share them out in rank order.  Returns a description for the JSON
+    line.  Best effort: any failure leaves the affinity alone and says so."""
+    torch.set_num_threads(1)
+    info = {'threads': 1}
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        return dict(info, cores='affinity not supported')
+    cand, numa = allowed, None
+    try:
+        pr = torch.cuda.get_device_properties(dev_index)
+        bdf = '%04x:%02x:%02x.0' % (getattr(pr, 'pci_domain_id', 0), pr.pci_bus_id, pr.pci_device_id)
+        base = '/sys/bus/pci/devices/' + bdf
+        numa = int(open(base + '/numa_node').read())
+        loc = set()
+        for part in open(base + '/local_cpulist').read().strip().split(','):
+            if part:
+                lo, _, hi = part.partition('-')
+                loc.update(range(int(lo), int(hi or lo) + 1))
+        if loc & set(allowed):
+            cand = sorted(loc & set(allowed))
+    except (OSError, ValueError, AttributeError, RuntimeError):
+        pass
+    sets = [None] * world
+    dist.all_gather_object(sets, (tuple(cand), local))
+    peers = sorted(l for c, l in sets if c == tuple(cand))           # the ranks that would pick from the same cores
+    per = max(1, len(cand) // len(peers))
+    me = peers.index(local)
+    mine = cand[me * per:(me + 1) * per] or cand[-1:]
+    try:
+        os.sched_setaffinity(0, mine)
+        info['cores'] = '%d-%d' % (mine[0], mine[-1]) if len(mine) > 1 else str(mine[0])
+    except OSError as e:
+        info['cores'] = 'unchanged (%s)' % e
+    info['numa_node'] = numa
+    return info
 
 
 def cpu_model():
@@ -191,6 +237,7 @@ def main():
             dist.init_process_group('nccl', device_id=dev)
         else:
             dist.init_process_group(args.backend)
+    binding = bind_rank(rank, local, world, dev.index) if world > 1 else None
 
     import cgc_net_amd  # noqa: F401
     from cgc_net_amd import kernels, network
@@ -200,7 +247,7 @@ def main():
     # ---- synthetic workload: `pool` distinct batches, resident in HBM.  weak: per rank, seeded by rank; strong: the SAME
     # global batches on every rank, each rank keeping its chunk of the cumulative-node-count split (data.partition_by_nodes)
     from cgc_net_amd.data import partition_by_nodes
-    legs = ['single'] if world == 1 else (['strong', 'weak'] if args.scaling == 'both' else [args.scaling])
+    legs = (['single'] + ([] if args.no_split_leg else ['split'])) if world == 1 else (['strong', 'weak'] if args.scaling == 'both' else [args.scaling])
 
     def make_batches(leg):
         strong_ = leg == 'strong'
@@ -242,6 +289,7 @@ def main():
     def run_leg(leg, with_kernel_timing):
         """W untimed + exactly K timed steps, bracketed by barrier + synchronize; returns the leg's measurements."""
         lists_, cpu_, dev_ = make_batches(leg)
+        model.gemm_mode = 1 if leg == 'split' else args.gemm_mode      # (cgc_gemm_f32_ws's mode; the headline leg is exact unless asked otherwise)
         for i in range(args.warmup):
             step(dev_[i % len(dev_)])
         kernels.get()
@@ -274,12 +322,17 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t[0])
             res.update(own_max=float(t[1]), own_min=-float(t[2]), allreduce_ms=float(t[3]), allreduce_calls=len(ar))
+            info = [None] * world         # what each rank worked on and where it ran: the node-count split, its cores, its NUMA node
+            dist.all_gather_object(info, dict(rank=rank, gpu=local, graphs=[len(l) for l in lists_],
+                                              nodes=[int(b.x.shape[0]) for b in cpu_], **(binding or {})))
+            res['rank_info'] = info
         res['elapsed'] = el
         if not torch.isfinite(loss_).item():
             raise SystemExit('non-finite loss')
         return res
 
-    results = [run_leg(leg, (not args.no_kernel_timing) and i == 0) for i, leg in enumerate(legs)]
+    results = [run_leg(leg, (not args.no_kernel_timing) and (i == 0 or leg == 'split')) for i, leg in enumerate(legs)]
+    model.gemm_mode = args.gemm_mode
     head = results[0]
     strong = head['leg'] == 'strong'
     elapsed, lists, cpu_batches, timer = head['elapsed'], head['lists'], head['cpu_batches'], head['timer']
@@ -308,6 +361,11 @@ def main():
                                    "count (the reference's DataParallel scatter, train.py:276-287)" % (args.batch, world)) if strong else \
                                   'value = WEAK scaling: %d graphs per GPU per step' % args.batch
             out['rccl_ranks'] = dist.get_world_size()
+            try:
+                out['rccl_version'] = '.'.join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:                                  # (gloo-only builds)
+                out['rccl_version'] = None
+            out['ranks'] = head['rank_info']
             out['backend'] = dist.get_backend() + (' (= RCCL over xGMI on ROCm)' if dist.get_backend() == 'nccl' else '')
             out['allreduce_ms'] = round(head['allreduce_ms'], 4)
             out['allreduce'] = {'per_step': head['allreduce_calls'] / max(args.steps, 1), 'bytes': 4 * (getattr(dp, '_seq_total', None) or sum(p.numel() for p in model.parameters())),
@@ -321,10 +379,12 @@ def main():
                 out[k + '_ms_per_step'] = round(1e3 * r['elapsed'] / args.steps, 3)
                 out[k + '_allreduce_ms'] = round(r['allreduce_ms'], 4)
                 out[k + '_global_batch'] = args.batch * (1 if k == 'strong' else world)
-        if timer is not None:
-            recs = timer.records()
+        shipped = args.flags == 'shipped'
+
+        def rooflines(timer_):
+            """(dominant GEMM, wide SpMM) roofline objects from a leg's per-launch HIP events."""
+            recs = timer_.records()
             per_step = len(recs) // args.steps if args.steps and len(recs) % max(args.steps, 1) == 0 else 0
-            shipped = args.flags == 'shipped'
             g_ms = g_fl = s_ms = s_by = 0.0
             g_n = s_n = 0
             for i, (tag, dims, ms) in enumerate(recs):
@@ -344,24 +404,48 @@ def main():
                     s_ms += ms
                     s_by += 8.0 * n_ * width + 4.0 * (n_ + 1) + (8.0 if dims[3] else 4.0) * nnz
                     s_n += 1
+            gemm = spmm = None
             if g_n:
                 tf = g_fl / (g_ms * 1e-3) / 1e12
-                out['roofline'] = {'kernel': 'k_gemm_f32<2,2,2,2,*> (fp32 MFMA 32x32x2, 128x128x32 tile; all launches of its NN/NT/TN instantiations, '
-                                             'tail fix-up kernel included)', 'bound': 'mfma',
-                                   'achieved': round(tf, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                                   'frac': round(tf / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': None,
-                                   'launches_per_step': g_n / args.steps, 'avg_launch_ms': round(g_ms / g_n, 4),
-                                   'gflop_per_launch': round(g_fl / g_n / 1e9, 3),
-                                   'ms_per_step': round(g_ms / args.steps, 3)}
+                gemm = {'bound': 'mfma', 'achieved': round(tf, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                        'frac': round(tf / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': None,
+                        'launches_per_step': g_n / args.steps, 'avg_launch_ms': round(g_ms / g_n, 4),
+                        'gflop_per_launch': round(g_fl / g_n / 1e9, 3), 'ms_per_step': round(g_ms / args.steps, 3)}
             if s_n:
                 gbs = s_by / (s_ms * 1e-3) / 1e9
-                out['roofline_aggregation'] = {'kernel': 'k_spmm_wide<9,*> (A*S and its transpose, width %d)' % c1, 'bound': 'hbm',
-                                               'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                                               'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': None,
-                                               'launches_per_step': s_n / args.steps,
-                                               'avg_launch_ms': round(s_ms / s_n, 4),
-                                               'mb_per_launch': round(s_by / s_n / 1e6, 2)}
-            timer.close()
+                spmm = {'kernel': 'k_spmm_wide<9,*> (A*S and its transpose, width %d)' % c1, 'bound': 'hbm',
+                        'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': None,
+                        'launches_per_step': s_n / args.steps, 'avg_launch_ms': round(s_ms / s_n, 4), 'mb_per_launch': round(s_by / s_n / 1e6, 2)}
+            timer_.close()
+            return gemm, spmm
+        EXACT_KERNEL = ('k_gemm_f32<2,2,2,2,*> (fp32 MFMA 32x32x2, 128x128x32 tile; all launches of its NN/NT/TN instantiations, '
+                        'tail fix-up kernel included)')
+        SPLIT_KERNEL = ('k_gemm_split<*> (the same six products per step as six v_mfma_f32_32x32x16_bf16 pairs per fp32 product, 256x128x16 tile; '
+                        'tail fix-up kernel included)')
+        if timer is not None:
+            gemm, spmm = rooflines(timer)
+            if gemm is not None:
+                out['roofline'] = dict({'kernel': SPLIT_KERNEL if args.gemm_mode == 1 else EXACT_KERNEL}, **gemm)
+            if spmm is not None:
+                out['roofline_aggregation'] = spmm
+        if args.gemm_mode == 1:
+            out['config']['gemm_mode'] = 'CGC_GEMM_SPLIT_BF16 (experiment: the headline leg itself ran in split mode)'
+        for r in results[1:]:
+            if r['leg'] != 'split':
+                continue
+            # the same W + K steps with the six dominant products in mode CGC_GEMM_SPLIT_BF16: reported BESIDE the headline
+            out['value_split'] = round(args.batch * args.steps / r['elapsed'], 2)
+            out['ms_per_step_split'] = round(1e3 * r['elapsed'] / args.steps, 3)
+            if r['timer'] is not None:
+                gemm, _ = rooflines(r['timer'])
+                if gemm is not None:
+                    tf = gemm['achieved']
+                    out['roofline_split'] = dict({'kernel': SPLIT_KERNEL}, **gemm)
+                    out['roofline_split'].update({
+                        'achieved_is': 'fp32-equivalent TFLOP/s: 2MNK of the fp32 product / launch duration (the kernel issues 6 x that on the bf16 pipe)',
+                        'frac_is': 'achieved / the fp32 MFMA peak (157.3): a speed-up figure, not a utilisation -- see bf16_pipe_frac',
+                        'bf16_pipe_frac': round(6.0 * tf / 2500.0, 4), 'bf16_pipe_peak': 2500.0,
+                        'error_table': 'profiles/r05_split_gemm_error_table.txt (max / rms error vs float64 next to the exact kernel, every form)'})
         # HBM traffic per launch and counter-derived matrix-core utilisation: from the committed PMC passes of this same command
         # (profiles/make_traffic_json.py, profiles/make_counters_json.py) -- ONLY when they were taken on exactly this kernel source
         # (sha256 over csrc/ + include/, stamped into the json); otherwise null + "stale"

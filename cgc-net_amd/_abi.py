@@ -3,7 +3,7 @@ import ctypes as C
 
 P, I, F, D, L = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_int64
 
-ABI_VERSION = 2      # = CGC_ABI_VERSION of include/cgc_hip.h these prototypes were written against (tests compare the two)
+ABI_VERSION = 3      # = CGC_ABI_VERSION of include/cgc_hip.h these prototypes were written against (tests compare the two)
 
 PROTOTYPES = {
     'cgc_abi_version': [],
@@ -25,8 +25,9 @@ PROTOTYPES = {
     'cgc_gemm_f32': [I, I, I, I, I, F, P, I, P, I, F, P, I, P, I, L, L, L, P, I, I, P],
     'cgc_gemm_f32_cat': [I, I, I, I, I, F, P, I, P, I, F, P, I, P, I, L, L, L, P, I, I, I, P, P, P, P, P, P, P, P],
     'cgc_gemm_ws_floats': [],
-    'cgc_gemm_f32_ws': [I, I, I, I, I, F, P, I, P, I, F, P, I, P, I, L, L, L, P, I, I, P, L, P],
-    'cgc_gemm_f32_cat_ws': [I, I, I, I, I, F, P, I, P, I, F, P, I, P, I, L, L, L, P, I, I, I, P, P, P, P, P, P, P, P, L, P],
+    'cgc_gemm_split_count': [],
+    'cgc_gemm_f32_ws': [I, I, I, I, I, F, P, I, P, I, F, P, I, P, I, L, L, L, P, I, I, P, L, I, P],
+    'cgc_gemm_f32_cat_ws': [I, I, I, I, I, F, P, I, P, I, F, P, I, P, I, L, L, L, P, I, I, I, P, P, P, P, P, P, P, P, L, I, P],
     'cgc_gemm_tuning': [I],
     'cgc_reduce_batch_sum': [P, P, I, L, F, P],
     'cgc_reduce_batched': [P, P, I, I, I, F, P],
@@ -103,4 +104,4 @@ def declare(lib):
         if name == 'cgc_timing_create':
             fn.restype = P          # a handle, not a status
             continue
-        fn.restype = C.c_int64 if name.endswith(('_ws_ints', '_ws_floats', '_offset', '_grad_floats', '_saved_floats', '_scratch_floats')) else C.c_int
+        fn.restype = C.c_int64 if name.endswith(('_ws_ints', '_ws_floats', '_offset', '_grad_floats', '_saved_floats', '_scratch_floats', '_split_count')) else C.c_int

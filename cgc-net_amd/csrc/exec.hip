@@ -108,6 +108,7 @@ struct Ctx {
   Arena* scratch;
   float* gws;                     // slab workspace of the GEMM's tail split
   int64_t gws_floats;
+  int gemm_mode = CGC_GEMM_EXACT; // cgc_level_desc.flags bit 1: CGC_GEMM_SPLIT_BF16 for the products that qualify (gemm_split.hip)
 };
 
 static int fail_at(int rc, const char* what, int line) {      // CGC_EXEC_DEBUG=1: say which call of the schedule failed
@@ -138,7 +139,7 @@ int gemm(const Ctx& c, int tA, int tB, int M, int N, int K, const float* A, int 
          int ragged = 0, int max_ragged = 0) {
   if (c.dry) return 0;
   return cgc_gemm_f32_ws(tA, tB, M, N, K, 1.f, A, lda, B, ldb, beta, C, ldc, bias, batch, sA, sB, sC, gptr, ragged, max_ragged, c.gws,
-                         c.gws_floats, c.s);
+                         c.gws_floats, c.gemm_mode, c.s);
 }
 
 int gemm_x1(const Ctx& c, int tA, int tB, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float beta, float* C, int ldc,
@@ -150,7 +151,7 @@ int gemm_x1(const Ctx& c, int tA, int tB, int M, int N, int K, const float* A, i
   const int la[1] = {xlda}, lb[1] = {xldb}, kk[1] = {xK};
   const int64_t s1[1] = {xsA}, s2[1] = {xsB};
   return cgc_gemm_f32_cat_ws(tA, tB, M, N, K, 1.f, A, lda, B, ldb, beta, C, ldc, bias, batch, sA, sB, sC, gptr, ragged, max_ragged, 1, pa, la,
-                             s1, pb, lb, s2, kk, c.gws, c.gws_floats, c.s);
+                             s1, pb, lb, s2, kk, c.gws, c.gws_floats, c.gemm_mode, c.s);
 }
 
 // how many row slices the tall-skinny "weight gradient" contraction out[Fa,Fb] = A[n,Fa]^T B[n,Fb] is cut into (ops._split_parts):
@@ -659,7 +660,7 @@ int level_bwd_blocks(const Ctx& c, Level& L, const cgc_block_params* emb, const 
       } else {
         // the whole chain through both row normalisations as ONE product of thin operands (rowops.hip: k_adj_grad_operands): here
         // `gAt` is d P [n, ldP] (level_bwd kept it instead of forming d P S^T), nullptr at a level without DiffPool
-        const int Kc = L.wt + (gAt != nullptr ? L.C : 0) + 1, ldK = up(Kc, 4);
+        const int Kc = L.wt + (gAt != nullptr ? L.C : 0) + 2, ldK = up(Kc, 4);
         float* Lc = sc.f((size_t)n * ldK);
         float* Rc = sc.f((size_t)n * ldK);
         const float* ag[3] = {L.aggk[1], L.aggk[0], L.agg0};
@@ -825,6 +826,7 @@ extern "C" int cgc_level_fwd(const cgc_level_desc* d, const cgc_block_params* em
   L.layout_grads();
   Ctx c{stream, false, &sc, nullptr, cgc_gemm_ws_floats()};
   c.gws = sc.f((size_t)c.gws_floats);
+  c.gemm_mode = (d->flags & 2) ? CGC_GEMM_SPLIT_BF16 : CGC_GEMM_EXACT;
   const int rc = level_fwd(c, L, emb, pool, jk, g, gptr, x_in, A_in, readout, x_out, A_out);
   if (assign_out != nullptr) *assign_out = L.S;
   if (assign_ld != nullptr) *assign_ld = L.ldC;
@@ -843,5 +845,6 @@ extern "C" int cgc_level_bwd(const cgc_level_desc* d, const cgc_block_params* em
   L.layout_grads();
   Ctx c{stream, false, &sc, nullptr, cgc_gemm_ws_floats()};
   c.gws = sc.f((size_t)c.gws_floats);
+  c.gemm_mode = (d->flags & 2) ? CGC_GEMM_SPLIT_BF16 : CGC_GEMM_EXACT;
   return level_bwd(c, L, emb, pool, jk, g, gptr, x_in, A_in, d_readout, d_x_out, d_A_out, grads, d_x_in, d_A_in);
 }

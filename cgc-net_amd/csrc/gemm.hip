@@ -704,7 +704,10 @@ extern "C" int cgc_gemm_tuning(int cfg) {
   return old;
 }
 
-static int gemm_dispatch(GemmArgs& a, int transA, int transB, int batch, int max_ragged, float* ws, int64_t ws_floats,
+int gemm_split_launch(const GemmArgs& a0, int transA, int transB, int batch, int m_extent, int k_extent, float* ws, int64_t ws_floats,
+                      hipStream_t stream);      // gemm_split.hip
+
+static int gemm_dispatch(GemmArgs& a, int transA, int transB, int batch, int max_ragged, float* ws, int64_t ws_floats, int mode,
                          hipStream_t stream) {
   const int M = a.M, N = a.N, K = a.K, ragged = a.ragged;
   if (batch <= 0 || N <= 0) return 0;
@@ -728,13 +731,24 @@ static int gemm_dispatch(GemmArgs& a, int transA, int transB, int batch, int max
   static const int fill_min = getenv("CGC_GEMM_FILL") ? atoi(getenv("CGC_GEMM_FILL")) : 448;
   const bool sk = k_extent <= shortk_max && a.nx == 0;
   const long long fill = (long long)ceil_div(m_extent, 128) * batch;
+  // the 128 x 128 pipelined route; mode CGC_GEMM_SPLIT_BF16: as six bf16 MFMA pairs on 256 x 128 tiles (gemm_split.hip) when every
+  // operand segment is fit for unguarded 16-byte loads; otherwise -- and for every other route -- the exact kernel
+  static const int force_mode = getenv("CGC_GEMM_MODE") ? atoi(getenv("CGC_GEMM_MODE")) : -1;      // experiments: overrides the argument
+  const bool want_split = (force_mode >= 0 ? force_mode : mode) == CGC_GEMM_SPLIT_BF16;
+  auto big_route = [&](bool shortk, float* w) -> int {
+    if (want_split && !shortk && !(transA && transB) && gemm_all_fast(a, transA, transB, batch, m_extent, k_extent)) {
+      const int rc = gemm_split_launch(a, transA, transB, batch, m_extent, k_extent, w, ws_floats, stream);
+      if (rc != CGC_EINVAL) return rc;
+    }
+    return launch_cfg<2, 2, 2, 2>(a, transA, transB, batch, m_extent, k_extent, shortk, w, ws_floats, stream);
+  };
   // experiment hook: CGC_GEMM_CFG = 1..6 forces a tile shape (128x128, 128x64, 64x128, 64x64, 128x32, 32x128), +10 forces the
   // pipelined kernel, +20 the short-K kernel
   const int force = g_force_cfg;
   if (force > 0) {
     const bool fsk = force >= 20 ? true : force >= 10 ? false : sk;
     switch (force % 10) {
-      case 1: return launch_cfg<2, 2, 2, 2>(a, transA, transB, batch, m_extent, k_extent, fsk, ws, ws_floats, stream);
+      case 1: return big_route(fsk, ws);
       case 2: return launch_cfg<4, 1, 1, 2>(a, transA, transB, batch, m_extent, k_extent, fsk, ws_any, ws_floats, stream);
       case 3: return launch_cfg<1, 4, 2, 1>(a, transA, transB, batch, m_extent, k_extent, fsk, ws_any, ws_floats, stream);
       case 4: return launch_cfg<2, 2, 1, 1>(a, transA, transB, batch, m_extent, k_extent, fsk, ws_any, ws_floats, stream);
@@ -760,13 +774,12 @@ static int gemm_dispatch(GemmArgs& a, int transA, int transB, int batch, int max
       // long reductions (S^T P of a 4-graph shard: 324 tiles of 57 k-tiles): whole 128 x 128 tiles, cut in two along K, beat
       // twice as many 128 x 64 tiles (235 -> 208 us).  (More pieces per tile -- 3 = 1.9 rounds of a third -- were measured
       // too: 204 us, and a cost model that picked the piece count by rounds x length made the small tails slower.)
-      if (!sk && ws != nullptr && k_extent >= 24 * BK)
-        return launch_cfg<2, 2, 2, 2>(a, transA, transB, batch, m_extent, k_extent, sk, ws, ws_floats, stream);
+      if (!sk && ws != nullptr && k_extent >= 24 * BK) return big_route(sk, ws);
       return launch_cfg<4, 1, 1, 2>(a, transA, transB, batch, m_extent, k_extent, sk, ws_any, ws_floats, stream);
     }
     return launch_cfg<1, 4, 2, 1>(a, transA, transB, batch, m_extent, k_extent, sk, ws_any, ws_floats, stream);
   }
-  return launch_cfg<2, 2, 2, 2>(a, transA, transB, batch, m_extent, k_extent, sk, ws, ws_floats, stream);                        // 128 x 128
+  return big_route(sk, ws);                        // 128 x 128
 }
 
 static void gemm_fill(GemmArgs& a, int M, int N, int K, float alpha, const float* A, int lda, const float* B, int ldb, float beta,
@@ -783,27 +796,29 @@ static void gemm_fill(GemmArgs& a, int M, int N, int K, float alpha, const float
 
 extern "C" int cgc_gemm_f32_ws(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda, const float* B,
                                int ldb, float beta, float* C, int ldc, const float* bias, int batch, int64_t strideA, int64_t strideB,
-                               int64_t strideC, const int* gptr, int ragged, int max_ragged, float* ws, int64_t ws_floats,
+                               int64_t strideC, const int* gptr, int ragged, int max_ragged, float* ws, int64_t ws_floats, int mode,
                                cgc_stream_t stream_) {
+  if (mode != CGC_GEMM_EXACT && mode != CGC_GEMM_SPLIT_BF16) return CGC_EINVAL;
   GemmArgs a;
   gemm_fill(a, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, strideA, strideB, strideC, gptr, ragged);
-  return gemm_dispatch(a, transA, transB, batch, max_ragged, ws, ws_floats, as_stream(stream_));
+  return gemm_dispatch(a, transA, transB, batch, max_ragged, ws, ws_floats, mode, as_stream(stream_));
 }
 
 extern "C" int cgc_gemm_f32(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda, const float* B, int ldb,
                             float beta, float* C, int ldc, const float* bias, int batch, int64_t strideA, int64_t strideB,
                             int64_t strideC, const int* gptr, int ragged, int max_ragged, cgc_stream_t stream_) {
   return cgc_gemm_f32_ws(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, batch, strideA, strideB, strideC, gptr,
-                         ragged, max_ragged, nullptr, 0, stream_);
+                         ragged, max_ragged, nullptr, 0, CGC_GEMM_EXACT, stream_);
 }
 
 extern "C" int cgc_gemm_f32_cat_ws(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda, const float* B,
                                    int ldb, float beta, float* C, int ldc, const float* bias, int batch, int64_t strideA,
                                    int64_t strideB, int64_t strideC, const int* gptr, int ragged, int max_ragged, int nx,
                                    const float* const* xA, const int* xlda, const int64_t* xstrideA, const float* const* xB,
-                                   const int* xldb, const int64_t* xstrideB, const int* xK, float* ws, int64_t ws_floats,
+                                   const int* xldb, const int64_t* xstrideB, const int* xK, float* ws, int64_t ws_floats, int mode,
                                    cgc_stream_t stream_) {
   if (nx < 0 || nx > 2) return CGC_EINVAL;
+  if (mode != CGC_GEMM_EXACT && mode != CGC_GEMM_SPLIT_BF16) return CGC_EINVAL;
   GemmArgs a;
   gemm_fill(a, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, strideA, strideB, strideC, gptr, ragged);
   int kept = 0;
@@ -814,7 +829,7 @@ extern "C" int cgc_gemm_f32_cat_ws(int transA, int transB, int M, int N, int K, 
     ++kept;
   }
   a.nx = kept;
-  return gemm_dispatch(a, transA, transB, batch, max_ragged, ws, ws_floats, as_stream(stream_));
+  return gemm_dispatch(a, transA, transB, batch, max_ragged, ws, ws_floats, mode, as_stream(stream_));
 }
 
 extern "C" int cgc_gemm_f32_cat(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda, const float* B,
@@ -823,7 +838,7 @@ extern "C" int cgc_gemm_f32_cat(int transA, int transB, int M, int N, int K, flo
                                 const float* const* xA, const int* xlda, const int64_t* xstrideA, const float* const* xB,
                                 const int* xldb, const int64_t* xstrideB, const int* xK, cgc_stream_t stream_) {
   return cgc_gemm_f32_cat_ws(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, batch, strideA, strideB, strideC,
-                             gptr, ragged, max_ragged, nx, xA, xlda, xstrideA, xB, xldb, xstrideB, xK, nullptr, 0, stream_);
+                             gptr, ragged, max_ragged, nx, xA, xlda, xstrideA, xB, xldb, xstrideB, xK, nullptr, 0, CGC_GEMM_EXACT, stream_);
 }
 
 // ---- deterministic split-K combine

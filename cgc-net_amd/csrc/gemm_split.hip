@@ -49,40 +49,42 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {      // v_cvt_
   t[1] = b;
   return __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2));
 }
-template <int E>
-__device__ __forceinline__ float comp(const float4& v) { return E == 0 ? v.x : E == 1 ? v.y : E == 2 ? v.z : v.w; }
+__device__ __forceinline__ float comp(const float4& v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
+
+// Everything below is written so that, once the per-tile loops are fully unrolled, every array index is a constant (the register
+// arrays then live in registers) and no closure survives: free functions with explicit arguments, no lambda inside a lambda (a
+// by-reference lambda nested in another kept its closure -- a struct of pointers to locals -- in scratch memory: gemm.hip).
 
 // Operand whose K index is the contiguous one in memory (A stored [M, K]; B stored [N, K]).  ROWS x 16 tile = ROWS * 4 units of
-// 16 bytes; thread t: unit q = t & 3 of rows (t >> 2) + 64 i.  A unit is one "group": four consecutive k of one row.
+// 16 bytes; thread t: unit q = t & 3 of rows row_of(i), i = 0 .. ROWS / 64 - 1.  A unit is one "group": four consecutive k of one row.
 template <int ROWS>
 struct SplitLoaderK {
   static constexpr int NF = ROWS / 64, NG = NF;
-  float4 reg[NF];
-  __device__ __forceinline__ void offsets(unsigned (&off)[NF], int ld, int row0, int row_last) const {
+  // row of unit i: 64 i + 16 wave + ((t >> 4) & 3) + 4 ((t >> 2) & 3) -- the 16 lanes of an LDS write group (8-byte writes) hold rows
+  // b, b + 4, b + 8, b + 12: on the 40-byte row stride their 32-byte windows start 160 = 32 (mod 128) bytes apart and tile the
+  // 128-byte bank window exactly (rows b .. b + 3 overlap: 25 % of the LDS cycles of the first version were bank conflicts)
+  static __device__ __forceinline__ int row_of(int i) {
+    const int t = (int)threadIdx.x;
+    return 64 * i + 16 * (t >> 6) + ((t >> 4) & 3) + 4 * ((t >> 2) & 3);
+  }
+  static __device__ __forceinline__ void offsets(unsigned (&off)[NF], int ld, int row0, int row_last) {
 #pragma unroll
-    for (int i = 0; i < NF; ++i)
-      off[i] = (unsigned)min(row0 + (int)(threadIdx.x >> 2) + 64 * i, row_last) * (unsigned)ld * 4u + (threadIdx.x & 3u) * 16u;
+    for (int i = 0; i < NF; ++i) off[i] = (unsigned)min(row0 + row_of(i), row_last) * (unsigned)ld * 4u + (threadIdx.x & 3u) * 16u;
   }
   static __device__ __forceinline__ unsigned soffset(int /*ld*/, int k0) { return (unsigned)k0 * 4u; }
-  __device__ __forceinline__ void load_buf(int i, __amdgpu_buffer_rsrc_t rsrc, const unsigned (&off)[NF], unsigned soff) {
-    reg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[i], soff, 0));
-  }
   // any tile of any segment: units past the end of K re-read the last valid 16 bytes of their row (the split zeroes them)
-  __device__ __forceinline__ void load_any(int i, const float* __restrict__ base, int ld, int row0, int row_last, int k0, int klim) {
-    const int row = min(row0 + (int)(threadIdx.x >> 2) + 64 * i, row_last);
+  static __device__ __forceinline__ float4 load_any(int i, const float* __restrict__ base, int ld, int row0, int row_last, int k0, int klim) {
+    const int row = min(row0 + row_of(i), row_last);
     const int k = min(k0 + (int)(threadIdx.x & 3) * 4, (klim - 1) & ~3);
-    reg[i] = *reinterpret_cast<const float4*>(base + (size_t)row * ld + k);
+    return *reinterpret_cast<const float4*>(base + (size_t)row * ld + k);
   }
-  template <int U>
-  __device__ __forceinline__ void get(float (&x)[4]) const {
-    x[0] = reg[U].x; x[1] = reg[U].y; x[2] = reg[U].z; x[3] = reg[U].w;
+  static __device__ __forceinline__ void get(const float4 (&reg)[NF], int u, float (&x)[4]) {
+    x[0] = reg[u].x; x[1] = reg[u].y; x[2] = reg[u].z; x[3] = reg[u].w;
   }
-  template <int U>
-  __device__ __forceinline__ int kof(int e) const { return (int)(threadIdx.x & 3) * 4 + e; }      // k of element e inside the tile
-  __device__ __forceinline__ unsigned wbase() const { return (threadIdx.x >> 2) * SROW + (threadIdx.x & 3u) * 8u; }
-  template <int U, int PLANE>
-  __device__ __forceinline__ void put(unsigned char* st, int p, unsigned w0, unsigned w1) const {   // st = stage base + region + wbase()
-    *reinterpret_cast<uint2*>(st + U * 64 * SROW + p * PLANE) = make_uint2(w0, w1);
+  static __device__ __forceinline__ int kof(int /*u*/, int e) { return (int)(threadIdx.x & 3) * 4 + e; }      // k of element e inside the tile
+  static __device__ __forceinline__ unsigned wbase() { return (unsigned)row_of(0) * SROW + (threadIdx.x & 3u) * 8u; }
+  static __device__ __forceinline__ void put(unsigned char* st, int u, int plane_off, unsigned w0, unsigned w1) {   // st = stage + region + wbase()
+    *reinterpret_cast<uint2*>(st + u * 64 * SROW + plane_off) = make_uint2(w0, w1);
   }
 };
 
@@ -90,45 +92,38 @@ struct SplitLoaderK {
 // (KH = 4 for the 256-wide operand, 2 for the 128-wide one): lane -> (kgrp = t % (16 / KH), g = t / (16 / KH)); float4 j of the block is
 // row k = KH * kgrp + j, columns 4 g .. 4 g + 3.  The 16 lanes of an LDS write group then cover 4 column groups x 4 k groups (KH = 4:
 // 8-byte writes) or the 32 lanes 4 x 8 (KH = 2: 4-byte writes): distinct banks.  Groups: KH = 4: column c of the block (its four k);
-// KH = 2: columns 2u, 2u + 1 (two k each).
+// KH = 2: columns 2u, 2u + 1 (two k each).  The transposition is a choice of register names.
 template <int COLS>
 struct SplitLoaderMN {
   static constexpr int KH = COLS / 64, NF = KH, NG = KH == 4 ? 4 : 2, KG = 16 / KH;
-  float4 reg[NF];
-  __device__ __forceinline__ int kgrp() const { return (int)threadIdx.x % KG; }
-  __device__ __forceinline__ int g() const { return (int)threadIdx.x / KG; }
-  __device__ __forceinline__ void offsets(unsigned (&off)[NF], int ld, int col0, int col_last4) const {
+  static __device__ __forceinline__ int kgrp() { return (int)threadIdx.x % KG; }
+  static __device__ __forceinline__ int g() { return (int)threadIdx.x / KG; }
+  static __device__ __forceinline__ void offsets(unsigned (&off)[NF], int ld, int col0, int col_last4) {
 #pragma unroll
     for (int j = 0; j < NF; ++j)
       off[j] = (unsigned)(KH * kgrp() + j) * (unsigned)ld * 4u + (unsigned)min(col0 + 4 * g(), col_last4) * 4u;
   }
   static __device__ __forceinline__ unsigned soffset(int ld, int k0) { return (unsigned)k0 * (unsigned)ld * 4u; }
-  __device__ __forceinline__ void load_buf(int j, __amdgpu_buffer_rsrc_t rsrc, const unsigned (&off)[NF], unsigned soff) {
-    reg[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[j], soff, 0));
-  }
   // rows (k) past the end re-read row klim - 1 (the split zeroes them)
-  __device__ __forceinline__ void load_any(int j, const float* __restrict__ base, int ld, int col0, int col_last4, int k0, int klim) {
+  static __device__ __forceinline__ float4 load_any(int j, const float* __restrict__ base, int ld, int col0, int col_last4, int k0, int klim) {
     const int k = min(k0 + KH * kgrp() + j, klim - 1);
-    reg[j] = *reinterpret_cast<const float4*>(base + (size_t)k * ld + min(col0 + 4 * g(), col_last4));
+    return *reinterpret_cast<const float4*>(base + (size_t)k * ld + min(col0 + 4 * g(), col_last4));
   }
-  template <int U>
-  __device__ __forceinline__ void get(float (&x)[4]) const {
+  static __device__ __forceinline__ void get(const float4 (&reg)[NF], int u, float (&x)[4]) {
     if constexpr (KH == 4) {
-      x[0] = comp<U>(reg[0]); x[1] = comp<U>(reg[1]); x[2] = comp<U>(reg[2]); x[3] = comp<U>(reg[3]);
+      x[0] = comp(reg[0], u); x[1] = comp(reg[1], u); x[2] = comp(reg[2], u); x[3] = comp(reg[3], u);
     } else {
-      x[0] = comp<2 * U>(reg[0]); x[1] = comp<2 * U>(reg[1]); x[2] = comp<2 * U + 1>(reg[0]); x[3] = comp<2 * U + 1>(reg[1]);
+      x[0] = comp(reg[0], 2 * u); x[1] = comp(reg[1], 2 * u); x[2] = comp(reg[0], 2 * u + 1); x[3] = comp(reg[1], 2 * u + 1);
     }
   }
-  template <int U>
-  __device__ __forceinline__ int kof(int e) const { return KH == 4 ? 4 * kgrp() + e : 2 * kgrp() + (e & 1); }
-  __device__ __forceinline__ unsigned wbase() const { return (unsigned)g() * 4u * SROW + (unsigned)kgrp() * (KH == 4 ? 8u : 4u); }
-  template <int U, int PLANE>
-  __device__ __forceinline__ void put(unsigned char* st, int p, unsigned w0, unsigned w1) const {
+  static __device__ __forceinline__ int kof(int /*u*/, int e) { return KH == 4 ? 4 * kgrp() + e : 2 * kgrp() + (e & 1); }
+  static __device__ __forceinline__ unsigned wbase() { return (unsigned)g() * 4u * SROW + (unsigned)kgrp() * (KH == 4 ? 8u : 4u); }
+  static __device__ __forceinline__ void put(unsigned char* st, int u, int plane_off, unsigned w0, unsigned w1) {
     if constexpr (KH == 4) {
-      *reinterpret_cast<uint2*>(st + U * SROW + p * PLANE) = make_uint2(w0, w1);
+      *reinterpret_cast<uint2*>(st + u * SROW + plane_off) = make_uint2(w0, w1);
     } else {
-      *reinterpret_cast<unsigned*>(st + (2 * U) * SROW + p * PLANE) = w0;
-      *reinterpret_cast<unsigned*>(st + (2 * U + 1) * SROW + p * PLANE) = w1;
+      *reinterpret_cast<unsigned*>(st + (2 * u) * SROW + plane_off) = w0;
+      *reinterpret_cast<unsigned*>(st + (2 * u + 1) * SROW + plane_off) = w1;
     }
   }
 };
@@ -144,7 +139,7 @@ struct SplitTile {
   const float* B;
   int lda, ldb, klim, k0;
 };
-__device__ __forceinline__ SplitTile split_tile(const SplitSegs& t, int kt) {
+__device__ __forceinline__ SplitTile split_tile(const SplitSegs t, int kt) {
   const int kx = kt - t.nk_main;
   const bool in_main = kx < 0, in_x0 = kx < t.nkx0;
   SplitTile r;
@@ -157,8 +152,73 @@ __device__ __forceinline__ SplitTile split_tile(const SplitSegs& t, int kt) {
   return r;
 }
 
+// ---- the split of one group of four values in eight micro-steps (sidx = 8 * group + step; groups 0-3: operand A, 4-5: operand B)
+struct GroupState {
+  float x[4], r1[4], r2[4];
+  unsigned hp[2], mp[2], lp[2];
+};
+template <class LoaderA, class LoaderB, bool MASKED>
+__device__ __forceinline__ void split_micro(int sidx, GroupState (&gs)[6], const float4 (&ra)[LoaderA::NF], const float4 (&rb)[LoaderB::NF],
+                                            unsigned char* wa, unsigned char* wb, int k0, int klim) {
+  const int u = sidx >> 3, st = sidx & 7;
+  GroupState& s = gs[u];
+  if (st == 0) {
+    if (u < 4) LoaderA::get(ra, u, s.x); else LoaderB::get(rb, u - 4, s.x);
+    if (MASKED) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int ke = k0 + (u < 4 ? LoaderA::kof(u, e) : LoaderB::kof(u - 4, e));
+        s.x[e] = ke < klim ? s.x[e] : 0.f;
+      }
+    }
+    s.hp[0] = pack_bf16(s.x[0], s.x[1]);
+    s.hp[1] = pack_bf16(s.x[2], s.x[3]);
+  } else if (st == 1 || st == 2) {
+    const int h = st - 1;
+    const float e0 = __builtin_bit_cast(float, s.hp[h] << 16), e1 = __builtin_bit_cast(float, s.hp[h] & 0xffff0000u);
+    s.r1[2 * h] = s.x[2 * h] - e0;
+    s.r1[2 * h + 1] = s.x[2 * h + 1] - e1;
+    asm volatile("" : "+v"(s.r1[2 * h]), "+v"(s.r1[2 * h + 1]));
+  } else if (st == 3) {
+    s.mp[0] = pack_bf16(s.r1[0], s.r1[1]);
+    s.mp[1] = pack_bf16(s.r1[2], s.r1[3]);
+  } else if (st == 4 || st == 5) {
+    const int h = st - 4;
+    const float e0 = __builtin_bit_cast(float, s.mp[h] << 16), e1 = __builtin_bit_cast(float, s.mp[h] & 0xffff0000u);
+    s.r2[2 * h] = s.r1[2 * h] - e0;
+    s.r2[2 * h + 1] = s.r1[2 * h + 1] - e1;
+    asm volatile("" : "+v"(s.r2[2 * h]), "+v"(s.r2[2 * h + 1]));
+  } else if (st == 6) {
+    s.lp[0] = pack_bf16(s.r2[0], s.r2[1]);
+    s.lp[1] = pack_bf16(s.r2[2], s.r2[3]);
+  } else {
+    if (u < 4) {
+      LoaderA::put(wa, u, 0, s.hp[0], s.hp[1]);
+      LoaderA::put(wa, u, S_PLA, s.mp[0], s.mp[1]);
+      LoaderA::put(wa, u, 2 * S_PLA, s.lp[0], s.lp[1]);
+    } else {
+      LoaderB::put(wb, u - 4, 0, s.hp[0], s.hp[1]);
+      LoaderB::put(wb, u - 4, S_PLB, s.mp[0], s.mp[1]);
+      LoaderB::put(wb, u - 4, 2 * S_PLB, s.lp[0], s.lp[1]);
+    }
+  }
+}
+
+// One half (8 bytes = four k) of an operand fragment.  fa / fb: the lane's row of the stage's A / B region (+ 16 bytes for lanes 32-63).
+__device__ __forceinline__ void frag_half(uint4v& f, int h, const unsigned char* p) {
+  const uint2 v = *reinterpret_cast<const uint2*>(p + h * 8);
+  f[2 * h] = v.x;
+  f[2 * h + 1] = v.y;
+}
+
+// Fragment registers of a wave: one set (the k-tile being multiplied) + a second copy of B's hi plane only.  The pair order of a tile
+// -- lh, mm, mh, hl, hm, hh -- retires the planes one after the other, and the NEXT tile's copy of a plane is read (from the next
+// stage) as soon as this tile's is dead: A.lo after pair 0, A.mid after pair 2, B.lo after pair 3, B.mid after pair 4; A.hi and B.hi
+// live to the end -- the next tile's A.hi is read during ITS pairs 0-2 (which do not use it), the next tile's B.hi into the second copy.
+// 80 registers instead of the 144 of a full double buffer: with the three register sets of raw operands in flight (72) the kernel
+// otherwise does not fit the 256 architectural registers that everything but the accumulators has to share.
 struct SplitFrags {
-  uint4v a[4][3], b[2][3];                 // [sub-tile][plane]: 8 bf16 = the lane's 8 k of its row
+  uint4v a[4][3], b[2][3], b0n[2];
 };
 
 template <bool TA, bool TB>
@@ -191,8 +251,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_split(const GemmArgs a) {
   typedef typename std::conditional<TB, SplitLoaderK<S_BN>, SplitLoaderMN<S_BN>>::type LoaderB;
   static_assert(LoaderA::NG == 4 && LoaderB::NG == 2, "six groups of four values per thread and k-tile");
   constexpr int NFA = LoaderA::NF, NFB = LoaderB::NF;
-  LoaderA la[3];                             // three register sets: tile t lives in set t % 3 from its request until its split
-  LoaderB lb[3];
+  float4 ra[3][NFA], rb[3][NFB];            // three register sets: tile t lives in set t % 3 from its request until its split
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave / WGN, wn = wave - wm * WGN;
@@ -235,148 +294,61 @@ __global__ __launch_bounds__(256, 1) void k_gemm_split(const GemmArgs a) {
   const int a_last = TA ? ((M - 1) & ~3) : M - 1, b_last = TB ? N - 1 : ((N - 1) & ~3);
 
   unsigned offA[NFA], offB[NFB];
-  la[0].offsets(offA, a.lda, m0, a_last);
-  lb[0].offsets(offB, a.ldb, n0, b_last);
+  LoaderA::offsets(offA, a.lda, m0, a_last);
+  LoaderB::offsets(offB, a.ldb, n0, b_last);
   const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, 0xffffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(B), 0, 0xffffffff, 0x00020000);
 
-  // LDS addresses: per stage, the lane's fragment rows (read) and the thread's units (write)
+  // LDS addresses: the lane's fragment rows (read) and the thread's units (write), relative to a stage
   const unsigned fa_off = (unsigned)(wm * 128 + l31) * SROW + lhi * 16, fb_off = 3 * S_PLA + (unsigned)(wn * 64 + l31) * SROW + lhi * 16;
-  const unsigned wa_off = la[0].wbase(), wb_off = 3 * S_PLA + lb[0].wbase();
+  const unsigned wa_off = LoaderA::wbase(), wb_off = 3 * S_PLA + LoaderB::wbase();
 
-  // request local tile `lt` (clamped into the piece: a tile past the end is never used, its addresses must be valid)
-  auto request_any = [&](LoaderA& ra, LoaderB& rb, int lt) {
+  SplitFrags fr;
+  // ---- prologue: tiles 0, 1 split into stages 0, 1; tiles 2, 3, 4 in flight in the three sets; the fragments of tile 0 except A.hi
+#pragma unroll
+  for (int q = 0; q < 5; ++q) {               // q: 0, 1, 2 request tiles 0, 1, 2; then split 0, request 3; split 1, request 4
+    const int lt = q, set = q % 3;
+    if (q >= 3) {
+      const SplitTile t = split_tile(seg, kbeg + (q - 3 < n ? q - 3 : n - 1));
+      GroupState gs[6];
+#pragma unroll
+      for (int sidx = 0; sidx < 48; ++sidx)
+        split_micro<LoaderA, LoaderB, true>(sidx, gs, ra[set], rb[set], slds + (q - 3) * S_STAGE + wa_off, slds + (q - 3) * S_STAGE + wb_off, t.k0,
+                                            t.klim);
+    }
     const SplitTile t = split_tile(seg, kbeg + (lt < n ? lt : n - 1));
 #pragma unroll
-    for (int i = 0; i < NFA; ++i) ra.load_any(i, t.A, t.lda, m0, a_last, t.k0, t.klim);
+    for (int i = 0; i < NFA; ++i) ra[set][i] = LoaderA::load_any(i, t.A, t.lda, m0, a_last, t.k0, t.klim);
 #pragma unroll
-    for (int i = 0; i < NFB; ++i) rb.load_any(i, t.B, t.ldb, n0, b_last, t.k0, t.klim);
-  };
-
-  // ---- the split of one group of four values: eight micro-steps (see the file header)
-  struct GroupState {
-    float x[4], r1[4], r2[4];
-    unsigned hp[2], mp[2], lp[2];
-  };
-  auto split_step = [&](auto u_c, auto st_c, auto masked_c, GroupState& gs, LoaderA& ra, LoaderB& rb, unsigned char* stage_base, int k0,
-                        int klim) {
-    constexpr int U = decltype(u_c)::value, ST = decltype(st_c)::value;
-    constexpr bool MASKED = decltype(masked_c)::value;
-    constexpr bool IS_A = U < 4;
-    constexpr int UL = IS_A ? U : U - 4;
-    if constexpr (ST == 0) {
-      if constexpr (IS_A) ra.template get<UL>(gs.x); else rb.template get<UL>(gs.x);
-      if constexpr (MASKED) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int ke = k0 + (IS_A ? ra.template kof<UL>(e) : rb.template kof<UL>(e));
-          gs.x[e] = ke < klim ? gs.x[e] : 0.f;
-        }
-      }
-      gs.hp[0] = pack_bf16(gs.x[0], gs.x[1]);
-      gs.hp[1] = pack_bf16(gs.x[2], gs.x[3]);
-    } else if constexpr (ST == 1 || ST == 2) {
-      constexpr int h = ST - 1;
-      const float e0 = __builtin_bit_cast(float, gs.hp[h] << 16), e1 = __builtin_bit_cast(float, gs.hp[h] & 0xffff0000u);
-      gs.r1[2 * h] = gs.x[2 * h] - e0;
-      gs.r1[2 * h + 1] = gs.x[2 * h + 1] - e1;
-      asm volatile("" : "+v"(gs.r1[2 * h]), "+v"(gs.r1[2 * h + 1]));
-    } else if constexpr (ST == 3) {
-      gs.mp[0] = pack_bf16(gs.r1[0], gs.r1[1]);
-      gs.mp[1] = pack_bf16(gs.r1[2], gs.r1[3]);
-    } else if constexpr (ST == 4 || ST == 5) {
-      constexpr int h = ST - 4;
-      const float e0 = __builtin_bit_cast(float, gs.mp[h] << 16), e1 = __builtin_bit_cast(float, gs.mp[h] & 0xffff0000u);
-      gs.r2[2 * h] = gs.r1[2 * h] - e0;
-      gs.r2[2 * h + 1] = gs.r1[2 * h + 1] - e1;
-      asm volatile("" : "+v"(gs.r2[2 * h]), "+v"(gs.r2[2 * h + 1]));
-    } else if constexpr (ST == 6) {
-      gs.lp[0] = pack_bf16(gs.r2[0], gs.r2[1]);
-      gs.lp[1] = pack_bf16(gs.r2[2], gs.r2[3]);
-    } else {
-      if constexpr (IS_A) {
-        unsigned char* st = stage_base + wa_off;
-        ra.template put<UL, S_PLA>(st, 0, gs.hp[0], gs.hp[1]);
-        ra.template put<UL, S_PLA>(st, 1, gs.mp[0], gs.mp[1]);
-        ra.template put<UL, S_PLA>(st, 2, gs.lp[0], gs.lp[1]);
-      } else {
-        unsigned char* st = stage_base + wb_off;
-        rb.template put<UL, S_PLB>(st, 0, gs.hp[0], gs.hp[1]);
-        rb.template put<UL, S_PLB>(st, 1, gs.mp[0], gs.mp[1]);
-        rb.template put<UL, S_PLB>(st, 2, gs.lp[0], gs.lp[1]);
-      }
-    }
-  };
-  // micro-step s (0 .. 47) of a tile's split: group s / 8, step s % 8
-  auto micro = [&](auto s_c, auto masked_c, GroupState (&gs)[6], LoaderA& ra, LoaderB& rb, unsigned char* stage_base, int k0, int klim) {
-    constexpr int SIDX = decltype(s_c)::value;
-    split_step(std::integral_constant<int, SIDX / 8>(), std::integral_constant<int, SIDX % 8>(), masked_c, gs[SIDX / 8], ra, rb, stage_base,
-               k0, klim);
-  };
-  // a whole tile's split in one go (prologue)
-  auto split_all = [&](LoaderA& ra, LoaderB& rb, unsigned char* stage_base, int lt) {
-    const SplitTile t = split_tile(seg, kbeg + (lt < n ? lt : n - 1));
-    GroupState gs[6];
-    auto run = [&](auto self, auto s_c) {
-      constexpr int SIDX = decltype(s_c)::value;
-      if constexpr (SIDX < 48) {
-        micro(s_c, std::true_type(), gs, ra, rb, stage_base, t.k0, t.klim);
-        self(self, std::integral_constant<int, SIDX + 1>());
-      }
-    };
-    run(run, std::integral_constant<int, 0>());
-  };
-  // fragment q (0 .. 35) of a tile: A sub-tile i, plane p, half h (24 of them), then B
-  auto frag_read = [&](auto q_c, SplitFrags& f, const unsigned char* stage_base) {
-    constexpr int Q = decltype(q_c)::value;
-    if constexpr (Q < 24) {
-      constexpr int i = Q / 6, p = (Q % 6) / 2, h = Q % 2;
-      const uint2 v = *reinterpret_cast<const uint2*>(stage_base + fa_off + i * 32 * SROW + p * S_PLA + h * 8);
-      f.a[i][p][2 * h] = v.x;
-      f.a[i][p][2 * h + 1] = v.y;
-    } else {
-      constexpr int R = Q - 24, j = R / 6, p = (R % 6) / 2, h = R % 2;
-      const uint2 v = *reinterpret_cast<const uint2*>(stage_base + fb_off + j * 32 * SROW + p * S_PLB + h * 8);
-      f.b[j][p][2 * h] = v.x;
-      f.b[j][p][2 * h + 1] = v.y;
-    }
-  };
-
-  SplitFrags fr[2];
-  // ---- prologue: tiles 0, 1 split into stages 0, 1; tiles 2, 3, 4 in flight in the three sets; fragments of tile 0 in fr[0]
-  request_any(la[0], lb[0], 0);
-  request_any(la[1], lb[1], 1);
-  request_any(la[2], lb[2], 2);
-  split_all(la[0], lb[0], slds, 0);
-  request_any(la[0], lb[0], 3);
-  split_all(la[1], lb[1], slds + S_STAGE, 1);
-  request_any(la[1], lb[1], 4);
-  __syncthreads();
-  {
-    auto run = [&](auto self, auto q_c) {
-      constexpr int Q = decltype(q_c)::value;
-      if constexpr (Q < 36) {
-        frag_read(q_c, fr[0], slds);
-        self(self, std::integral_constant<int, Q + 1>());
-      }
-    };
-    run(run, std::integral_constant<int, 0>());
+    for (int i = 0; i < NFB; ++i) rb[set][i] = LoaderB::load_any(i, t.B, t.ldb, n0, b_last, t.k0, t.klim);
   }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int p = 1; p < 3; ++p)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) frag_half(fr.a[i][p], h, slds + fa_off + i * 32 * SROW + p * S_PLA);
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) frag_half(fr.b[j][p], h, slds + fb_off + j * 32 * SROW + p * S_PLB);
 
-  // ---- one k-tile.  POS = local tile index mod 6 fixes every buffer: fragments fr[POS & 1] (being multiplied) and fr[~POS & 1] (being
-  // read, tile lt + 1, stage (POS + 1) % 3), the set (POS + 2) % 3 being split into stage (POS + 2) % 3 (tile lt + 2) and refilled
-  // (tile lt + 5).  FULL: tiles lt + 2 and lt + 5 are whole tiles of the main operand pair -- buffer loads, no masks, no conditional.
-  // Otherwise the generic request / masked split.  Past the end of the piece everything still runs, on clamped addresses, into
-  // buffers nobody multiplies: no conditional there either.
-  constexpr int PA_[6] = {0, 0, 1, 0, 1, 2}, PB_[6] = {0, 1, 0, 2, 1, 0};
+  // ---- one k-tile.  POS = local tile index mod 3 fixes the buffers: stage POS holds this tile, stage (POS + 1) % 3 the next one
+  // (being read), set / stage (POS + 2) % 3 the tile after that (being split) and then tile lt + 5 (requested).  FULL: tiles lt + 2 and
+  // lt + 5 are whole tiles of the main operand pair -- buffer loads, no masks, no conditional.  Otherwise the generic request / masked
+  // split.  Past the end of the piece everything still runs, on clamped addresses, into buffers nobody multiplies: no conditional
+  // there either.  48 MFMAs; behind MFMA m: ONE fragment half (m < 36... see the table), micro-step m of the split, at most one load.
   auto tile_step = [&](auto pos_c, auto full_c, int lt) {
     constexpr int POS = decltype(pos_c)::value;
     constexpr bool FULL = decltype(full_c)::value;
-    constexpr int FC = POS & 1, FN = FC ^ 1, SR = (POS + 1) % 3, SW = (POS + 2) % 3;
+    constexpr int SR = (POS + 1) % 3, SW = (POS + 2) % 3;
+    const unsigned char* cstage = slds + POS * S_STAGE;
     const unsigned char* rstage = slds + SR * S_STAGE;
-    unsigned char* wstage = slds + SW * S_STAGE;
-    LoaderA& ra = la[SW];
-    LoaderB& rb = lb[SW];
+    unsigned char* wa = slds + SW * S_STAGE + wa_off;
+    unsigned char* wb = slds + SW * S_STAGE + wb_off;
     GroupState gs[6];
     int k0s = 0, klims = 0;
     SplitTile tnext;
@@ -387,32 +359,68 @@ __global__ __launch_bounds__(256, 1) void k_gemm_split(const GemmArgs a) {
       klims = ts.klim;
       tnext = split_tile(seg, kbeg + (lt + 5 < n ? lt + 5 : n - 1));
     } else {
+      tnext.A = A; tnext.B = B; tnext.lda = a.lda; tnext.ldb = a.ldb; tnext.klim = K; tnext.k0 = 0;
       soffA = LoaderA::soffset(a.lda, (kbeg + lt + 5) * SBK);
       soffB = LoaderB::soffset(a.ldb, (kbeg + lt + 5) * SBK);
     }
-    auto run = [&](auto self, auto m_c) {
-      constexpr int MI = decltype(m_c)::value;
-      if constexpr (MI < 48) {
-        constexpr int t = MI / 8, ij = MI % 8, i = ij >> 1, j = ij & 1;
-        // operands swapped (B fragment first): the accumulator holds the transposed sub-tile, see gemm_epilogue
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fr[FC].b[j][PB_[t]]),
-                                                            __builtin_bit_cast(bf16x8, fr[FC].a[i][PA_[t]]), acc[i][j], 0, 0, 0);
-        if constexpr (MI < 36) frag_read(std::integral_constant<int, MI>(), fr[FN], rstage);
-        micro(std::integral_constant<int, MI>(), std::integral_constant<bool, !FULL>(), gs, ra, rb, wstage, k0s, klims);
-        // the set's registers are free once its groups have been picked up (A: micro-step 24, B: 40): refill
-        if constexpr (MI >= 36 && MI < 36 + NFA) {
-          if constexpr (FULL) ra.load_buf(MI - 36, rsrcA, offA, soffA);
-          else ra.load_any(MI - 36, tnext.A, tnext.lda, m0, a_last, tnext.k0, tnext.klim);
-        }
-        if constexpr (MI >= 44 && MI < 44 + NFB) {
-          if constexpr (FULL) rb.load_buf(MI - 44, rsrcB, offB, soffB);
-          else rb.load_any(MI - 44, tnext.B, tnext.ldb, n0, b_last, tnext.k0, tnext.klim);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        self(self, std::integral_constant<int, MI + 1>());
+    // pair order: (A plane, B plane) = lh, mm, mh, hl, hm, hh
+    constexpr int PA_[6] = {2, 1, 1, 0, 0, 0}, PB_[6] = {0, 1, 0, 2, 1, 0};
+#pragma clang loop unroll(full)
+    for (int m = 0; m < 48; ++m) {
+      const int t = m / 8, ij = m % 8, i = ij >> 1, j = ij & 1;
+      // operands swapped (B fragment first): the accumulator holds the transposed sub-tile, see gemm_epilogue
+#ifndef CGC_XS_NOMFMA          // (CGC_XS_*: timing ablations that break the result -- tools/variant_lib.sh; never defined in the build)
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fr.b[j][PB_[t]]), __builtin_bit_cast(bf16x8, fr.a[i][PA_[t]]),
+                                                          acc[i][j], 0, 0, 0);
+#else
+      acc[i][j][m % 16] += __builtin_bit_cast(float, fr.b[j][PB_[t]][m & 3]) + __builtin_bit_cast(float, fr.a[i][PA_[t]][m & 3]);
+#endif
+#ifndef CGC_XS_NOREAD
+      // fragment halves: 36 reads in the gaps where their registers are free (SplitFrags), each at least 12 MFMAs ahead of its first use
+      if (m < 8) {                                     // this tile's A.hi (first used by pair 3, MFMA 24)
+        frag_half(fr.a[m >> 1][0], m & 1, cstage + fa_off + (m >> 1) * 32 * SROW);
+      } else if (m < 16) {                             // next tile's A.lo (this tile's: pair 0 only)
+        frag_half(fr.a[(m - 8) >> 1][2], m & 1, rstage + fa_off + ((m - 8) >> 1) * 32 * SROW + 2 * S_PLA);
+      } else if (m < 20) {                             // next tile's B.hi, into the second copy
+        frag_half(fr.b0n[(m - 16) >> 1], m & 1, rstage + fb_off + ((m - 16) >> 1) * 32 * SROW);
+      } else if (m >= 24 && m < 32) {                  // next tile's A.mid (this tile's: pairs 1, 2)
+        frag_half(fr.a[(m - 24) >> 1][1], m & 1, rstage + fa_off + ((m - 24) >> 1) * 32 * SROW + S_PLA);
+      } else if (m >= 32 && m < 36) {                  // next tile's B.lo (this tile's: pair 3)
+        frag_half(fr.b[(m - 32) >> 1][2], m & 1, rstage + fb_off + ((m - 32) >> 1) * 32 * SROW + 2 * S_PLB);
+      } else if (m >= 40 && m < 44) {                  // next tile's B.mid (this tile's: pairs 1, 4)
+        frag_half(fr.b[(m - 40) >> 1][1], m & 1, rstage + fb_off + ((m - 40) >> 1) * 32 * SROW + S_PLB);
       }
-    };
-    run(run, std::integral_constant<int, 0>());
+#endif
+#ifdef CGC_XS_NOSPLIT
+      if (!FULL)
+#endif
+#ifdef CGC_XS_NOWRITE
+      if (!FULL || (m & 7) != 7)
+#endif
+      split_micro<LoaderA, LoaderB, !FULL>(m, gs, ra[SW], rb[SW], wa, wb, k0s, klims);
+#ifdef CGC_XS_NOLOAD
+      if (!FULL) {
+#else
+      {
+#endif
+      // the set's registers are free once its groups have been picked up (A: micro-step 24, B: 40): refill
+      if (m >= 28 && m < 28 + NFA) {
+        if constexpr (FULL) ra[SW][m - 28] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrcA, offA[m - 28], soffA, 0));
+        else ra[SW][m - 28] = LoaderA::load_any(m - 28, tnext.A, tnext.lda, m0, a_last, tnext.k0, tnext.klim);
+      }
+      if (m >= 44 && m < 44 + NFB) {
+        if constexpr (FULL) rb[SW][m - 44] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrcB, offB[m - 44], soffB, 0));
+        else rb[SW][m - 44] = LoaderB::load_any(m - 44, tnext.B, tnext.ldb, n0, b_last, tnext.k0, tnext.klim);
+      }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // the next tile's B.hi becomes the current one (register renaming: a move the allocator removes, or two v_mov per sub-tile)
+    fr.b[0][0] = fr.b0n[0];
+    fr.b[1][0] = fr.b0n[1];
+#ifdef CGC_XS_NOBAR
+    if (!FULL)
+#endif
     __syncthreads();
   };
   typedef std::true_type FULL_;
@@ -420,24 +428,17 @@ __global__ __launch_bounds__(256, 1) void k_gemm_split(const GemmArgs a) {
 #define SPLIT_POS(P_) std::integral_constant<int, P_>()
   int lt = 0;
   // steps whose tiles lt + 2 and lt + 5 are whole main-pair tiles
-  const int full_steps = nk_full - 5 - kbeg;
-  for (; lt + 6 <= full_steps; lt += 6) {
+  const int full_steps = min(nk_full - 5 - kbeg, n);            // (never past the end of the piece: the next piece's tiles are not ours)
+  for (; lt + 3 <= full_steps; lt += 3) {
     tile_step(SPLIT_POS(0), FULL_(), lt);
     tile_step(SPLIT_POS(1), FULL_(), lt + 1);
     tile_step(SPLIT_POS(2), FULL_(), lt + 2);
-    tile_step(SPLIT_POS(3), FULL_(), lt + 3);
-    tile_step(SPLIT_POS(4), FULL_(), lt + 4);
-    tile_step(SPLIT_POS(5), FULL_(), lt + 5);
   }
   for (; lt < n; ++lt) {
-    switch (lt % 6) {
-      case 0: tile_step(SPLIT_POS(0), ANY_(), lt); break;
-      case 1: tile_step(SPLIT_POS(1), ANY_(), lt); break;
-      case 2: tile_step(SPLIT_POS(2), ANY_(), lt); break;
-      case 3: tile_step(SPLIT_POS(3), ANY_(), lt); break;
-      case 4: tile_step(SPLIT_POS(4), ANY_(), lt); break;
-      default: tile_step(SPLIT_POS(5), ANY_(), lt); break;
-    }
+    const int pos = lt % 3;
+    if (pos == 0) tile_step(SPLIT_POS(0), ANY_(), lt);
+    else if (pos == 1) tile_step(SPLIT_POS(1), ANY_(), lt);
+    else tile_step(SPLIT_POS(2), ANY_(), lt);
   }
 #undef SPLIT_POS
 
@@ -461,6 +462,10 @@ __global__ __launch_bounds__(256, 1) void k_gemm_split(const GemmArgs a) {
 
 // Workgroups the chip holds at once: one per CU
 static const int kSplitResident = 256;
+
+// how many products this process has sent to the split kernel (tests: "did the mode apply to this product?")
+static int64_t g_split_launches = 0;
+extern "C" int64_t cgc_gemm_split_count(void) { return __atomic_load_n(&g_split_launches, __ATOMIC_RELAXED); }
 
 // Launch the split kernel for a product that qualifies (gemm.hip: gemm_dispatch decided: 128 x 128 route, every operand segment
 // fit for unguarded 16-byte loads).  Returns CGC_EINVAL when the shape is outside what the kernel indexes (the caller then runs the
@@ -511,6 +516,7 @@ int gemm_split_launch(const GemmArgs& a0, int transA, int transB, int batch, int
   else SPLIT_LAUNCH(true, false);
 #undef SPLIT_LAUNCH
   CGC_RETURN_IF_LAUNCH_FAILED();
+  __atomic_fetch_add(&g_split_launches, 1, __ATOMIC_RELAXED);
   if (a.ws != nullptr) {
     const long long lmax = tiles < kSplitResident ? tiles : kSplitResident - 1;
     hipLaunchKernelGGL((k_gemm_fixup<2, 2, 4, 2>), dim3((unsigned)(lmax * 4 * 4 * 2)), dim3(64), 0, stream, a);

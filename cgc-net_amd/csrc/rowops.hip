@@ -1522,7 +1522,7 @@ extern "C" int cgc_adj_prep_bwd(const float* A, const float* An, const float* in
 // sum_k (dP S^T)_ik A~_ik = dP_i . P_i = v_i, and the diagonal entries are dP_i . S_i = e_i and sum_l dC_l,i . B_l,i = f_i:
 //     T_i = v_i + [d_i == rowsum < 1 ? 1 : 0] u_i - p (e_i + f_i / d_i - ge1_i u_i / d_i),     w_i = s_i (ge1_i u_i / d_i + T_i / (1 - p))
 // (without --norm_adj: s_i = 1, w_i = ge1_i u_i / d_i, no diagonal rule).  So the whole gradient is ONE product over the concatenated
-// thin operands  [ s/d dC_2 | s/d dC_1 | s/d dC_0 | s dP | -w ] . [ B_2 | B_1 | B_0 | S | 1 ]^T  written once -- instead of two N x N
+// thin operands  [ s/d dC_2 | s/d dC_1 | s/d dC_0 | s dP | -w_hi | -w_lo ] . [ B_2 | B_1 | B_0 | S | 1 | 1 ]^T  written once -- instead of two N x N
 // products (dP S^T: 125 us, the rank-100 update: 130 us at C3) whose results a third kernel reads back together with A, A^ (163 us,
 // five passes over 166 MB).  This kernel forms the two operands: one wave per row.
 struct AdjGradArgs {
@@ -1540,22 +1540,33 @@ struct AdjGradArgs {
   float p;                // < 0: no re-normalisation
 };
 
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// Round 5: the four row reductions and the row term w run in DOUBLE, and w travels as TWO k columns (w_hi | w_lo, both against 1):
+// w_i is a constant along row i of d A, so whatever error it carries is the same for all N entries of the row and the next contraction
+// (softmax weights, all positive) adds it up N times instead of sqrt(N) -- in float it cost the fused route up to 3x in gradient
+// accuracy against the N x N route, whose row terms are sums over the very entries they centre.  With
+// w good to 2^-48 what is left of the difference is the rounding of the saved fp32 operands themselves.
 __global__ __launch_bounds__(256) void k_adj_grad_operands(const AdjGradArgs a) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= a.n) return;
   const float* __restrict__ g = a.gcat + (size_t)row * a.wt;
   const float* __restrict__ x = a.xcat + (size_t)row * a.wt;
-  float u = 0.f, f = 0.f, v = 0.f, e = 0.f;
+  double u = 0.0, f = 0.0, v = 0.0, e = 0.0;
   for (int c = lane; c < a.wt; c += 64) {
-    const float gv = g[c];
+    const double gv = (double)g[c];
     int k = c, part = 0;
     if (k >= a.aw[0]) { k -= a.aw[0]; part = 1; }
     if (part == 1 && k >= a.aw[1]) { k -= a.aw[1]; part = 2; }
     const float* __restrict__ ag = part == 0 ? a.agg[0] : part == 1 ? a.agg[1] : a.agg[2];
     const int w = part == 0 ? a.aw[0] : part == 1 ? a.aw[1] : a.aw[2];
-    u = fmaf(gv, ag[(size_t)row * w + k], u);
-    f = fmaf(gv, x[c], f);
+    u = fma(gv, (double)ag[(size_t)row * w + k], u);
+    f = fma(gv, (double)x[c], f);
   }
   const bool pool = a.dP != nullptr;
   if (pool) {
@@ -1563,25 +1574,27 @@ __global__ __launch_bounds__(256) void k_adj_grad_operands(const AdjGradArgs a) 
     const float* __restrict__ pp = a.P + (size_t)row * a.ldP;
     const float* __restrict__ ss = a.S + (size_t)row * a.ldS;
     for (int c = lane; c < a.C; c += 64) {
-      const float d = dp[c];
-      v = fmaf(d, pp[c], v);
-      e = fmaf(d, ss[c], e);
+      const double d = (double)dp[c];
+      v = fma(d, (double)pp[c], v);
+      e = fma(d, (double)ss[c], e);
     }
   }
-  u = group_sum(u, 64);
-  f = group_sum(f, 64);
-  v = group_sum(v, 64);
-  e = group_sum(e, 64);
+  u = wave_sum_f64(u);
+  f = wave_sum_f64(f);
+  v = wave_sum_f64(v);
+  e = wave_sum_f64(e);
   const bool renorm = a.p >= 0.f;
   const float inv = a.invd[row], ge = a.ge1[row];
   const float s = renorm ? (1.f - a.p) * a.rq[row] : 1.f;
-  float w;
+  double w;
   if (renorm) {
-    const float T = v + (1.f - ge) * u - a.p * (e + f * inv - ge * u * inv);
-    w = s * (ge * u * inv + T / (1.f - a.p));
+    const double p = (double)a.p;
+    const double T = v + (1.0 - (double)ge) * u - p * (e + f * (double)inv - (double)ge * u * (double)inv);
+    w = (double)s * ((double)ge * u * (double)inv + T / (1.0 - p));
   } else {
-    w = ge * u * inv;
+    w = (double)ge * u * (double)inv;
   }
+  const float w_hi = (float)w, w_lo = (float)(w - (double)w_hi);
   float* __restrict__ L = a.Lc + (size_t)row * a.ldK;
   float* __restrict__ Rr = a.Rc + (size_t)row * a.ldK;
   const float sc = s * inv;
@@ -1599,18 +1612,18 @@ __global__ __launch_bounds__(256) void k_adj_grad_operands(const AdjGradArgs a) 
     }
     o += a.C;
   }
-  for (int c = o + lane; c < a.ldK; c += 64) {       // the row term rides along as one more k: (-w) * 1; padding: zeros
-    L[c] = c == o ? -w : 0.f;
-    Rr[c] = c == o ? 1.f : 0.f;
+  for (int c = o + lane; c < a.ldK; c += 64) {       // the row term rides along as two more k: (-w_hi) * 1 + (-w_lo) * 1; padding: zeros
+    L[c] = c == o ? -w_hi : c == o + 1 ? -w_lo : 0.f;
+    Rr[c] = c <= o + 1 ? 1.f : 0.f;
   }
 }
 
-// K of the product = wt + C + 1; ldK >= K (a multiple of 4 for the unguarded GEMM loaders).  agg[i] has row stride aw[i].
+// K of the product = wt + C + 2; ldK >= K (a multiple of 4 for the unguarded GEMM loaders).  agg[i] has row stride aw[i].
 extern "C" int cgc_adj_grad_operands(const float* gcat, const float* xcat, int wt, const float* const* agg, const int* aw, const float* dP,
                                      const float* P, int ldP, const float* S, int ldS, int C, const float* invd, const float* ge1,
                                      const float* rq, int n, float p, float* Lc, float* Rc, int ldK, cgc_stream_t stream) {
   if (n <= 0) return 0;
-  if (wt <= 0 || aw[0] + aw[1] + aw[2] != wt || ldK < wt + (dP != nullptr ? C : 0) + 1) return CGC_EINVAL;
+  if (wt <= 0 || aw[0] + aw[1] + aw[2] != wt || ldK < wt + (dP != nullptr ? C : 0) + 2) return CGC_EINVAL;
   if (p >= 0.f && rq == nullptr) return CGC_EINVAL;
   AdjGradArgs a;
   a.gcat = gcat; a.xcat = xcat;

@@ -246,6 +246,9 @@ def get():
     return _instance
 
 
+GEMM_EXACT, GEMM_SPLIT_BF16 = 0, 1      # include/cgc_hip.h: CGC_GEMM_EXACT / CGC_GEMM_SPLIT_BF16
+
+
 def is_native():
     return isinstance(_instance, HipKernels)
 
@@ -354,6 +357,10 @@ _NO_WS = _NoWorkspace()
 
 class HipKernels(KernelSpec):
     tail_split = True   # hand cgc_gemm_f32_ws its slab workspace (False: every output tile is computed whole; tests / A-B timing)
+    # cgc_gemm_f32_ws's `mode` for the products issued through this table (the per-operator path): GEMM_EXACT (default) or
+    # GEMM_SPLIT_BF16 -- the big products as six bf16 MFMA pairs per fp32 product (csrc/gemm_split.hip).  The encoder sets it from
+    # its own ``gemm_mode`` at the top of forward(); the sequencer gets the same choice through cgc_level_desc.flags bit 1.
+    gemm_mode = 0
 
     def __init__(self):
         path = lib_path()
@@ -529,12 +536,12 @@ class HipKernels(KernelSpec):
                                               PA(*[e[0].data_ptr() for e in extra]), IA(*[e[2] for e in extra]),
                                               LA(*[e[5] for e in extra]), PA(*[e[1].data_ptr() for e in extra]),
                                               IA(*[e[3] for e in extra]), LA(*[e[6] for e in extra]),
-                                              IA(*[e[4] for e in extra]), ws.data_ptr(), ws.numel(), stream)
+                                              IA(*[e[4] for e in extra]), ws.data_ptr(), ws.numel(), int(self.gemm_mode), stream)
         else:
             rc = self.lib.cgc_gemm_f32_ws(int(transA), int(transB), M, N, K, ctypes.c_float(alpha), _ptr(A), lda,
                                           _ptr(B), ldb, ctypes.c_float(beta), _ptr(C), ldc, _ptr(bias), batch,
                                           ctypes.c_int64(strideA), ctypes.c_int64(strideB), ctypes.c_int64(strideC),
-                                          _ptr(gptr), ragged, max_ragged, ws.data_ptr(), ws.numel(), stream)
+                                          _ptr(gptr), ragged, max_ragged, ws.data_ptr(), ws.numel(), int(self.gemm_mode), stream)
         self._chk(rc, 'cgc_gemm_f32')
 
     def reduce_batch_sum(self, ws, out, parts, numel, beta=0.0):
@@ -748,7 +755,7 @@ class HipKernels(KernelSpec):
         n, wt = gcat.shape
         C = dP.shape[1] if dP is not None else 0
         self._dev(gcat, xcat, dP, P, S, invd, ge1, rq, dA_out, *aggs)
-        K = wt + C + 1
+        K = wt + C + 2                       # (+ the row term as two columns: w_hi | w_lo)
         ldK = (K + 3) // 4 * 4
         Lc = torch.empty(n, ldK, dtype=torch.float32, device=gcat.device)
         Rc = torch.empty(n, ldK, dtype=torch.float32, device=gcat.device)

@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import native, ops
+from . import kernels, native, ops
 from .graph import BatchGraph, uniform_ptr
 
 EPS = 1e-15
@@ -332,6 +332,10 @@ class SoftPoolingGcnEncoder(nn.Module):
         # levels 2-3: the adjacency gradient as one product of thin operands (cgc_level_desc.flags bit 0; -1.4 % per step at C3, up
         # to 3x the rounding error on the coarsened levels' gradients: off unless asked for)
         self.adj_backward_fused = os.environ.get('CGC_ADJ_FUSED', '0') == '1'
+        # 0 = kernels.GEMM_EXACT (fp32 matrix-core chain, the default); 1 = kernels.GEMM_SPLIT_BF16: the six dominant products of a
+        # step (assignment Linear, S^T(AS), their backward: model/network.py:121-122,206-207) as six bf16 MFMA pairs per fp32 product
+        # -- same results to fp32 rounding (include/cgc_hip.h: cgc_gemm_f32_ws), 1.3-1.6x faster on those products
+        self.gemm_mode = int(os.environ.get('CGC_GEMM_SPLIT_BF16', '0'))
         self._unorder = None
 
     def __getstate__(self):
@@ -540,6 +544,8 @@ class SoftPoolingGcnEncoder(nn.Module):
 
     def forward(self, data):
         self.assign_matrix = []
+        if kernels.is_native():
+            kernels.get().gemm_mode = int(getattr(self, 'gemm_mode', 0))
         if self.load_data_sparse:
             label = data.y
         else:

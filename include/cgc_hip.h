@@ -39,8 +39,10 @@ typedef void* cgc_stream_t; /* hipStream_t */
  * (cgc-net_amd/_abi.py: ABI_VERSION) with cgc_abi_version() of the library they loaded and refuse a mismatch.
  *   1: rounds 1-3 (operators, step sequencer, head, optimiser, measurement hook)
  *   2: round 4 (head: labels outside [0, L) are ignored like F.cross_entropy's ignore_index; forward BatchNorm statistics in double:
- *      cgc_stats_ws_floats; additions listed in DESIGN.md) */
-#define CGC_ABI_VERSION 2
+ *      cgc_stats_ws_floats; additions listed in DESIGN.md)
+ *   3: round 5 (cgc_gemm_f32_ws / cgc_gemm_f32_cat_ws take a `mode`; cgc_level_desc.flags bit 1; head: a label outside [0, L) other
+ *      than -100 makes the loss NaN instead of being ignored) */
+#define CGC_ABI_VERSION 3
 int cgc_abi_version(void);
 
 /* ---- A1: graph structure.  Replaces to_dense_adj (model/utils.py:3-36, called at model/network.py:241).
@@ -166,18 +168,29 @@ int cgc_gemm_f32_cat(int transA, int transB, int M, int N, int K, float alpha, c
  * piece parks its raw fp32 accumulators in a slab of ws, and a second kernel adds a tile's slabs IN PIECE ORDER and applies
  * alpha / beta / bias: deterministic (no atomics, no arrival order), no flags, no spinning.  ws: ws_floats >= cgc_gemm_ws_floats()
  * floats, contents irrelevant before and after; products on one stream may share it.  ws = NULL (or too small, or a product the
- * split does not apply to: short reductions, other tile shapes) behaves exactly as the plain entry points. */
+ * split does not apply to: short reductions, other tile shapes) behaves exactly as the plain entry points.
+ *
+ * mode (round 5):  CGC_GEMM_EXACT -- the fp32 matrix-core chain (v_mfma_f32_32x32x2_f32: bitwise an fmaf chain), the default of every
+ * caller;  CGC_GEMM_SPLIT_BF16 -- products that take the 128 x 128 route (both output extents > 128, reduction > 160, operands fit
+ * for 16-byte loads) are computed on the bf16 matrix cores instead: every fp32 element as hi + mid + lo (three bf16 values, exact),
+ * the six pairs above 2^-24 multiplied exactly and summed in fp32 (csrc/gemm_split.hip).  Same forms (NN / NT / TN, ragged 1 / 2 / 3,
+ * extra K segments, beta, bias, tail split), same determinism; max and rms error against float64 within 1.25 x the exact kernel's
+ * (tests/test_kernels_gpu.py::test_split_gemm_*).  Inputs must be finite; magnitudes below ~2^-108 lose the low planes.  Products the
+ * mode does not apply to run on the exact kernel.  The plain entry points above are always exact. */
+#define CGC_GEMM_EXACT 0
+#define CGC_GEMM_SPLIT_BF16 1
+int64_t cgc_gemm_split_count(void);   /* products this process has sent to the split kernel so far (diagnostic: did the mode apply?) */
 int64_t cgc_gemm_ws_floats(void);
 int cgc_gemm_f32_ws(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
                     const float* B, int ldb, float beta, float* C, int ldc, const float* bias, int batch,
                     int64_t strideA, int64_t strideB, int64_t strideC, const int* gptr, int ragged, int max_ragged,
-                    float* ws, int64_t ws_floats, cgc_stream_t stream);
+                    float* ws, int64_t ws_floats, int mode, cgc_stream_t stream);
 int cgc_gemm_f32_cat_ws(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
                         const float* B, int ldb, float beta, float* C, int ldc, const float* bias, int batch,
                         int64_t strideA, int64_t strideB, int64_t strideC, const int* gptr, int ragged, int max_ragged,
                         int nx, const float* const* xA, const int* xlda, const int64_t* xstrideA,
                         const float* const* xB, const int* xldb, const int64_t* xstrideB, const int* xK,
-                        float* ws, int64_t ws_floats, cgc_stream_t stream);
+                        float* ws, int64_t ws_floats, int mode, cgc_stream_t stream);
 /* Tuning hook for experiments (tools/gemm_cfg_sweep.py): cfg 1..6 forces the tile shape 128x128, 128x64, 64x128, 64x64, 128x32,
  * 32x128 for every following product of this process, +10 the pipelined kernel, +20 the short-K kernel; 0 restores the automatic
  * selection.  Returns the previous value.  Results do not depend on it (same arithmetic per output element up to tile-edge order). */
@@ -322,7 +335,7 @@ int cgc_adj_prep_fwd(const float* A, int R, int C, float p, float* At, float* An
  * re-normalisation is (1 - p) * rq -- what cgc_adj_grad_operands needs */
 int cgc_adj_prep_fwd2(const float* A, int R, int C, float p, float* At, float* An, float* invd, float* ge1, float* rq, cgc_stream_t stream);
 /* Backward of the two row normalisations WITHOUT N x N intermediates (csrc/rowops.hip, k_adj_grad_operands, has the derivation):
- * forms Lc, Rc [n, ldK] such that  d A[b] = Lc[b] Rc[b]^T  (K = wt + C + 1 columns; one batched NT product), to be followed by
+ * forms Lc, Rc [n, ldK] such that  d A[b] = Lc[b] Rc[b]^T  (K = wt + C + 2 columns -- the row term in double, carried as w_hi | w_lo; one batched NT product), to be followed by
  * cgc_zero_diag when p >= 0.  gcat / xcat [n, wt]: the gradients / inputs of the level's three aggregations side by side; agg[3] /
  * aw[3]: the saved aggregation outputs in the same column order and their widths; dP, P [n, ldP], S [n, ldS]: the DiffPool operands
  * (dP NULL: the level has no DiffPool; C is then ignored); invd, ge1 (cgc_adj_prep_fwd), rq (cgc_adj_prep_fwd2; needed when p >= 0). */
@@ -372,7 +385,9 @@ typedef struct {
                            * batched GEMM + cgc_zero_diag) instead of two N x N products + cgc_adj_prep_bwd: 1.4 % faster per step at C3,
                            * same value, but its row terms are no longer formed from the N x N matrices they centre -- a row-coherent
                            * rounding error that costs up to 3x in gradient accuracy on the coarsened levels.
-                           * Off by default: the default schedule is the per-operator path's, bit for bit */
+                           * Off by default: the default schedule is the per-operator path's, bit for bit
+                           * bit 1: the level's products run with mode CGC_GEMM_SPLIT_BF16 (cgc_gemm_f32_ws): those on the 128 x 128
+                           * route as six bf16 MFMA pairs per fp32 product.  Off by default */
 } cgc_level_desc;
 
 typedef struct {          /* one GNN_Module's parameters (DEVICE pointers; unused ones NULL) */

@@ -20,3 +20,25 @@ def torch_kernels(monkeypatch):
     from oracle.flat_ref import TorchKernels
     monkeypatch.setattr(kernels, '_instance', TorchKernels())
     yield
+
+
+@pytest.fixture(params=['exact', 'split'])
+def gemm_mode(request, monkeypatch):
+    """Run a model-level GPU test twice: with the default exact fp32 GEMM and with CGC_GEMM_SPLIT_BF16 (csrc/gemm_split.hip: the big
+    products as six bf16 MFMA pairs per fp32 product) -- same test body, same bars.  Encoders built inside the test pick the mode up
+    from the environment (network.SoftPoolingGcnEncoder.gemm_mode); the fixture also reports how many products took the split kernel."""
+    import cgc_net_amd.kernels as kernels
+    split = request.param == 'split'
+    monkeypatch.setenv('CGC_GEMM_SPLIT_BF16', '1' if split else '0')
+    K = kernels.get()
+    before = int(K.lib.cgc_gemm_split_count())
+
+    class Mode(object):
+        name = request.param
+        is_split = split
+
+        @staticmethod
+        def launches():
+            return int(K.lib.cgc_gemm_split_count()) - before
+    yield Mode
+    K.gemm_mode = kernels.GEMM_EXACT

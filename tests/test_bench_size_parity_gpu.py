@@ -164,16 +164,17 @@ def _compare_model(cpu_batch, maxn, feat, flags):
 
 
 @pytest.mark.parametrize('flags', [dict(norm_adj=True, jk=True), dict()], ids=['shipped', 'plain'])
-def test_full_model_c3_shapes_vs_oracle(flags):
+def test_full_model_c3_shapes_vs_oracle(flags, gemm_mode):
     ds = SyntheticCellGraphs(8, 1800, 16, base_seed=11)
     cpu_batch = Batch.from_data_list([ds[i] for i in range(8)])
     records, worst = _compare_model(cpu_batch, 11404, 16, flags)
+    assert (gemm_mode.launches() >= 12) == gemm_mode.is_split, gemm_mode.launches()      # (twin + model: six products each)
     # the benchmarked kernels were on the path: the six 128x128 contractions and both wide aggregations
     assert records.get('gemm_128x128', 0) >= 6, records
     assert records.get('spmm_wide', 0) == 2, records
 
 
-def test_full_model_c5_shapes_fuse_sampled_vs_oracle():
+def test_full_model_c5_shapes_fuse_sampled_vs_oracle(gemm_mode):
     """BASELINE configs[4]: ~8000-node graphs (the 'fuse' sampler keeps half of 16000 nuclei, dataflow/data.py:210-219),
     64 features, cluster counts 1600 / 160, shipped flags.  Sampling and the k-NN graph run on the device (F3, F2)."""
     B, cand = 3, 16000
@@ -193,18 +194,20 @@ def test_full_model_c5_shapes_fuse_sampled_vs_oracle():
     cpu_batch = Batch.from_data_list(items)
     records, worst = _compare_model(cpu_batch, 16000, 64, dict(norm_adj=True, jk=True))
     assert records.get('gemm_128x128', 0) >= 6 and records.get('spmm_wide', 0) == 2, records
+    assert (gemm_mode.launches() >= 12) == gemm_mode.is_split, gemm_mode.launches()
 
 
-def test_full_model_exact_bench_batch_vs_oracle():
+def test_full_model_exact_bench_batch_vs_oracle(gemm_mode):
     """THE benchmarked batch itself: 32 graphs (bench.py's seed 0 pool, batch 0), shipped flags, max_num_nodes = 11404 --
     forward + backward against the dense oracle in fp32 and fp64 (the oracle needs ~20 s of host time for it)."""
     ds = SyntheticCellGraphs(32, 1800, 16, base_seed=0)
     cpu_batch = Batch.from_data_list([ds[i] for i in range(32)])
     records, worst = _compare_model(cpu_batch, 11404, 16, dict(norm_adj=True, jk=True))
     assert records.get('gemm_128x128', 0) >= 6 and records.get('spmm_wide', 0) == 2, records
+    assert (gemm_mode.launches() >= 12) == gemm_mode.is_split, gemm_mode.launches()
 
 
-def test_training_step_is_deterministic():
+def test_training_step_is_deterministic(gemm_mode):
     """Every reduction in the path has a fixed order (slot reductions, split-K combines, in-kernel accumulations): the same
     step from the same state gives BITWISE the same loss and gradients, run after run."""
     ds = SyntheticCellGraphs(8, 1800, 16, base_seed=3)

@@ -182,7 +182,13 @@ def test_bench_self_launch_two_ranks_reports_strong_and_weak():
     assert rec['n_gpus'] == 2 and rec['scaling'] == 'strong' and rec['config']['global_batch'] == 8
     assert rec['value'] > 0 and abs(rec['value'] - 8 * 3 / (rec['ms_per_step'] * 3e-3)) < 0.05 * rec['value']
     assert 'STRONG' in rec['scaling_note']
-    assert rec['rccl_ranks'] == 2 and rec['backend'].startswith('gloo')
+    assert rec['rccl_ranks'] == 2 and rec['backend'].startswith('gloo') and 'rccl_version' in rec
+    # every rank says what it worked on and where it ran: the cumulative-node-count split of each global batch, ONE intra-op thread,
+    # a core slice of its own (disjoint from the other rank's when the box has more than one usable core)
+    assert [r_['rank'] for r_ in rec['ranks']] == [0, 1]
+    assert all(r_['threads'] == 1 and 'cores' in r_ for r_ in rec['ranks'])
+    assert all(a + b == 8 for a, b in zip(rec['ranks'][0]['graphs'], rec['ranks'][1]['graphs']))
+    assert rec['ranks'][0]['cores'] != rec['ranks'][1]['cores'] or len(os.sched_getaffinity(0)) == 1
     # the weak leg: 8 graphs per rank per step
     assert rec['weak_global_batch'] == 16
     assert rec['weak_value'] > 0 and abs(rec['weak_value'] - 16 * 3 / (rec['weak_ms_per_step'] * 3e-3)) < 0.05 * rec['weak_value']
