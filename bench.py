@@ -237,7 +237,7 @@ def main():
             dist.init_process_group('nccl', device_id=dev)
         else:
             dist.init_process_group(args.backend)
-    binding = bind_rank(rank, local, world, dev.index) if world > 1 else None
+    binding = bind_rank(rank, int(os.environ.get('LOCAL_RANK', '0')), world, dev.index) if world > 1 else None      # (the un-wrapped local rank: --oversubscribe folds `local`)
 
     import cgc_net_amd  # noqa: F401
     from cgc_net_amd import kernels, network

@@ -569,7 +569,7 @@ int level_fwd(const Ctx& c, Level& L, const cgc_block_params* emb, const cgc_blo
   CALL(cgc_softmax_fwd(L.S, n, C, L.ldC, L.S, c.s));
   // _diff_pool (model/network.py:194-208): X' = S^T X, A' = S^T (A S)
   if (!L.dense) {
-    CALL(cgc_spmm_graphs_ordered(g->rowptr, g->col, nullptr, g->val, nullptr, nullptr, L.S, L.P, n, C, L.ldC, gptr, L.B, d.nmax, 1, g->gorder, c.s));
+    CALL(cgc_spmm_graphs_ordered(g->rowptr, g->col, nullptr, g->val, nullptr, nullptr, L.S, L.P, n, C, L.ldC, gptr, L.B, d.nmax, 1 | (g->spatial ? 4 : 0), g->gorder, c.s));
     TRY(gemm(c, 1, 0, C, L.D, 0, L.S, L.ldC, L.embed(), L.D, 0.f, x_out, L.D, nullptr, L.B, 0, 0, (int64_t)C * L.D, gptr, 2, d.nmax));
     TRY(gemm(c, 1, 0, C, C, 0, L.S, L.ldC, L.P, L.ldC, 0.f, A_out, C, nullptr, L.B, 0, 0, (int64_t)C * C, gptr, 2, d.nmax));
   } else {
@@ -690,7 +690,7 @@ int level_bwd(const Ctx& c, Level& L, const cgc_block_params* emb, const cgc_blo
     if (!L.dense) {
       float* dp = sc.f((size_t)n * L.ldC);
       TRY(gemm(c, 0, 0, 0, C, C, L.S, L.ldC, d_ao, C, 0.f, dp, L.ldC, nullptr, B, 0, (int64_t)C * C, 0, gptr, 1, d.nmax));      // dP = S dA'
-      CALL(cgc_spmm_graphs_ordered(g->t_rowptr, g->t_col, nullptr, g->t_val, nullptr, nullptr, dp, ds, n, C, L.ldC, gptr, B, d.nmax, 2, g->gorder,
+      CALL(cgc_spmm_graphs_ordered(g->t_rowptr, g->t_col, nullptr, g->t_val, nullptr, nullptr, dp, ds, n, C, L.ldC, gptr, B, d.nmax, 2 | (g->spatial ? 4 : 0), g->gorder,
                                    c.s));                                                                                          // dS = A^T dP
       TRY(gemm_x1(c, 0, 1, 0, C, C, L.P, L.ldC, d_ao, C, 1.f, ds, L.ldC, nullptr, B, 0, (int64_t)C * C, 0, gptr, 1, d.nmax, L.embed(), D, 0, d_xo,
                   D, (int64_t)C * D, D));                                                                  // + P dA'^T + X dX'^T

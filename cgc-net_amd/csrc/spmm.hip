@@ -220,6 +220,191 @@ __global__ __launch_bounds__(256) void k_spmm_wide(const int* __restrict__ rowpt
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Wide rows, SPATIALLY ORDERED nodes (round 5): the neighbour union of a block of consecutive rows staged in LDS.
+//
+// k_spmm_wide re-reads every neighbour row ~9x from L2 (2.9 GB of L2 -> CU traffic per launch at C3 for 531 MB of algorithmic
+// bytes: it runs at the rate of its gathers, 0.42 of the HBM peak).  When the nuclei of a graph are listed grid cell by grid cell
+// (data.spatial_order: cell = the k-NN radius), the neighbours of RB = 32 CONSECUTIVE rows -- a strip ~6 cells long -- lie in the 3 x 8
+// cells around it: ~130 distinct rows instead of 32 x 9 gathers.  One workgroup owns such a block for ALL column tiles:
+//   once:      the block's edges -> the window [min col, max col] -> a presence table in LDS -> prefix sum = slot of every union row,
+//              every edge's (slot, weight) parked in LDS;
+//   per tile:  the U union rows' 512-byte pieces copied into LDS ONCE (coalesced 16-byte loads, 32 lanes per row), then the 32 rows
+//              of the block gather from LDS (ds_read_b128, slot / weight by broadcast reads) and stream their 512 bytes out.
+// L2 -> CU traffic drops to U / RB ~ 4x the rows instead of 9x, and two workgroups share a CU (80 KB of LDS each): one stages while the
+// other gathers.  A block whose union, edge count or id window exceeds the LDS budget (nodes NOT in spatial order, hubs) falls back to
+// direct gathers for that block -- correct for any input, fast only for ordered ones: the caller says so (visit bit 2).
+#define PATCH_RB 32         // rows per block
+#define PATCH_T 128         // floats per column tile (512 bytes: 32 lanes x 16 bytes)
+#define PATCH_CAP 144       // union rows the stage holds
+#define PATCH_ECAP 512      // edges of a block
+#define PATCH_TW 2048       // id window (max col - min col + 1) the presence table covers
+struct PatchLds {
+  float stage[PATCH_CAP * PATCH_T];          // 73728 B
+  unsigned short table[PATCH_TW];            // presence, then slot (0xffff: absent)
+  unsigned short eslot[PATCH_ECAP];
+  float ew[PATCH_ECAP];
+  unsigned short list[PATCH_CAP];            // slot -> id - lo
+  int scan[8];
+  int lo, hi, U, ok;
+};
+
+template <bool VAL, bool PERM, bool PRE>
+__global__ __launch_bounds__(256, 2) void k_spmm_patch(const int* __restrict__ rowptr, const int* __restrict__ col, const int* __restrict__ perm,
+                                                       const float* __restrict__ val, const float* __restrict__ pre,
+                                                       const float* __restrict__ post, const float* __restrict__ x, float* __restrict__ out,
+                                                       int W, int ld, const int* __restrict__ gptr, int B, int blocks_per_graph,
+                                                       const int* __restrict__ gorder) {
+  typedef float f4v __attribute__((ext_vector_type(4)));
+  extern __shared__ __attribute__((aligned(16))) unsigned char patch_raw[];
+  PatchLds& L = *reinterpret_cast<PatchLds*>(patch_raw);
+  const int nb = gridDim.x, b = blockIdx.x;
+  const int vb = (nb % 8 == 0) ? (b % 8) * (nb / 8) + b / 8 : b;       // XCD-contiguous: neighbouring blocks share an L2
+  const int gi = vb / blocks_per_graph;
+  if (gi >= B) return;
+  const int g = gorder != nullptr ? gorder[gi] : gi;
+  const int g0 = gptr[g], g1 = gptr[g + 1];
+  const int r0 = g0 + (vb - gi * blocks_per_graph) * PATCH_RB;
+  if (r0 >= g1) return;
+  const int r1 = min(r0 + PATCH_RB, g1);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l32 = lane & 31, half = lane >> 5;
+  const int s0 = rowptr[r0], e1 = rowptr[r1], E = e1 - s0;
+  const int n_ct = (W + PATCH_T - 1) / PATCH_T;
+
+  // ---- once per block: id window, presence table, slots, per-edge (slot, weight)
+  if (tid == 0) { L.lo = 0x7fffffff; L.hi = -1; L.ok = 1; }
+  __syncthreads();
+  {
+    int mn = 0x7fffffff, mx = -1;
+    for (int k = s0 + tid; k < e1; k += 256) {
+      const int c = col[k];
+      mn = min(mn, c);
+      mx = max(mx, c);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      mn = min(mn, __shfl_xor(mn, o));
+      mx = max(mx, __shfl_xor(mx, o));
+    }
+    if (lane == 0 && mx >= 0) {
+      atomicMin(&L.lo, mn);
+      atomicMax(&L.hi, mx);
+    }
+  }
+  __syncthreads();
+  const int lo = L.lo, span = L.hi - lo + 1;            // (E == 0: span <= 0, nothing to stage)
+  bool direct = E > PATCH_ECAP || span > PATCH_TW;
+  if (!direct && E > 0) {
+    for (int i = tid; i < span; i += 256) L.table[i] = 0;
+    __syncthreads();
+    for (int k = s0 + tid; k < e1; k += 256) L.table[col[k] - lo] = 1;
+    __syncthreads();
+    // exclusive prefix sum of the presence flags: 8 consecutive entries per thread (span <= 2048), wave scan, 4 wave totals
+    const int base = tid * 8;
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) cnt += (base + j < span && L.table[base + j]) ? 1 : 0;
+    int incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int up = __shfl_up(incl, o);
+      if (lane >= o) incl += up;
+    }
+    if (lane == 63) L.scan[wave] = incl;
+    __syncthreads();
+    int off = incl - cnt;
+    for (int w = 0; w < wave; ++w) off += L.scan[w];
+    const int U = L.scan[0] + L.scan[1] + L.scan[2] + L.scan[3];
+    __syncthreads();                                     // (everybody has read the flags' wave totals; the table is rewritten below)
+    if (U <= PATCH_CAP) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (base + j < span) {
+          const bool present = L.table[base + j] != 0;
+          L.table[base + j] = present ? (unsigned short)off : (unsigned short)0xffff;
+          if (present) {
+            L.list[off] = (unsigned short)(base + j);
+            ++off;
+          }
+        }
+      }
+    }
+    if (tid == 0) L.U = U;
+    __syncthreads();
+    if (U > PATCH_CAP) {
+      direct = true;
+    } else {
+      for (int k = s0 + tid; k < e1; k += 256) {
+        const int c = col[k];
+        float w = VAL ? val[PERM ? perm[k] : k] : 1.f;
+        if (PRE) w *= pre[c];
+        L.eslot[k - s0] = L.table[c - lo];
+        L.ew[k - s0] = w;
+      }
+    }
+  }
+  __syncthreads();
+  const int U = direct ? 0 : (E > 0 ? L.U : 0);
+
+  for (int ct = 0; ct < n_ct; ++ct) {
+    const int c0 = ct * PATCH_T + l32 * 4;
+    const bool colok = c0 < W;
+    if (!direct) {
+      // stage: half a wave per union row, 8 rows per trip and workgroup
+      for (int sl = wave * 2 + half; sl < U; sl += 32) {          // four rows per lane in flight
+        f4v v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int q = min(sl + 8 * j, U - 1);
+          v[j] = colok ? *reinterpret_cast<const f4v*>(x + (size_t)(lo + L.list[q]) * ld + c0) : f4v{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (sl + 8 * j < U) *reinterpret_cast<f4v*>(&L.stage[(sl + 8 * j) * PATCH_T + l32 * 4]) = v[j];
+      }
+      __syncthreads();
+    }
+    // gather: half a wave per output row
+    for (int r = r0 + wave * 2 + half; r < r1; r += 8) {
+      const int s = rowptr[r], e = rowptr[r + 1];
+      f4v acc = {0.f, 0.f, 0.f, 0.f};
+      if (!direct) {
+        // eight edges at a time: their slots and weights first (broadcast reads), then the eight 16-byte gathers, then the FMAs in
+        // edge order -- one after the other each edge is two dependent LDS round trips
+        const int ke = e - s0;
+        for (int k = s - s0; k < ke; k += 8) {
+          int sl[8];
+          float w[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int kk = min(k + u, ke - 1);
+            sl[u] = (int)L.eslot[kk];
+            w[u] = k + u < ke ? L.ew[kk] : 0.f;
+          }
+          f4v v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f4v*>(&L.stage[sl[u] * PATCH_T + l32 * 4]);
+#pragma unroll
+          for (int u = 0; u < 8; ++u) acc += w[u] * v[u];
+        }
+      } else if (colok) {
+        for (int k = s; k < e; ++k) {
+          const int c = col[k];
+          float w = VAL ? val[PERM ? perm[k] : k] : 1.f;
+          if (PRE) w *= pre[c];
+          acc += w * *reinterpret_cast<const f4v*>(x + (size_t)c * ld + c0);
+        }
+      }
+      if (colok) {
+        if (post != nullptr) acc *= post[r];
+        __builtin_nontemporal_store(acc, reinterpret_cast<f4v*>(out + (size_t)r * ld + c0));
+      }
+    }
+    if (!direct) __syncthreads();                        // (the stage is overwritten by the next column tile)
+  }
+}
+
 // tuning knobs (read once from the environment; defaults are the measured best for ~1800-node cell graphs)
 static int knob(const char* name, int dflt) {
   const char* v = getenv(name);
@@ -422,7 +607,37 @@ extern "C" int cgc_spmm_graphs_ordered(const int* rowptr, const int* col, const 
 #undef SLAB_ARGS
   }
   const int trec = width > 64 ? cgc_timing_begin(CGC_TAG_SPMM_WIDE, n, width, ld, val != nullptr, 0, 0, 0, as_stream(stream)) : -1;
-  const int rc = launch_gather(rowptr, col, perm, val, pre, post, x, out, n, width, ld, gptr, B, nmax, visit, as_stream(stream), gorder);
+  // visit bit 2: the caller lists every graph's nodes grid cell by grid cell.  The LDS-staged patch kernel that could exploit it is an
+  // EXPERIMENT (CGC_SPMM_PATCH=1): measured 277-312 us against 150 us for k_spmm_wide on the same ordered graphs at C3 (profiles/
+  // r05_k4_patch_kernel.txt) -- its staging and gather phases are latency chains of a few waves, the gather kernel
+  // keeps 32 waves x 9 loads in flight per CU.  Off by default; the hint itself is free and already helps the gather kernel (+3 %)
+  static const int k_patch = knob("CGC_SPMM_PATCH", 0);
+  int rc;
+  if (((visit & 8) || (k_patch && (visit & 4))) && gptr != nullptr && B > 0 && nmax > 0 && width > 256 && width % 4 == 0 && ld % 4 == 0 &&
+      aligned16(x) && aligned16(out)) {
+    hipStream_t st = as_stream(stream);
+    const int bpg = ceil_div(nmax, PATCH_RB);
+    const int nbp = ceil_div(B * bpg, 8) * 8;
+    const bool hv = val != nullptr, hp = hv && perm != nullptr, hq = pre != nullptr;
+#define PATCH_LAUNCH(V, P, Q)                                                                                                         \
+  do {                                                                                                                                \
+    static bool attr__[CGC_MAX_DEVICES] = {};                                                                                         \
+    cgc_allow_lds(reinterpret_cast<const void*>(&k_spmm_patch<V, P, Q>), (int)sizeof(PatchLds), attr__);                              \
+    hipLaunchKernelGGL((k_spmm_patch<V, P, Q>), dim3(nbp), dim3(256), sizeof(PatchLds), st, rowptr, col, perm, val, pre, post, x, out, \
+                       width, ld, gptr, B, bpg, gorder);                                                                              \
+  } while (0)
+    if (!hv && !hq) PATCH_LAUNCH(false, false, false);
+    else if (!hv) PATCH_LAUNCH(false, false, true);
+    else if (!hp && !hq) PATCH_LAUNCH(true, false, false);
+    else if (!hp) PATCH_LAUNCH(true, false, true);
+    else if (!hq) PATCH_LAUNCH(true, true, false);
+    else PATCH_LAUNCH(true, true, true);
+#undef PATCH_LAUNCH
+    hipError_t e__ = hipGetLastError();
+    rc = e__ == hipSuccess ? 0 : (int)e__;
+  } else {
+    rc = launch_gather(rowptr, col, perm, val, pre, post, x, out, n, width, ld, gptr, B, nmax, visit & 3, as_stream(stream), gorder);
+  }
   cgc_timing_end(trec, as_stream(stream));
   return rc;
 }

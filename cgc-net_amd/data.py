@@ -83,7 +83,7 @@ class Batch(Data):
         assert knn is None and mean is None and std is None and not spatial, \
             'host collate: items arrive finished (dataflow/data.py:330-354)'
         out = Batch()
-        keys = data_list[0].keys
+        keys = [k for k in data_list[0].keys if not k.startswith('_')]      # (underscore attributes are host-side notes, not data)
         offset, cat, batch_vec = 0, {k: [] for k in keys}, []
         for g, d in enumerate(data_list):
             n = d.num_nodes
@@ -105,6 +105,10 @@ class Batch(Data):
         # per-graph row offsets: travel to the device with the batch (.to()), so that the model does not start every step with a
         # blocking host-to-device copy of its own
         out._gptr = torch.tensor([0] + list(np.cumsum(out._node_counts)), dtype=torch.int32)
+        # every item says its nodes are listed grid cell by grid cell (spatial_order): the wide aggregation may stage neighbour unions
+        # of consecutive rows in LDS (graph.BatchGraph.spatial -> cgc_spmm_graphs visit bit 2)
+        if all(getattr(d, '_spatial', False) for d in data_list):
+            out._spatial = True
         return out
 
 
@@ -175,6 +179,8 @@ def _collate_on_device(data_list, device, knn, mean, std, spatial=False):
     dv = {k: dbuf[o:o + nbytes].view(dtype).view(shape) for k, _, _, shape, dtype, o, nbytes in segs}
     out = Batch()
     for k in first.keys:
+        if k.startswith('_'):
+            continue
         if k in dv:
             out[k] = dv[k]
         elif not torch.is_tensor(first[k]):
@@ -206,6 +212,8 @@ def _collate_on_device(data_list, device, knn, mean, std, spatial=False):
     out.num_graphs = B
     out._node_counts = counts
     out._gptr = dv['_gptr']
+    if spatial or all(getattr(d, '_spatial', False) for d in data_list):
+        out._spatial = True
     return out
 
 
@@ -332,7 +340,10 @@ class SyntheticCellGraphs(torch.utils.data.Dataset):
         x = torch.from_numpy(rng.standard_normal((n, self.num_features)).astype(np.float32))
         y = torch.tensor([int(rng.randint(0, self.num_classes))], dtype=torch.long)
         edge_index = radius_graph(pos, self.radius, None, True, self.max_neighbours)
-        return Data(x=x, pos=pos, y=y, edge_index=edge_index, patch_idx=torch.tensor([idx]))
+        d = Data(x=x, pos=pos, y=y, edge_index=edge_index, patch_idx=torch.tensor([idx]))
+        if self.spatial:
+            d._spatial = True
+        return d
 
 
 def fuse_sample(pos, k, rng, farthest_frac=0.7):

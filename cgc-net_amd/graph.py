@@ -57,6 +57,7 @@ class BatchGraph(object):
         self.val = None
         self.t_val = None
         self.renorm_p = None
+        self.spatial = False
 
     @property
     def padded_rows(self):
@@ -77,6 +78,9 @@ class BatchGraph(object):
     def from_batch(cls, batch, renorm_p=None):
         x, edge_index = batch.x, batch.edge_index
         g = cls(x.shape[0], cls.node_counts_of(batch), x.device, getattr(batch, '_dense_rows', None), getattr(batch, '_gptr', None))
+        # the nodes of every graph are listed grid cell by grid cell (data.spatial_order; the Batch says so): the wide aggregation
+        # stages the neighbour union of consecutive rows in LDS (cgc_spmm_graphs: visit bit 2).  A hint about speed, never about results.
+        g.spatial = bool(getattr(batch, '_spatial', False))
         g._build(edge_index.contiguous(), renorm_p)
         return g
 

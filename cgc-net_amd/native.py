@@ -37,7 +37,7 @@ class JkParams(C.Structure):
 
 
 class Graph(C.Structure):
-    _fields_ = [('rowptr', P), ('col', P), ('t_rowptr', P), ('t_col', P), ('val', P), ('t_val', P), ('inv_d', P), ('gorder', P)]
+    _fields_ = [('rowptr', P), ('col', P), ('t_rowptr', P), ('t_col', P), ('val', P), ('t_val', P), ('inv_d', P), ('gorder', P), ('spatial', I)]
 
 
 class GradLayout(C.Structure):
@@ -247,6 +247,7 @@ class _Level(Function):
         if g is not None:
             gs.rowptr, gs.col, gs.t_rowptr, gs.t_col = _p(g.rowptr), _p(g.col), _p(g.t_rowptr), _p(g.t_col)
             gs.val, gs.t_val, gs.inv_d, gs.gorder = _p(g.val), _p(g.t_val), _p(g.inv_d), _p(g.gorder)
+            gs.spatial = int(bool(getattr(g, 'spatial', False)))
         s_ptr, s_ld = P(), I()
         rc = lib.cgc_level_fwd(C.byref(d), C.byref(pe), C.byref(pp), C.byref(pj), C.byref(gs), _p(gptr), _p(x_in), _p(A_in), _p(saved),
                                _p(scratch), _p(readout), _p(x_out), _p(A_out), C.byref(s_ptr), C.byref(s_ld), stream)
@@ -358,6 +359,7 @@ def level_eval(enc, desc, emb, pool, jk, g, gptr, x_in, A_in, assign=None, prep=
     if g is not None:
         gs.rowptr, gs.col, gs.t_rowptr, gs.t_col = _p(g.rowptr), _p(g.col), _p(g.t_rowptr), _p(g.t_col)
         gs.val, gs.t_val, gs.inv_d, gs.gorder = _p(g.val), _p(g.t_val), _p(g.inv_d), _p(g.gorder)
+        gs.spatial = int(bool(getattr(g, 'spatial', False)))
     s_ptr, s_ld = P(), I()
     rc = lib.cgc_level_fwd(C.byref(d), C.byref(pe), C.byref(pp), C.byref(pj), C.byref(gs), _p(gptr), _p(x_in), _p(A_in), _p(saved),
                            _p(scratch), _p(readout), _p(x_out), _p(A_out), C.byref(s_ptr), C.byref(s_ld), K._stream())

@@ -457,6 +457,7 @@ class SoftPoolingGcnEncoder(nn.Module):
         flat.x = data.x[perm]
         flat.edge_index = inv[data.edge_index]
         flat._node_counts = counts
+        flat._spatial = True
         for k in ('_gptr', '_dense_rows'):
             if getattr(data, k, None) is not None:
                 setattr(flat, k, getattr(data, k))

@@ -637,7 +637,7 @@ class _DiffPoolSparse(Function):
             if p.stride(0) != ld:                                 # foreign stride: fall back to dense rows
                 s, ld, pad = s.contiguous(), c, None
                 p = torch.empty_like(s)
-        K().spmm(g.rowptr, g.col, None, g.val, None, None, s, p, n, c, g.gptr, g.B, g.nmax, 1, pad, g.gorder)   # S: fresh from the softmax
+        K().spmm(g.rowptr, g.col, None, g.val, None, None, s, p, n, c, g.gptr, g.B, g.nmax, 1 | (4 if g.spatial else 0), pad, g.gorder)   # S: fresh from the softmax
         xo = torch.empty(g.B, c, dx, dtype=torch.float32, device=dev)
         ao = torch.empty(g.B, c, c, dtype=torch.float32, device=dev)
         # ragged-K, transposed-A contractions: per graph  [c x N_b] . [N_b x (dx | c)]
@@ -665,7 +665,7 @@ class _DiffPoolSparse(Function):
         # dS = A^T dP  (transpose SpMM) + P dA'^T + X dX'^T
         ds = rows()
         K().spmm(g.t_rowptr, g.t_col, None, g.t_val, None, None, dp, ds, n, c,
-                 g.gptr, g.B, g.nmax, 2, pad, g.gorder)                                              # dP: fresh from the gemm
+                 g.gptr, g.B, g.nmax, 2 | (4 if g.spatial else 0), pad, g.gorder)                                              # dP: fresh from the gemm
         # ... both products in one launch: [P | X] [dA' | dX']^T, the K = dx segment rides on the K = c product
         K().gemm(p, dao, ds, 0, c, c, False, True, ld, c, ld, 1.0, 1.0, None, g.B, 0, c * c, 0, g.gptr, 1, g.nmax, n,
                  extra=[(embed, dxo, dx, dx, dx, 0, c * dx)])

@@ -121,8 +121,12 @@ int cgc_spmm(const int* rowptr, const int* col, const int* perm, const float* va
 /* Same contract when the rows are a batch of graphs (block-diagonal adjacency): gptr[B+1] = first row of each graph,
  * nmax = largest graph.  Wide rows are then swept one (graph, 1 KiB column tile) slab at a time per XCD so that the ~9x
  * re-read of neighbour rows is served by that XCD's L2.  visit = scheduling hint only (results identical): which graphs
- * of x the previous kernel left in the Infinity Cache -- 0 unknown / ascending, 1 x was written in ascending row order,
- * 2 x was written by cgc_gemm_f32 as a ragged batch. */
+ * of x the previous kernel left in the Infinity Cache -- bits 0-1: 0 unknown / ascending, 1 x was written in ascending row order,
+ * 2 x was written by cgc_gemm_f32 as a ragged batch.  Bit 2 (+4, round 5): the nodes of every graph are listed grid cell by grid cell
+ * (neighbours in space are neighbours in memory: data.spatial_order): the gather kernel's re-reads then hit nearer caches (+3 % at
+ * C3, +30 % at C5).  Bit 3 (+8): EXPERIMENT -- rows wider than 256 floats take k_spmm_patch, which stages the neighbour UNION of 32
+ * consecutive rows in LDS once per 512-byte column tile and gathers from there (a block whose union does not fit is gathered
+ * directly: any row order gives the same result); measured slower than the gather kernel, kept for its test. */
 int cgc_spmm_graphs(const int* rowptr, const int* col, const int* perm, const float* val, const float* pre,
                     const float* post, const float* x, float* out, int n, int width, int ld /* row stride of x and out
                     (>= width): wide rows are kept at a multiple of 32 floats so that a 128-byte line never holds parts
@@ -413,6 +417,7 @@ typedef struct {          /* level 1: what graph.BatchGraph holds */
   const float* val; const float* t_val;   /* NULL without _re_norm_adj */
   const float* inv_d;
   const int* gorder;      /* NULL or the visiting sequence of cgc_spmm_graphs_ordered */
+  int spatial;            /* 1: every graph's nodes are listed grid cell by grid cell (cgc_spmm_graphs: visit bit 2) */
 } cgc_graph;
 
 typedef struct {          /* element offsets into the gradient buffer of cgc_level_bwd; -1 = absent */

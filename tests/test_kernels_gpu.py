@@ -192,6 +192,39 @@ def test_wide_spmm_visiting_sequences(visit):
     assert sorted(big.gorder.tolist()) == list(range(8)) and BatchGraph(n, counts, DEV).gorder is None
 
 
+@pytest.mark.parametrize('ordered', [True, False], ids=['grid-cell order', 'draw order'])
+@pytest.mark.parametrize('width,ld,weighted', [(1140, 1152, True), (1140, 1152, False), (300, 320, True), (512, 512, False)])
+def test_wide_spmm_with_neighbour_unions_in_lds(width, ld, weighted, ordered):
+    """visit bit 3 (cgc_spmm_graphs; an experiment, off in the product): k_spmm_patch stages the neighbour union of 32 consecutive
+    rows in LDS per 512-byte column tile (A S of _diff_pool, model/network.py:207, and its transpose in the backward).  Real cell
+    graphs (k-NN within 100 px) in grid-cell order take the staged path; the same graphs in DRAW order overflow the union budget and
+    every block falls back to direct gathers inside the same kernel: both must equal the reference aggregation, the forward graph and
+    its transpose, with and without edge weights / the post scale, and the padding columns stay untouched."""
+    from cgc_net_amd.data import Batch, SyntheticCellGraphs
+    from cgc_net_amd.graph import BatchGraph
+    ds = SyntheticCellGraphs(5, 700, 4, base_seed=31, spatial=ordered)
+    b = Batch.from_data_list([ds[i] for i in range(5)])
+    assert bool(getattr(b, '_spatial', False)) == ordered
+    gr = BatchGraph.from_batch(b.to(DEV), 0.4 if weighted else None)
+    n = gr.n
+    x = rnd(n, width, seed=3)
+    post = rnd(n, seed=4).abs() + 0.5
+    xb = torch.full((n, ld), 7.0, device=DEV)
+    xb[:, :width] = g(x)
+    for rowptr, col, val, pst in ((gr.rowptr, gr.col, gr.val, None), (gr.t_rowptr, gr.t_col, gr.t_val, g(post))):
+        want = torch.zeros(n, width)
+        REF.spmm(rowptr.cpu(), col.cpu(), None, None if val is None else val.cpu(), None, None if pst is None else pst.cpu(), x, want, n, width)
+        outs = []
+        for visit in (1 | 4 | 8, 1 | (4 if ordered else 0)):      # staged unions / the gather kernel (with the order hint)
+            ob = torch.full((n, ld), -3.0, device=DEV)
+            hip().spmm(rowptr, col, None, val, None, pst, xb[:, :width], ob[:, :width], n, width, gr.gptr, gr.B, gr.nmax, visit, ld)
+            close(ob[:, :width], want, what='patch spmm visit %d' % visit)
+            assert bool((ob[:, width:] == -3.0).all())
+            outs.append(ob)
+        # same neighbours, same order of summation inside a row: the two kernels agree to the last bit
+        assert torch.equal(outs[0], outs[1])
+
+
 GEMM_CASES = [
     # (M, N, K, tA, tB)
     (300, 200, 150, False, False), (129, 257, 33, False, True), (260, 140, 1000, True, False),
