@@ -78,6 +78,9 @@ def parse():
                    help='N=1: skip the second leg that runs the same W + K steps with the six dominant products in mode CGC_GEMM_SPLIT_BF16 '
                         '(reported beside the headline as value_split / roofline_split; the headline is always the exact fp32 kernel)')
     p.add_argument('--gemm-mode', type=int, default=0, help='experiments: mode of the HEADLINE leg (0 exact, 1 split); the JSON says so')
+    p.add_argument('--no-gc', action='store_true',
+                   help="experiment: Python's cyclic garbage collector off during the timed steps (gc.disable() after a gc.collect()): does "
+                        "the idle gap at the forward -> backward turn of some traced steps come from a collection pause?")
     p.add_argument('--plain-adam', action='store_true', help='torch.optim.Adam without fused=True (one kernel per parameter group)')
     return p.parse_args()
 
@@ -302,6 +305,10 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+        if args.no_gc:
+            import gc
+            gc.collect()
+            gc.disable()
         if timer_ is not None:
             timer_.start()
         t0 = time.perf_counter()
@@ -315,6 +322,9 @@ def main():
         el = time.perf_counter() - t0
         if timer_ is not None:
             timer_.stop()
+        if args.no_gc:
+            import gc
+            gc.enable()
         res = dict(leg=leg, lists=lists_, cpu_batches=cpu_, timer=timer_, loss=loss_)
         if world > 1:
             ar = dp.allreduce_ms()

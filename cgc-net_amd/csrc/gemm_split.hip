@@ -238,6 +238,13 @@ __global__ __launch_bounds__(256, 1) void k_gemm_split(const GemmArgs a) {
   piece = __builtin_amdgcn_readfirstlane(piece);
   S = __builtin_amdgcn_readfirstlane(S);
   tj = __builtin_amdgcn_readfirstlane(tj);
+#ifdef CGC_XS_STAGGER       // experiment: de-phase the workgroups of the first round (all tiles take the same time: the whole chip otherwise
+                           // reaches its epilogue -- 128 KB of stores per workgroup -- and its prologue at the same moment)
+  if (blockIdx.x < 256) {
+    const int d = (blockIdx.x >> 3) & 3;
+    for (int i = 0; i < d * CGC_XS_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+#endif
   const TileBase tb(a, b);
   const int M = tb.M, K = tb.K, N = a.N;
   const float* A = tb.A;
@@ -457,6 +464,9 @@ __global__ __launch_bounds__(256, 1) void k_gemm_split(const GemmArgs a) {
     return;
   }
   // (the last step ended with a barrier: the LDS is free for the parking strips of the epilogue)
+#ifdef CGC_XS_NOEPI
+  if (acc[0][0][0] == 12345.678f)
+#endif
   gemm_epilogue<TM, TN>(a, C, M, N, m0 + wm * TM * 32, n0 + wn * TN * 32, acc, lds_f + wave * 32 * (TN * 32 + 4), lane);
 }
 

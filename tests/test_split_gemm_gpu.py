@@ -3,8 +3,9 @@ pairs) in every form the step's dominant products take -- the assignment Linear 
 (model/network.py:121-122, 206-207) -- against float64, NEXT TO the exact fp32 kernel on the same inputs.
 
 Yardstick: error of an output element relative to sum_k |a_ik| |b_kj| (the quantity fp32 rounding scales with).  Bars: maximum and
-rms of the split mode <= 1.25 x those of the exact kernel (+ 2e-9), on N(0, 1) inputs, on inputs whose rows carry scales from 2^-30
-to 2^+30, and on inputs near the bottom of the exponent range (2^-100)."""
+rms of the split mode <= 1.25 x those of the exact kernel (+ 2e-9), on N(0, 1) inputs, on inputs whose output rows / columns carry
+scales from 2^-30 to 2^+30, and on inputs near the bottom of the exponent range (2^-100); a fourth input family puts the scales along
+K (see check())."""
 import os
 
 import numpy as np
@@ -35,12 +36,17 @@ def big_route():
     k.lib.cgc_gemm_tuning(old)
 
 
-def gen(shape, seed, kind):
+def gen(shape, seed, kind, mn=-2):
+    """``mn``: the axis of this operand that is an OUTPUT index (a row of op(A), a column of op(B)); the other matrix axis is k."""
     g = torch.Generator(device='cpu').manual_seed(seed)
     x = torch.randn(*shape, generator=g)
-    if kind == 'wide':                       # every row its own scale, 2^-30 .. 2^+30
-        e = torch.randint(-30, 31, shape[:-1] + (1,), generator=g).float()
-        x = x * torch.exp2(e)
+    if kind in ('wide', 'skewk') and len(shape) >= 2:
+        # wide: every output row / column its own scale, 2^-30 .. 2^+30.  skewk: the scales run along K instead -- in both operands, so
+        # the terms of every sum span 2^+-60 and one or two of them ARE the sum
+        ax = (mn if kind == 'wide' else (-1 if mn == -2 else -2)) % len(shape)
+        sh = [1] * len(shape)
+        sh[ax] = shape[ax]
+        x = x * torch.exp2(torch.randint(-30, 31, sh, generator=g).float())
     elif kind == 'tiny':                     # near the bottom of the exponent range: the lo plane is still a normal bf16
         x = x * 2.0 ** -100
     return x.to(DEV)
@@ -67,11 +73,15 @@ def both_modes(run, want, mag):
 
 
 def check(res, what, outputs):
-    """rms: 1.25 x the exact kernel's on every case.  max: 1.25 x where it is a stable statistic (>= 10^6 outputs); on the small shapes
-    (tens of thousands of outputs, heavy-tailed on the wide-range inputs) the maximum of either kernel moves by tens of per cent with
-    the seed: 2 x.  (Where ONE k term dominates a sum -- the wide-range inputs scale the rows of a [K, N] operand, i.e. the k index --
-    the split product carries the rounding of its hh pair plus the dropped pairs' 2^-26: by construction up to 1.25 x the single
-    rounding of an fma; measured rms ratios 1.11-1.22 there, 0.99-1.01 everywhere else.)"""
+    """rms: 1.25 x the exact kernel's.  max: 1.25 x where it is a stable statistic (>= 10^6 outputs); on the small shapes (tens of
+    thousands of outputs) the maximum of either kernel moves by tens of per cent with the seed: 2 x.
+    The 'skewk' inputs (scales of 2^+-30 along K in BOTH operands: one or two terms of 2^+-60 ARE the sum) are where the two kernels
+    differ by construction.  v_mfma_f32_32x32x2_f32 is bitwise an fmaf chain: the dominant product is rounded once.  The six bf16 pairs
+    deliver it as hh + (hm + mh) + ... through v_mfma_f32_32x32x16_bf16, which adds sixteen products and the accumulator with its own
+    internal roundings (not one), minus the dropped pairs' 2^-26.  Measured there: rms 1.07 - 1.28 x the exact kernel's (1.41 x on a
+    33 k-output product), max 0.98 - 1.33 x (2.6 x on that small sample); both kernels stay below 1.2e-6 of sum |a||b| (the exact
+    kernel itself reaches 1.1e-6 on these inputs).  Bars for this family: rms 1.5 x, max 1.5 x (3 x on the small shapes), 2e-6 absolute.
+    On every other input -- the ones the 1.25 x bars are for -- the measured ratios are 0.80 - 1.01."""
     (em, er), (sm, sr) = res[EXACT], res[SPLIT]
     line = '%s: exact max %.2e rms %.2e | split max %.2e rms %.2e  (ratios %.2f / %.2f)' % (what, em, er, sm, sr, sm / max(em, 1e-30), sr / max(er, 1e-30))
     print(line)
@@ -79,12 +89,14 @@ def check(res, what, outputs):
     if path:
         with open(path, 'a') as fh:
             fh.write(line + '\n')
-    assert sr <= 1.25 * er + 2e-9, (what, res)
-    assert sm <= (1.25 if outputs >= 1000000 else 2.0) * em + 2e-9, (what, res)
-    assert sm < 1e-6                                              # and absolutely: fp32-grade
+    skew = what.endswith('skewk')
+    big = outputs >= 1000000
+    assert sr <= (1.5 if skew else 1.25) * er + 2e-9, (what, res)
+    assert sm <= ((1.5 if big else 3.0) if skew else (1.25 if big else 2.0)) * em + 2e-9, (what, res)
+    assert sm < (2e-6 if skew else 1e-6)                          # and absolutely: fp32-grade
 
 
-KINDS = ['normal', 'wide', 'tiny']
+KINDS = ['normal', 'wide', 'skewk', 'tiny']
 
 
 @pytest.mark.parametrize('kind', KINDS)
@@ -96,8 +108,8 @@ def test_split_gemm_flat(M, N, K, tA, tB, kind):
     k = hip()
     up4 = lambda v: (v + 3) // 4 * 4
     lda, ldb = up4(M if tA else K) + 4, up4(K if tB else N) + 4
-    A = gen((K, lda) if tA else (M, lda), 1, kind)
-    B = gen((N, ldb) if tB else (K, ldb), 2, 'normal' if kind == 'tiny' else kind)
+    A = gen((K, lda) if tA else (M, lda), 1, kind, -1 if tA else -2)
+    B = gen((N, ldb) if tB else (K, ldb), 2, 'normal' if kind == 'tiny' else kind, -2 if tB else -1)
     bias, C0 = gen((N,), 3, 'normal'), gen((M, N), 4, 'normal')
     a = (A[:, :M].t() if tA else A[:, :K]).double()
     b = (B[:, :K].t() if tB else B[:, :N]).double()
@@ -122,9 +134,9 @@ def test_split_gemm_ragged_m_with_extra_segment(tB, xk, beta, kind):
     n, nmax, batch, N, K = sum(counts), max(counts), len(counts), 1140, 1140
     gptr = torch.tensor(np.cumsum([0] + counts), dtype=torch.int32, device=DEV)
     S = gen((n, K), 1, kind)
-    G = gen((batch, N, K) if tB else (batch, K, N), 2, 'normal' if kind == 'tiny' else kind)
+    G = gen((batch, N, K) if tB else (batch, K, N), 2, 'normal' if kind == 'tiny' else kind, -2 if tB else -1)
     X = gen((n, max(xk, 4)), 5, kind)
-    H = gen((batch, N, max(xk, 4)) if tB else (batch, max(xk, 4), N), 6, 'normal' if kind == 'tiny' else kind)
+    H = gen((batch, N, max(xk, 4)) if tB else (batch, max(xk, 4), N), 6, 'normal' if kind == 'tiny' else kind, -2 if tB else -1)
     C0 = gen((n, N), 3, 'normal')
     gp = gptr.cpu().tolist()
     op = lambda t: t.double().t() if tB else t.double()
@@ -154,9 +166,9 @@ def test_split_gemm_flat_with_two_extra_segments(kind):
     k = hip()
     M, N = 2100, 1140
     for K0 in (1140, 20):
-        A, B = gen((M, K0), 1, kind), gen((K0, N), 2, 'normal' if kind == 'tiny' else kind)
-        X1, H1 = gen((M, 20), 3, kind), gen((20, N), 4, 'normal' if kind == 'tiny' else kind)
-        X2, H2 = gen((M, 24), 5, kind), gen((24, N), 6, 'normal' if kind == 'tiny' else kind)
+        A, B = gen((M, K0), 1, kind), gen((K0, N), 2, 'normal' if kind == 'tiny' else kind, -1)
+        X1, H1 = gen((M, 20), 3, kind), gen((20, N), 4, 'normal' if kind == 'tiny' else kind, -1)
+        X2, H2 = gen((M, 24), 5, kind), gen((24, N), 6, 'normal' if kind == 'tiny' else kind, -1)
         bias = gen((N,), 7, 'normal') * (2.0 ** -100 if kind == 'tiny' else 1.0)
         want = A.double() @ B.double() + X1.double() @ H1.double() + X2.double() @ H2.double() + bias.double()
         mag = A.double().abs() @ B.double().abs() + X1.double().abs() @ H1.double().abs() + X2.double().abs() @ H2.double().abs() + bias.double().abs()
@@ -175,7 +187,7 @@ def test_split_gemm_ragged_k(counts, kind):
     k = hip()
     n, nmax, batch, C = sum(counts), max(counts), len(counts), 1140
     gptr = torch.tensor(np.cumsum([0] + counts), dtype=torch.int32, device=DEV)
-    S, P = gen((n, C), 1, kind), gen((n, C), 2, 'normal' if kind == 'tiny' else kind)
+    S, P = gen((n, C), 1, kind, -1), gen((n, C), 2, 'normal' if kind == 'tiny' else kind, -1)
     gp = gptr.cpu().tolist()
     want = torch.stack([S[gp[b]:gp[b + 1]].double().t() @ P[gp[b]:gp[b + 1]].double() for b in range(batch)])
     mag = torch.stack([S[gp[b]:gp[b + 1]].double().abs().t() @ P[gp[b]:gp[b + 1]].double().abs() for b in range(batch)])
@@ -195,7 +207,7 @@ def test_split_gemm_uniform_k_chunks(kind):
     k = hip()
     M, N, Kd, chunk = 1140, 1140, 9000, 2080
     parts = -(-Kd // chunk)
-    A, B = gen((Kd, M), 1, kind), gen((Kd, N), 2, 'normal' if kind == 'tiny' else kind)
+    A, B = gen((Kd, M), 1, kind, -1), gen((Kd, N), 2, 'normal' if kind == 'tiny' else kind, -1)
     want = A.double().t() @ B.double()
     mag = A.double().abs().t() @ B.double().abs()
 
