@@ -450,11 +450,12 @@ def main():
                 gemm, _ = rooflines(r['timer'])
                 if gemm is not None:
                     tf = gemm['achieved']
+                    # the roofline of THIS kernel is the bf16 matrix pipe: it issues six bf16 products per fp32 product
                     out['roofline_split'] = dict({'kernel': SPLIT_KERNEL}, **gemm)
                     out['roofline_split'].update({
-                        'achieved_is': 'fp32-equivalent TFLOP/s: 2MNK of the fp32 product / launch duration (the kernel issues 6 x that on the bf16 pipe)',
-                        'frac_is': 'achieved / the fp32 MFMA peak (157.3): a speed-up figure, not a utilisation -- see bf16_pipe_frac',
-                        'bf16_pipe_frac': round(6.0 * tf / 2500.0, 4), 'bf16_pipe_peak': 2500.0,
+                        'achieved': round(6.0 * tf, 1), 'peak': 2500.0, 'frac': round(6.0 * tf / 2500.0, 4),
+                        'achieved_is': 'bf16 TFLOP/s issued: 6 pairs x 2MNK of the fp32 product / launch duration, against the dense bf16 MFMA peak',
+                        'fp32_equivalent_tflops': tf, 'fp32_equivalent_over_fp32_mfma_peak': round(tf / MFMA_F32_PEAK_TFLOPS, 4),
                         'error_table': 'profiles/r05_split_gemm_error_table.txt (max / rms error vs float64 next to the exact kernel, every form)'})
         # HBM traffic per launch and counter-derived matrix-core utilisation: from the committed PMC passes of this same command
         # (profiles/make_traffic_json.py, profiles/make_counters_json.py) -- ONLY when they were taken on exactly this kernel source
@@ -472,7 +473,8 @@ def main():
                 except (OSError, ValueError):
                     continue
                 fresh = js.get('source_sha256') == src
-                for obj, tag in (('roofline', 'gemm_128x128'), ('roofline_aggregation', 'spmm_wide')):
+                for obj, tag in (('roofline', 'gemm_split' if args.gemm_mode == 1 else 'gemm_128x128'), ('roofline_aggregation', 'spmm_wide'),
+                                 ('roofline_split', 'gemm_split')):
                     if obj not in out or tag not in js:
                         continue
                     if key == 'traffic':
@@ -481,7 +483,7 @@ def main():
                             out[obj]['traffic_source'] = 'profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes/launch; same kernel source)' % fname
                         else:
                             out[obj]['traffic_stale'] = True
-                    elif tag == 'gemm_128x128' and js[tag].get('mfma_busy') is not None:
+                    elif tag in ('gemm_128x128', 'gemm_split') and js[tag].get('mfma_busy') is not None:
                         if fresh:
                             out[obj]['mfma_busy_counter'] = js[tag]['mfma_busy']
                             out[obj]['mfma_busy_source'] = ('profiles/%s: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE/8) of this '

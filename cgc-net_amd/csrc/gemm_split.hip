@@ -344,8 +344,8 @@ __global__ __launch_bounds__(256, 1) void k_gemm_split(const GemmArgs a) {
       for (int h = 0; h < 2; ++h) frag_half(fr.b[j][p], h, slds + fb_off + j * 32 * SROW + p * S_PLB);
 
   // ---- one k-tile.  POS = local tile index mod 3 fixes the buffers: stage POS holds this tile, stage (POS + 1) % 3 the next one
-  // (being read), set / stage (POS + 2) % 3 the tile after that (being split) and then tile lt + 5 (requested).  FULL: tiles lt + 2 and
-  // lt + 5 are whole tiles of the main operand pair -- buffer loads, no masks, no conditional.  Otherwise the generic request / masked
+  // (being read), set / stage (POS + 2) % 3 the tile after that (being split) and then tile lt + 5 (requested).  FULL: tile lt + 2 is a
+  // whole tile of the main operand pair and tile lt + 5 is one too (or is never used) -- buffer loads, no masks, no conditional.  Otherwise the generic request / masked
   // split.  Past the end of the piece everything still runs, on clamped addresses, into buffers nobody multiplies: no conditional
   // there either.  48 MFMAs; behind MFMA m: ONE fragment half (m < 36... see the table), micro-step m of the split, at most one load.
   auto tile_step = [&](auto pos_c, auto full_c, int lt) {
@@ -367,8 +367,10 @@ __global__ __launch_bounds__(256, 1) void k_gemm_split(const GemmArgs a) {
       tnext = split_tile(seg, kbeg + (lt + 5 < n ? lt + 5 : n - 1));
     } else {
       tnext.A = A; tnext.B = B; tnext.lda = a.lda; tnext.ldb = a.ldb; tnext.klim = K; tnext.k0 = 0;
-      soffA = LoaderA::soffset(a.lda, (kbeg + lt + 5) * SBK);
-      soffB = LoaderB::soffset(a.ldb, (kbeg + lt + 5) * SBK);
+      // (a request past the last whole tile of the main pair re-reads that tile: valid memory, nobody splits it)
+      const int tl = min(kbeg + lt + 5, nk_full - 1);
+      soffA = LoaderA::soffset(a.lda, tl * SBK);
+      soffB = LoaderB::soffset(a.ldb, tl * SBK);
     }
     // pair order: (A plane, B plane) = lh, mm, mh, hl, hm, hh
     constexpr int PA_[6] = {2, 1, 1, 0, 0, 0}, PB_[6] = {0, 1, 0, 2, 1, 0};
@@ -434,8 +436,11 @@ __global__ __launch_bounds__(256, 1) void k_gemm_split(const GemmArgs a) {
   typedef std::false_type ANY_;
 #define SPLIT_POS(P_) std::integral_constant<int, P_>()
   int lt = 0;
-  // steps whose tiles lt + 2 and lt + 5 are whole main-pair tiles
-  const int full_steps = min(nk_full - 5 - kbeg, n);            // (never past the end of the piece: the next piece's tiles are not ours)
+  // steps whose tile lt + 2 (the one being split) is a whole tile of the main pair and whose request (tile lt + 5) is either such a tile
+  // too or not needed at all: past the end of the piece / of the main pair's whole tiles the request is clamped (see tile_step) -- what
+  // follows the main pair (a partial tile, the extra segments) is requested by the generic steps, which start three tiles before it
+  const int last_special = nk - nk_full;                          // tiles of this product that are not whole main-pair tiles
+  const int full_steps = min(last_special > 0 && kend > nk_full ? nk_full - 5 - kbeg : nk_full - 2 - kbeg, n);
   for (; lt + 3 <= full_steps; lt += 3) {
     tile_step(SPLIT_POS(0), FULL_(), lt);
     tile_step(SPLIT_POS(1), FULL_(), lt + 1);

@@ -18,7 +18,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import source_hash  # noqa: E402  (the kernel sources these counters were measured on: bench.py quotes them only for the same hash)
 
 vals = collections.defaultdict(dict)
-for line in open(sys.argv[1]):
+lines = [l for f in sys.argv[1:] for l in open(f)]          # (round 5: a second file = the pass with the split-mode GEMM)
+for line in lines:
     parts = line.split()
     if len(parts) < 5 or parts[0] == 'kernel':
         continue
@@ -43,5 +44,22 @@ for k, c in vals.items():
     tot_cyc += 1024.0 * cyc * calls
 out['gemm_128x128'] = {'mfma_busy': round(tot_busy / tot_cyc, 4) if tot_cyc else None,
                        'definition': 'SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE / 8), launch-weighted over the three instantiations'}
+# the split-mode kernel (csrc/gemm_split.hip): the same ratio (32 busy cycles per v_mfma_f32_32x32x16_bf16)
+sb = sc = 0.0
+for k, c in vals.items():
+    if not k.startswith('k_gemm_split<') or 'SQ_VALU_MFMA_BUSY_CYCLES' not in c or 'GRBM_GUI_ACTIVE' not in c:
+        continue
+    calls, busy = c['SQ_VALU_MFMA_BUSY_CYCLES']
+    cyc = c['GRBM_GUI_ACTIVE'][1] / 8.0
+    wave = c.get('SQ_WAVE_CYCLES', (0, 0.0))[1]
+    out[k] = {'launches_profiled': calls, 'mfma_busy': round(busy / (1024.0 * cyc), 4), 'kernel_cycles': round(cyc),
+              'wave_wait_any_frac': round(c.get('SQ_WAIT_ANY', (0, 0.0))[1] / wave, 4) if wave else None,
+              'wave_wait_inst_frac': round(c.get('SQ_WAIT_INST_ANY', (0, 0.0))[1] / wave, 4) if wave else None,
+              'lds_bank_conflict_cycles': c.get('SQ_LDS_BANK_CONFLICT', (0, 0.0))[1]}
+    sb += busy * calls
+    sc += 1024.0 * cyc * calls
+if sc:
+    out['gemm_split'] = {'mfma_busy': round(sb / sc, 4),
+                         'definition': 'SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE / 8) over the launches of k_gemm_split<*> (bf16 matrix pipe)'}
 out['source_sha256'] = source_hash()
 print(json.dumps(out, indent=1))

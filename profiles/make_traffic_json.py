@@ -23,8 +23,13 @@ def per_kernel(d, counter):
 
 def main():
     f, w = per_kernel(sys.argv[1], 'FETCH_SIZE'), per_kernel(sys.argv[2], 'WRITE_SIZE')
+    if len(sys.argv) > 4:          # (round 5: a second pair of passes = the same command with the split-mode GEMM)
+        f2, w2 = per_kernel(sys.argv[3], 'FETCH_SIZE'), per_kernel(sys.argv[4], 'WRITE_SIZE')
+        f.update({k: v for k, v in f2.items() if k.startswith('k_gemm_split<')})
+        w.update({k: v for k, v in w2.items() if k.startswith('k_gemm_split<')})
     out = {}
-    for tag, match, big_only in (('gemm_128x128', 'k_gemm_f32<2, 2, 2, 2', False), ('spmm_wide', 'k_spmm_wide<', True)):
+    for tag, match, big_only in (('gemm_128x128', 'k_gemm_f32<2, 2, 2, 2', False), ('spmm_wide', 'k_spmm_wide<', True),
+                                 ('gemm_split', 'k_gemm_split<', False)):
         fs = [v for k in f if k.startswith(match) for v in f[k]]
         ws = [v for k in w if k.startswith(match) for v in w[k]]
         if big_only:      # the wide (cluster-count) launches are the ones moving > 100 MB
