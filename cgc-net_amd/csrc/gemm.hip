@@ -360,6 +360,14 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const GemmArgs a) {   // 2 
       if (kt + 2 < kend) fetch(ll_a, ll_b, kt + 2);
       has_next = kt + 1 < kend;
     }
+    // k groups (of 8) of THIS tile that hold anything: a partial last tile / a short extra segment is zero past its end, and a group
+    // of zeros is 16 MFMAs per wave that add nothing (K = 1140 = 35 x 32 + 20: one group; + 40: three more; + 20: one more)
+    int nkb = BK / 8;
+    if constexpr (MODE != PH_FULL) {
+      const int kx = kt - nk_main;
+      const int left = kx < 0 ? K - kt * BK : kx < nkx0 ? a.xK[0] - kx * BK : a.xK[1] - (kx - nkx0) * BK;
+      nkb = left >= BK ? BK / 8 : (left + 7) >> 3;
+    }
     const float* as = As0 + cur * A_SZ + (TA ? wm * TM * 32 : wm * TM * 32 * KC_LD);
     const float* bs = Bs0 + cur * B_SZ + (TB ? wn * TN * 32 * KC_LD : wn * TN * 32);
     float* an = As0 + (cur ^ 1) * A_SZ;
@@ -408,6 +416,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const GemmArgs a) {   // 2 
         continue;
       }
 #endif
+      if (MODE == PH_FULL || kb < nkb) {
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -415,6 +424,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const GemmArgs a) {   // 2 
 #pragma unroll
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[kb & 1][j][t], av[kb & 1][i][t], acc[i][j], 0, 0, 0);   // C^T tile: see gemm_epilogue
+      }
 #ifdef CGC_X_NOWRITE
       if (MODE != PH_FULL && has_next) {
 #else
@@ -576,19 +586,22 @@ __global__ __launch_bounds__(256, 3) void k_gemm_f32_shortk(const GemmArgs a) {
     __syncthreads();
     const float* as = As0 + (TA ? wm * TM * 32 : wm * TM * 32 * KC_LD);
     const float* bs = Bs0 + (TB ? wn * TN * 32 * KC_LD : wn * TN * 32);
+    const int left = K - kt * BK, nkb = left >= BK ? BK / 8 : (left + 7) >> 3;     // (k groups of 8 past the end of K hold zeros: skipped)
 #pragma unroll
     for (int kb = 0; kb < BK / 8; ++kb) {
-      float av[TM][4], bv[TN][4];
+      if (kb < nkb) {                     // (uniform; a `break` here keeps the loop from being unrolled)
+        float av[TM][4], bv[TN][4];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) fetch_frag<TA, LDA_S>(as + (TA ? i * 32 : i * 32 * KC_LD), kb, l31, lhi, av[i]);
+        for (int i = 0; i < TM; ++i) fetch_frag<TA, LDA_S>(as + (TA ? i * 32 : i * 32 * KC_LD), kb, l31, lhi, av[i]);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) fetch_frag<!TB, LDB_S>(bs + (TB ? j * 32 * KC_LD : j * 32), kb, l31, lhi, bv[j]);
+        for (int j = 0; j < TN; ++j) fetch_frag<!TB, LDB_S>(bs + (TB ? j * 32 * KC_LD : j * 32), kb, l31, lhi, bv[j]);
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+          for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[j][t], av[i][t], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[j][t], av[i][t], acc[i][j], 0, 0, 0);
+      }
     }
   }
 
