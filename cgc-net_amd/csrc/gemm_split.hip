@@ -18,16 +18,19 @@
 //
 // Structure (one workgroup per CU: 256 threads = 4 waves, one per SIMD, 512 registers each):
 //   tile 256 x 128, wave tile 128 x 64 (4 x 2 accumulators of 32 x 32), k-tiles of 16;
-//   LDS: three stages of [3 planes][256 + 128 rows][16 k bf16] (rows of 32 B on a 40 B stride: the two ds_read_b64 of a fragment and
-//   the 8-byte writes of both operand orientations are bank-conflict free), 135 KB;
-//   global -> registers three k-tiles ahead of the split (buffer loads, no vector address arithmetic in the loop), split in registers
-//   -> LDS two k-tiles ahead of the MFMAs, fragments read one k-tile ahead into a second register set: a wave never waits for LDS or
-//   memory inside a k-tile, and there is ONE barrier per k-tile;
+//   LDS: two stages of [3 planes][256 + 128 rows][16 k bf16], rows of 32 B on a 48 B stride (108 KB): a fragment is ONE ds_read_b128
+//   (conflict-free: 3 is coprime with the 16 sixteen-byte slots of a bank row), and the 8-byte writes of a k-contiguous operand tile
+//   the bank window exactly;
+//   global -> registers two k-tiles ahead of the split (two register sets; buffer loads, no vector address arithmetic in the loop),
+//   split in registers -> LDS two k-tiles ahead of the MFMAs, fragments read one k-tile ahead, plane by plane into the registers the
+//   pair order frees (SplitFrags below): a wave never waits for LDS or memory inside a k-tile, and there is ONE barrier per k-tile;
 //   an operand whose k index is the memory row (A stored [K, M], B stored [K, N]) is transposed in registers for free: a thread loads a
 //   4 (k) x 4 (m) block -- 2 x 4 for the 128-wide operand -- and packs along k;
 //   the ~130 vector instructions of a k-tile's split are dealt out by hand behind its 48 MFMAs (one micro-step of 2-4 instructions per
 //   MFMA, a scheduling fence after each): behind a bf16 MFMA up to ~5 plain vector instructions of the SAME wave issue for free
-//   (tools/pipe_overlap_probe.hip), another wave's do not.
+//   (tools/pipe_overlap_probe.hip), another wave's do not.  What costs is every LDS instruction (~6 cycles of issue) and every
+//   buffer load (~27): 36 + 6 per k-tile here (the first version of this kernel: 54 + 6 with 8-byte fragment reads on 40-byte rows and
+//   three stages -- 2 % slower).
 #include <type_traits>
 
 #include "gemm_common.hpp"
@@ -38,10 +41,8 @@ typedef float float2v __attribute__((ext_vector_type(2)));
 typedef unsigned uint4v __attribute__((ext_vector_type(4)));
 
 #define SBK 16                          // k-tile
-#define SROW 40                         // bytes per LDS row of a plane: 16 bf16 + 8 bytes of padding
+#define SROW 48                         // bytes per LDS row of a plane: 16 bf16 + 16 bytes of padding (16-byte-aligned rows for ds_read_b128)
 constexpr int S_BM = 256, S_BN = 128;
-constexpr int S_PLA = S_BM * SROW, S_PLB = S_BN * SROW, S_STAGE = 3 * S_PLA + 3 * S_PLB, S_NSTAGE = 3;
-constexpr int S_LDS = S_NSTAGE * S_STAGE;       // 138240 bytes
 
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {      // v_cvt_pk_bf16_f32: round to nearest even, a in the low half
   float2v t;
@@ -57,15 +58,17 @@ __device__ __forceinline__ float comp(const float4& v, int e) { return e == 0 ? 
 
 // Operand whose K index is the contiguous one in memory (A stored [M, K]; B stored [N, K]).  ROWS x 16 tile = ROWS * 4 units of
 // 16 bytes; thread t: unit q = t & 3 of rows row_of(i), i = 0 .. ROWS / 64 - 1.  A unit is one "group": four consecutive k of one row.
-template <int ROWS>
+template <int ROWS, int RS = SROW>
 struct SplitLoaderK {
   static constexpr int NF = ROWS / 64, NG = NF;
-  // row of unit i: 64 i + 16 wave + ((t >> 4) & 3) + 4 ((t >> 2) & 3) -- the 16 lanes of an LDS write group (8-byte writes) hold rows
-  // b, b + 4, b + 8, b + 12: on the 40-byte row stride their 32-byte windows start 160 = 32 (mod 128) bytes apart and tile the
-  // 128-byte bank window exactly (rows b .. b + 3 overlap: 25 % of the LDS cycles of the first version were bank conflicts)
+  // row of unit i: 64 i + 16 wave + r16 with r16 = ((t >> 4) & 1) + 8 ((t >> 5) & 1) + 2 ((t >> 2) & 3): the 16 lanes of an LDS write group
+  // (8-byte writes) hold rows b, b + 2, b + 4, b + 6 -- on the 48-byte row stride their 32-byte windows start 96 = -32 (mod 128) bytes
+  // apart and tile the 128-byte bank window exactly (consecutive rows overlap: a quarter of the LDS cycles of the first version of
+  // this kernel were bank conflicts)
   static __device__ __forceinline__ int row_of(int i) {
     const int t = (int)threadIdx.x;
-    return 64 * i + 16 * (t >> 6) + ((t >> 4) & 3) + 4 * ((t >> 2) & 3);
+    static_assert(RS == 48, "the row mapping tiles the bank window for 48-byte rows");
+    return 64 * i + 16 * (t >> 6) + ((t >> 4) & 1) + 8 * ((t >> 5) & 1) + 2 * ((t >> 2) & 3);
   }
   static __device__ __forceinline__ void offsets(unsigned (&off)[NF], int ld, int row0, int row_last) {
 #pragma unroll
@@ -82,18 +85,19 @@ struct SplitLoaderK {
     x[0] = reg[u].x; x[1] = reg[u].y; x[2] = reg[u].z; x[3] = reg[u].w;
   }
   static __device__ __forceinline__ int kof(int /*u*/, int e) { return (int)(threadIdx.x & 3) * 4 + e; }      // k of element e inside the tile
-  static __device__ __forceinline__ unsigned wbase() { return (unsigned)row_of(0) * SROW + (threadIdx.x & 3u) * 8u; }
+  static __device__ __forceinline__ unsigned wbase() { return (unsigned)row_of(0) * RS + (threadIdx.x & 3u) * 8u; }
   static __device__ __forceinline__ void put(unsigned char* st, int u, int plane_off, unsigned w0, unsigned w1) {   // st = stage + region + wbase()
-    *reinterpret_cast<uint2*>(st + u * 64 * SROW + plane_off) = make_uint2(w0, w1);
+    *reinterpret_cast<uint2*>(st + u * 64 * RS + plane_off) = make_uint2(w0, w1);
   }
 };
 
 // Operand whose M / N index is the contiguous one (A stored [K, M]; B stored [K, N]).  16 x COLS tile; a thread owns a KH x 4 block
 // (KH = 4 for the 256-wide operand, 2 for the 128-wide one): lane -> (kgrp = t % (16 / KH), g = t / (16 / KH)); float4 j of the block is
 // row k = KH * kgrp + j, columns 4 g .. 4 g + 3.  The 16 lanes of an LDS write group then cover 4 column groups x 4 k groups (KH = 4:
-// 8-byte writes) or the 32 lanes 4 x 8 (KH = 2: 4-byte writes): distinct banks.  Groups: KH = 4: column c of the block (its four k);
-// KH = 2: columns 2u, 2u + 1 (two k each).  The transposition is a choice of register names.
-template <int COLS>
+// 8-byte writes) or the 32 lanes 4 x 8 (KH = 2: 4-byte writes): at most two lanes per bank on the 48-byte stride (free for 4-byte writes).
+// Groups: KH = 4: column c of the block (its four k); KH = 2: columns 2u, 2u + 1 (two k each).  The transposition is a choice of
+// register names.
+template <int COLS, int RS = SROW>
 struct SplitLoaderMN {
   static constexpr int KH = COLS / 64, NF = KH, NG = KH == 4 ? 4 : 2, KG = 16 / KH;
   static __device__ __forceinline__ int kgrp() { return (int)threadIdx.x % KG; }
@@ -117,13 +121,13 @@ struct SplitLoaderMN {
     }
   }
   static __device__ __forceinline__ int kof(int /*u*/, int e) { return KH == 4 ? 4 * kgrp() + e : 2 * kgrp() + (e & 1); }
-  static __device__ __forceinline__ unsigned wbase() { return (unsigned)g() * 4u * SROW + (unsigned)kgrp() * (KH == 4 ? 8u : 4u); }
+  static __device__ __forceinline__ unsigned wbase() { return (unsigned)g() * 4u * RS + (unsigned)kgrp() * (KH == 4 ? 8u : 4u); }
   static __device__ __forceinline__ void put(unsigned char* st, int u, int plane_off, unsigned w0, unsigned w1) {
     if constexpr (KH == 4) {
-      *reinterpret_cast<uint2*>(st + u * SROW + plane_off) = make_uint2(w0, w1);
+      *reinterpret_cast<uint2*>(st + u * RS + plane_off) = make_uint2(w0, w1);
     } else {
-      *reinterpret_cast<unsigned*>(st + (2 * u) * SROW + plane_off) = w0;
-      *reinterpret_cast<unsigned*>(st + (2 * u + 1) * SROW + plane_off) = w1;
+      *reinterpret_cast<unsigned*>(st + (2 * u) * RS + plane_off) = w0;
+      *reinterpret_cast<unsigned*>(st + (2 * u + 1) * RS + plane_off) = w1;
     }
   }
 };
@@ -157,7 +161,7 @@ struct GroupState {
   float x[4], r1[4], r2[4];
   unsigned hp[2], mp[2], lp[2];
 };
-template <class LoaderA, class LoaderB, bool MASKED>
+template <class LoaderA, class LoaderB, bool MASKED, int PLA, int PLB>
 __device__ __forceinline__ void split_micro(int sidx, GroupState (&gs)[6], const float4 (&ra)[LoaderA::NF], const float4 (&rb)[LoaderB::NF],
                                             unsigned char* wa, unsigned char* wb, int k0, int klim) {
   const int u = sidx >> 3, st = sidx & 7;
@@ -194,32 +198,29 @@ __device__ __forceinline__ void split_micro(int sidx, GroupState (&gs)[6], const
   } else {
     if (u < 4) {
       LoaderA::put(wa, u, 0, s.hp[0], s.hp[1]);
-      LoaderA::put(wa, u, S_PLA, s.mp[0], s.mp[1]);
-      LoaderA::put(wa, u, 2 * S_PLA, s.lp[0], s.lp[1]);
+      LoaderA::put(wa, u, PLA, s.mp[0], s.mp[1]);
+      LoaderA::put(wa, u, 2 * PLA, s.lp[0], s.lp[1]);
     } else {
       LoaderB::put(wb, u - 4, 0, s.hp[0], s.hp[1]);
-      LoaderB::put(wb, u - 4, S_PLB, s.mp[0], s.mp[1]);
-      LoaderB::put(wb, u - 4, 2 * S_PLB, s.lp[0], s.lp[1]);
+      LoaderB::put(wb, u - 4, PLB, s.mp[0], s.mp[1]);
+      LoaderB::put(wb, u - 4, 2 * PLB, s.lp[0], s.lp[1]);
     }
   }
 }
 
-// One half (8 bytes = four k) of an operand fragment.  fa / fb: the lane's row of the stage's A / B region (+ 16 bytes for lanes 32-63).
-__device__ __forceinline__ void frag_half(uint4v& f, int h, const unsigned char* p) {
-  const uint2 v = *reinterpret_cast<const uint2*>(p + h * 8);
-  f[2 * h] = v.x;
-  f[2 * h + 1] = v.y;
-}
+// Fragment registers of a wave: one set (the k-tile being multiplied) + a second copy of the two hi planes.  The pair order of a
+// tile -- lh, mm, mh, hl, hm, hh -- retires the planes one after the other, and the NEXT tile's copy of a plane is read (16 bytes per
+// lane and sub-tile: 18 ds_read_b128 per k-tile) as soon as this tile's is dead: A.lo after pair 0, A.mid after pair 2, B.lo after pair
+// 3, B.mid after pair 4; A.hi and B.hi live to the end, so the next tile's go into the second copies (24 registers) during pair 0.
+// 96 fragment registers instead of the 144 of a full double buffer -- with two register sets of raw operands (48) and the split's
+// temporaries everything but the accumulators has to fit 256 architectural registers (a full double buffer spilled 1194).
+// No fragment of the tile being multiplied is read from LDS any more, so its stage is free for the tile after next: TWO stages.
+constexpr int S_PLA = S_BM * SROW, S_PLB = S_BN * SROW, S_STAGE = 3 * S_PLA + 3 * S_PLB, S_LDS = 2 * S_STAGE;   // 110592 bytes
 
-// Fragment registers of a wave: one set (the k-tile being multiplied) + a second copy of B's hi plane only.  The pair order of a tile
-// -- lh, mm, mh, hl, hm, hh -- retires the planes one after the other, and the NEXT tile's copy of a plane is read (from the next
-// stage) as soon as this tile's is dead: A.lo after pair 0, A.mid after pair 2, B.lo after pair 3, B.mid after pair 4; A.hi and B.hi
-// live to the end -- the next tile's A.hi is read during ITS pairs 0-2 (which do not use it), the next tile's B.hi into the second copy.
-// 80 registers instead of the 144 of a full double buffer: with the three register sets of raw operands in flight (72) the kernel
-// otherwise does not fit the 256 architectural registers that everything but the accumulators has to share.
 struct SplitFrags {
-  uint4v a[4][3], b[2][3], b0n[2];
+  uint4v a[4][3], b[2][3], a0n[4], b0n[2];
 };
+__device__ __forceinline__ uint4v frag16(const unsigned char* p) { return *reinterpret_cast<const uint4v*>(p); }
 
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256, 1) void k_gemm_split(const GemmArgs a) {
@@ -238,13 +239,6 @@ __global__ __launch_bounds__(256, 1) void k_gemm_split(const GemmArgs a) {
   piece = __builtin_amdgcn_readfirstlane(piece);
   S = __builtin_amdgcn_readfirstlane(S);
   tj = __builtin_amdgcn_readfirstlane(tj);
-#ifdef CGC_XS_STAGGER       // experiment: de-phase the workgroups of the first round (all tiles take the same time: the whole chip otherwise
-                           // reaches its epilogue -- 128 KB of stores per workgroup -- and its prologue at the same moment)
-  if (blockIdx.x < 256) {
-    const int d = (blockIdx.x >> 3) & 3;
-    for (int i = 0; i < d * CGC_XS_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
-  }
-#endif
   const TileBase tb(a, b);
   const int M = tb.M, K = tb.K, N = a.N;
   const float* A = tb.A;
@@ -254,11 +248,11 @@ __global__ __launch_bounds__(256, 1) void k_gemm_split(const GemmArgs a) {
   const int m0 = tile_m * S_BM, n0 = tile_n * S_BN;
   if (m0 >= M) return;
 
-  typedef typename std::conditional<TA, SplitLoaderMN<S_BM>, SplitLoaderK<S_BM>>::type LoaderA;
-  typedef typename std::conditional<TB, SplitLoaderK<S_BN>, SplitLoaderMN<S_BN>>::type LoaderB;
+  typedef typename std::conditional<TA, SplitLoaderMN<S_BM, SROW>, SplitLoaderK<S_BM, SROW>>::type LoaderA;
+  typedef typename std::conditional<TB, SplitLoaderK<S_BN, SROW>, SplitLoaderMN<S_BN, SROW>>::type LoaderB;
   static_assert(LoaderA::NG == 4 && LoaderB::NG == 2, "six groups of four values per thread and k-tile");
   constexpr int NFA = LoaderA::NF, NFB = LoaderB::NF;
-  float4 ra[3][NFA], rb[3][NFB];            // three register sets: tile t lives in set t % 3 from its request until its split
+  float4 ra[2][NFA], rb[2][NFB];            // two register sets: tile t lives in set t % 2 from its request until its split
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave / WGN, wn = wave - wm * WGN;
@@ -272,7 +266,6 @@ __global__ __launch_bounds__(256, 1) void k_gemm_split(const GemmArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // k-tiles: the main operand pair, then the extra segments
   const int nk_main = (K + SBK - 1) / SBK, nk_full = K / SBK;
   SplitSegs seg;
   seg.A0 = A; seg.B0 = B; seg.lda0 = a.lda; seg.ldb0 = a.ldb; seg.K0 = K;
@@ -296,8 +289,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_split(const GemmArgs a) {
   const int nk = nk_main + seg.nkx0 + nkx1;
   const int kbeg = S > 1 ? (int)(((long long)nk * piece) / S) : 0;
   const int kend = S > 1 ? (int)(((long long)nk * (piece + 1)) / S) : nk;
-  const int n = kend - kbeg;                 // this workgroup's k-tiles: local index 0 .. n - 1
-  // edges: rows / columns past the extent are clamped to the last valid one (they only reach outputs that are never stored)
+  const int n = kend - kbeg;
   const int a_last = TA ? ((M - 1) & ~3) : M - 1, b_last = TB ? N - 1 : ((N - 1) & ~3);
 
   unsigned offA[NFA], offB[NFB];
@@ -306,24 +298,23 @@ __global__ __launch_bounds__(256, 1) void k_gemm_split(const GemmArgs a) {
   const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, 0xffffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(B), 0, 0xffffffff, 0x00020000);
 
-  // LDS addresses: the lane's fragment rows (read) and the thread's units (write), relative to a stage
   const unsigned fa_off = (unsigned)(wm * 128 + l31) * SROW + lhi * 16, fb_off = 3 * S_PLA + (unsigned)(wn * 64 + l31) * SROW + lhi * 16;
   const unsigned wa_off = LoaderA::wbase(), wb_off = 3 * S_PLA + LoaderB::wbase();
 
   SplitFrags fr;
-  // ---- prologue: tiles 0, 1 split into stages 0, 1; tiles 2, 3, 4 in flight in the three sets; the fragments of tile 0 except A.hi
+  // ---- prologue: tiles 0, 1 split into stages 0, 1; tiles 2, 3 in flight in the two sets; all fragments of tile 0 in registers
 #pragma unroll
-  for (int q = 0; q < 5; ++q) {               // q: 0, 1, 2 request tiles 0, 1, 2; then split 0, request 3; split 1, request 4
-    const int lt = q, set = q % 3;
-    if (q >= 3) {
-      const SplitTile t = split_tile(seg, kbeg + (q - 3 < n ? q - 3 : n - 1));
+  for (int q = 0; q < 4; ++q) {               // q: 0, 1 request tiles 0, 1; 2: split 0, request 2; 3: split 1, request 3
+    const int set = q & 1;
+    if (q >= 2) {
+      const SplitTile t = split_tile(seg, kbeg + (q - 2 < n ? q - 2 : n - 1));
       GroupState gs[6];
 #pragma unroll
       for (int sidx = 0; sidx < 48; ++sidx)
-        split_micro<LoaderA, LoaderB, true>(sidx, gs, ra[set], rb[set], slds + (q - 3) * S_STAGE + wa_off, slds + (q - 3) * S_STAGE + wb_off, t.k0,
-                                            t.klim);
+        split_micro<LoaderA, LoaderB, true, S_PLA, S_PLB>(sidx, gs, ra[set], rb[set], slds + (q - 2) * S_STAGE + wa_off,
+                                                            slds + (q - 2) * S_STAGE + wb_off, t.k0, t.klim);
     }
-    const SplitTile t = split_tile(seg, kbeg + (lt < n ? lt : n - 1));
+    const SplitTile t = split_tile(seg, kbeg + (q < n ? q : n - 1));
 #pragma unroll
     for (int i = 0; i < NFA; ++i) ra[set][i] = LoaderA::load_any(i, t.A, t.lda, m0, a_last, t.k0, t.klim);
 #pragma unroll
@@ -333,29 +324,19 @@ __global__ __launch_bounds__(256, 1) void k_gemm_split(const GemmArgs a) {
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int p = 1; p < 3; ++p)
-#pragma unroll
-      for (int h = 0; h < 2; ++h) frag_half(fr.a[i][p], h, slds + fa_off + i * 32 * SROW + p * S_PLA);
+    for (int p = 0; p < 3; ++p) fr.a[i][p] = frag16(slds + fa_off + i * 32 * SROW + p * S_PLA);
 #pragma unroll
   for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
-#pragma unroll
-      for (int h = 0; h < 2; ++h) frag_half(fr.b[j][p], h, slds + fb_off + j * 32 * SROW + p * S_PLB);
+    for (int p = 0; p < 3; ++p) fr.b[j][p] = frag16(slds + fb_off + j * 32 * SROW + p * S_PLB);
+  __syncthreads();                            // (step 0 writes tile 2 into stage 0: everybody has read tile 0 out of it)
 
-  // ---- one k-tile.  POS = local tile index mod 3 fixes the buffers: stage POS holds this tile, stage (POS + 1) % 3 the next one
-  // (being read), set / stage (POS + 2) % 3 the tile after that (being split) and then tile lt + 5 (requested).  FULL: tile lt + 2 is a
-  // whole tile of the main operand pair and tile lt + 5 is one too (or is never used) -- buffer loads, no masks, no conditional.  Otherwise the generic request / masked
-  // split.  Past the end of the piece everything still runs, on clamped addresses, into buffers nobody multiplies: no conditional
-  // there either.  48 MFMAs; behind MFMA m: ONE fragment half (m < 36... see the table), micro-step m of the split, at most one load.
   auto tile_step = [&](auto pos_c, auto full_c, int lt) {
-    constexpr int POS = decltype(pos_c)::value;
+    constexpr int POS = decltype(pos_c)::value;          // local tile index mod 2
     constexpr bool FULL = decltype(full_c)::value;
-    constexpr int SR = (POS + 1) % 3, SW = (POS + 2) % 3;
-    const unsigned char* cstage = slds + POS * S_STAGE;
-    const unsigned char* rstage = slds + SR * S_STAGE;
-    unsigned char* wa = slds + SW * S_STAGE + wa_off;
-    unsigned char* wb = slds + SW * S_STAGE + wb_off;
+    const unsigned char* rstage = slds + (POS ^ 1) * S_STAGE;      // tile lt + 1
+    unsigned char* wa = slds + POS * S_STAGE + wa_off;             // tile lt + 2 goes where tile lt was
+    unsigned char* wb = slds + POS * S_STAGE + wb_off;
     GroupState gs[6];
     int k0s = 0, klims = 0;
     SplitTile tnext;
@@ -364,99 +345,61 @@ __global__ __launch_bounds__(256, 1) void k_gemm_split(const GemmArgs a) {
       const SplitTile ts = split_tile(seg, kbeg + (lt + 2 < n ? lt + 2 : n - 1));
       k0s = ts.k0;
       klims = ts.klim;
-      tnext = split_tile(seg, kbeg + (lt + 5 < n ? lt + 5 : n - 1));
+      tnext = split_tile(seg, kbeg + (lt + 4 < n ? lt + 4 : n - 1));
     } else {
       tnext.A = A; tnext.B = B; tnext.lda = a.lda; tnext.ldb = a.ldb; tnext.klim = K; tnext.k0 = 0;
-      // (a request past the last whole tile of the main pair re-reads that tile: valid memory, nobody splits it)
-      const int tl = min(kbeg + lt + 5, nk_full - 1);
+      const int tl = min(kbeg + lt + 4, nk_full - 1);
       soffA = LoaderA::soffset(a.lda, tl * SBK);
       soffB = LoaderB::soffset(a.ldb, tl * SBK);
     }
-    // pair order: (A plane, B plane) = lh, mm, mh, hl, hm, hh
-    constexpr int PA_[6] = {2, 1, 1, 0, 0, 0}, PB_[6] = {0, 1, 0, 2, 1, 0};
+    constexpr int PA_[6] = {2, 1, 1, 0, 0, 0}, PB_[6] = {0, 1, 0, 2, 1, 0};      // lh, mm, mh, hl, hm, hh
 #pragma clang loop unroll(full)
     for (int m = 0; m < 48; ++m) {
       const int t = m / 8, ij = m % 8, i = ij >> 1, j = ij & 1;
-      // operands swapped (B fragment first): the accumulator holds the transposed sub-tile, see gemm_epilogue
-#ifndef CGC_XS_NOMFMA          // (CGC_XS_*: timing ablations that break the result -- tools/variant_lib.sh; never defined in the build)
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fr.b[j][PB_[t]]), __builtin_bit_cast(bf16x8, fr.a[i][PA_[t]]),
                                                           acc[i][j], 0, 0, 0);
-#else
-      acc[i][j][m % 16] += __builtin_bit_cast(float, fr.b[j][PB_[t]][m & 3]) + __builtin_bit_cast(float, fr.a[i][PA_[t]][m & 3]);
-#endif
-#ifndef CGC_XS_NOREAD
-      // fragment halves: 36 reads in the gaps where their registers are free (SplitFrags), each at least 12 MFMAs ahead of its first use
-      if (m < 8) {                                     // this tile's A.hi (first used by pair 3, MFMA 24)
-        frag_half(fr.a[m >> 1][0], m & 1, cstage + fa_off + (m >> 1) * 32 * SROW);
-      } else if (m < 16) {                             // next tile's A.lo (this tile's: pair 0 only)
-        frag_half(fr.a[(m - 8) >> 1][2], m & 1, rstage + fa_off + ((m - 8) >> 1) * 32 * SROW + 2 * S_PLA);
-      } else if (m < 20) {                             // next tile's B.hi, into the second copy
-        frag_half(fr.b0n[(m - 16) >> 1], m & 1, rstage + fb_off + ((m - 16) >> 1) * 32 * SROW);
-      } else if (m >= 24 && m < 32) {                  // next tile's A.mid (this tile's: pairs 1, 2)
-        frag_half(fr.a[(m - 24) >> 1][1], m & 1, rstage + fa_off + ((m - 24) >> 1) * 32 * SROW + S_PLA);
-      } else if (m >= 32 && m < 36) {                  // next tile's B.lo (this tile's: pair 3)
-        frag_half(fr.b[(m - 32) >> 1][2], m & 1, rstage + fb_off + ((m - 32) >> 1) * 32 * SROW + 2 * S_PLB);
-      } else if (m >= 40 && m < 44) {                  // next tile's B.mid (this tile's: pairs 1, 4)
-        frag_half(fr.b[(m - 40) >> 1][1], m & 1, rstage + fb_off + ((m - 40) >> 1) * 32 * SROW + S_PLB);
-      }
-#endif
-#ifdef CGC_XS_NOSPLIT
-      if (!FULL)
-#endif
-#ifdef CGC_XS_NOWRITE
-      if (!FULL || (m & 7) != 7)
-#endif
-      split_micro<LoaderA, LoaderB, !FULL>(m, gs, ra[SW], rb[SW], wa, wb, k0s, klims);
-#ifdef CGC_XS_NOLOAD
-      if (!FULL) {
-#else
-      {
-#endif
-      // the set's registers are free once its groups have been picked up (A: micro-step 24, B: 40): refill
+      // the next tile's fragments, 18 reads of 16 bytes, each plane as soon as this tile's copy is dead
+      if (m < 4) fr.a0n[m] = frag16(rstage + fa_off + m * 32 * SROW);                                        // A.hi' (second copy)
+      else if (m < 6) fr.b0n[m - 4] = frag16(rstage + fb_off + (m - 4) * 32 * SROW);                         // B.hi' (second copy)
+      else if (m >= 8 && m < 12) fr.a[m - 8][2] = frag16(rstage + fa_off + (m - 8) * 32 * SROW + 2 * S_PLA);   // A.lo (pair 0 only)
+      else if (m >= 24 && m < 28) fr.a[m - 24][1] = frag16(rstage + fa_off + (m - 24) * 32 * SROW + S_PLA);   // A.mid (pairs 1, 2)
+      else if (m >= 32 && m < 34) fr.b[m - 32][2] = frag16(rstage + fb_off + (m - 32) * 32 * SROW + 2 * S_PLB);   // B.lo (pair 3)
+      else if (m >= 40 && m < 42) fr.b[m - 40][1] = frag16(rstage + fb_off + (m - 40) * 32 * SROW + S_PLB);   // B.mid (pairs 1, 4)
+      split_micro<LoaderA, LoaderB, !FULL, S_PLA, S_PLB>(m, gs, ra[POS], rb[POS], wa, wb, k0s, klims);
       if (m >= 28 && m < 28 + NFA) {
-        if constexpr (FULL) ra[SW][m - 28] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrcA, offA[m - 28], soffA, 0));
-        else ra[SW][m - 28] = LoaderA::load_any(m - 28, tnext.A, tnext.lda, m0, a_last, tnext.k0, tnext.klim);
+        if constexpr (FULL) ra[POS][m - 28] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrcA, offA[m - 28], soffA, 0));
+        else ra[POS][m - 28] = LoaderA::load_any(m - 28, tnext.A, tnext.lda, m0, a_last, tnext.k0, tnext.klim);
       }
       if (m >= 44 && m < 44 + NFB) {
-        if constexpr (FULL) rb[SW][m - 44] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrcB, offB[m - 44], soffB, 0));
-        else rb[SW][m - 44] = LoaderB::load_any(m - 44, tnext.B, tnext.ldb, n0, b_last, tnext.k0, tnext.klim);
-      }
+        if constexpr (FULL) rb[POS][m - 44] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrcB, offB[m - 44], soffB, 0));
+        else rb[POS][m - 44] = LoaderB::load_any(m - 44, tnext.B, tnext.ldb, n0, b_last, tnext.k0, tnext.klim);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    // the next tile's B.hi becomes the current one (register renaming: a move the allocator removes, or two v_mov per sub-tile)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fr.a[i][0] = fr.a0n[i];
     fr.b[0][0] = fr.b0n[0];
     fr.b[1][0] = fr.b0n[1];
-#ifdef CGC_XS_NOBAR
-    if (!FULL)
-#endif
     __syncthreads();
   };
   typedef std::true_type FULL_;
   typedef std::false_type ANY_;
 #define SPLIT_POS(P_) std::integral_constant<int, P_>()
   int lt = 0;
-  // steps whose tile lt + 2 (the one being split) is a whole tile of the main pair and whose request (tile lt + 5) is either such a tile
-  // too or not needed at all: past the end of the piece / of the main pair's whole tiles the request is clamped (see tile_step) -- what
-  // follows the main pair (a partial tile, the extra segments) is requested by the generic steps, which start three tiles before it
-  const int last_special = nk - nk_full;                          // tiles of this product that are not whole main-pair tiles
-  const int full_steps = min(last_special > 0 && kend > nk_full ? nk_full - 5 - kbeg : nk_full - 2 - kbeg, n);
-  for (; lt + 3 <= full_steps; lt += 3) {
+  const int last_special = nk - nk_full;
+  const int full_steps = min(last_special > 0 && kend > nk_full ? nk_full - 4 - kbeg : nk_full - 2 - kbeg, n);
+  for (; lt + 2 <= full_steps; lt += 2) {
     tile_step(SPLIT_POS(0), FULL_(), lt);
     tile_step(SPLIT_POS(1), FULL_(), lt + 1);
-    tile_step(SPLIT_POS(2), FULL_(), lt + 2);
   }
   for (; lt < n; ++lt) {
-    const int pos = lt % 3;
-    if (pos == 0) tile_step(SPLIT_POS(0), ANY_(), lt);
-    else if (pos == 1) tile_step(SPLIT_POS(1), ANY_(), lt);
-    else tile_step(SPLIT_POS(2), ANY_(), lt);
+    if ((lt & 1) == 0) tile_step(SPLIT_POS(0), ANY_(), lt);
+    else tile_step(SPLIT_POS(1), ANY_(), lt);
   }
 #undef SPLIT_POS
 
   float* const lds_f = reinterpret_cast<float*>(slds);
   if (S > 1) {
-    // piece of a tail tile: raw accumulators into this piece's slab (k_gemm_fixup<2, 2, 4, 2> adds the slabs; same layout as k_gemm_f32)
     float* slab = a.ws + ((size_t)tj * S + piece) * (size_t)(S_BM * S_BN) + (size_t)wave * (TM * TN * 16 * 64) + lane * 4;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -468,10 +411,6 @@ __global__ __launch_bounds__(256, 1) void k_gemm_split(const GemmArgs a) {
               make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
     return;
   }
-  // (the last step ended with a barrier: the LDS is free for the parking strips of the epilogue)
-#ifdef CGC_XS_NOEPI
-  if (acc[0][0][0] == 12345.678f)
-#endif
   gemm_epilogue<TM, TN>(a, C, M, N, m0 + wm * TM * 32, n0 + wn * TN * 32, acc, lds_f + wave * 32 * (TN * 32 + 4), lane);
 }
 
