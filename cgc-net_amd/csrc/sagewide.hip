@@ -370,6 +370,290 @@ __global__ __launch_bounds__(512, 1) void k_sage_wide_fwd8(const float* __restri
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Round 5: the row norm WITHOUT the wide product.  ||agg_i W + b||^2 = agg_i^T (W W^T) agg_i + 2 agg_i . (W b) + b . b is a K x K
+// quadratic form per row (K = 20: 230 multiply-adds in double, 13 MFLOP for a whole C3 batch), so 1 / ||h|| of every row is known
+// BEFORE the projection runs and the projection needs no exchange between the waves that share a row: no LDS, no barrier, no
+// workgroup-wide W.  Three launches:
+//   k_sage_gram   G = upper triangle of W W^T (off-diagonal entries doubled) | 2 W b | b.b in double -- one wave per entry;
+//   k_sage_rinv   one thread per row evaluates the form in double from G (LDS, broadcast reads) and stores 1 / max(||h||, eps);
+//   k_sage_wide_cols  a WAVE owns 32 rows x 96 columns: its three 32-column slices of W stay in registers as MFMA B fragments
+//                 (3 KS registers), three independent accumulator chains, scaled by 1 / ||h|| and stored straight from the
+//                 accumulators (128-byte row segments, buffer stores), BatchNorm column sums per lane as in the kernels above.
+//                 The waves of a workgroup take neighbouring column groups of the same rows; three workgroups per CU, so one
+//                 wave's stores and statistics run under the other waves' MFMA chains (the 8-wave kernel above serialises them:
+//                 42 + 32 + 23 + 6 us).
+// G travels in the first bytes of hn itself (written by the first launch, read by the second, overwritten by the third: stream order).
+#define SWC_TILES 3
+__global__ __launch_bounds__(256) void k_sage_gram(const float* __restrict__ W, const float* __restrict__ bias, int K, int F,
+                                                   double* __restrict__ G) {
+  // entry e: e < K (K + 1) / 2 -> (i, j >= i) of the upper triangle in row-major order; then K entries 2 (W b)_i; then b . b.
+  // One workgroup per entry, a fixed summation tree (thread -> wave -> workgroup): the same bits on every run.
+  __shared__ double part[4];
+  const int tri = K * (K + 1) / 2, e = blockIdx.x;
+  const float *x, *y;
+  double scale = 1.0;
+  if (e < tri) {
+    int i = 0, rem = e;
+    while (rem >= K - i) { rem -= K - i; ++i; }
+    const int j = i + rem;
+    x = W + (size_t)i * F;
+    y = W + (size_t)j * F;
+    scale = i == j ? 1.0 : 2.0;
+  } else if (e < tri + K) {
+    x = W + (size_t)(e - tri) * F;
+    y = bias;
+    scale = 2.0;
+  } else {
+    x = y = bias;
+  }
+  double s = 0.0;
+  if (y != nullptr) {
+    for (int c0 = 0; c0 < F; c0 += 256 * 8) {
+      float xv[8], yv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {                  // (every load of the pass in flight before the first use)
+        const int c = c0 + u * 256 + (int)threadIdx.x;
+        xv[u] = c < F ? x[c] : 0.f;
+        yv[u] = c < F ? y[c] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s = fma((double)xv[u], (double)yv[u], s);
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) G[e] = ((part[0] + part[1]) + (part[2] + part[3])) * scale;
+}
+
+template <int KK>
+__global__ __launch_bounds__(256) void k_sage_rinv(const float* __restrict__ agg, int lda, int n, int K, const double* __restrict__ G,
+                                                   float* __restrict__ rinv) {
+  __shared__ double g[KK * (KK + 1) / 2 + KK + 1];       // the same packing as G, for width KK (entries with an index >= K: zero)
+  const int tri = K * (K + 1) / 2;
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  float xf[KK];                                           // the row travels while G is staged
+  {
+    const float* __restrict__ a = agg + (size_t)min(row, n - 1) * lda;
+#pragma unroll
+    for (int k = 0; k < KK; ++k) xf[k] = k < K ? a[k] : 0.f;
+  }
+  for (int e = threadIdx.x; e < KK * (KK + 1) / 2 + KK + 1; e += 256) {
+    double v = 0.0;
+    if (e < KK * (KK + 1) / 2) {
+      int i = 0, rem = e;
+      while (rem >= KK - i) { rem -= KK - i; ++i; }
+      const int j = i + rem;
+      if (j < K) v = G[i * K - i * (i - 1) / 2 + (j - i)];
+    } else if (e < KK * (KK + 1) / 2 + KK) {
+      const int i = e - KK * (KK + 1) / 2;
+      if (i < K) v = G[tri + i];
+    } else {
+      v = G[tri + K];
+    }
+    g[e] = v;
+  }
+  __syncthreads();
+  if (row >= n) return;
+  double x[KK];
+#pragma unroll
+  for (int k = 0; k < KK; ++k) x[k] = (double)xf[k];
+  double q = g[KK * (KK + 1) / 2 + KK];
+  int e = 0;
+#pragma unroll
+  for (int i = 0; i < KK; ++i) {
+    double t = g[KK * (KK + 1) / 2 + i];
+#pragma unroll
+    for (int j = i; j < KK; ++j) t = fma(g[e++], x[j], t);
+    q = fma(t, x[i], q);
+  }
+  const double nrm = sqrt(q > 0.0 ? q : 0.0);
+  rinv[row] = (float)(1.0 / (nrm > (double)L2_EPS ? nrm : (double)L2_EPS));
+}
+
+// the 16 row factors a lane needs for the row tile at row0 (accumulator register r <-> row (r & 3) + 8 (r >> 2) + 4 lhi): four 16-byte
+// loads for a whole tile; the partial last tile reads element by element (whether a 16-byte buffer load that straddles num_records
+// returns its in-range part is not something to rely on)
+__device__ __forceinline__ void load_rows(__amdgpu_buffer_rsrc_t rsrc, int row0, int n, int lhi, float4 (&out)[4]) {
+  if (row0 + 32 <= n) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      out[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (unsigned)(row0 + 8 * j + 4 * lhi) * 4u, 0, 0));
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned o = (unsigned)(row0 + 8 * j + 4 * lhi) * 4u;
+      out[j].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, o, 0, 0));
+      out[j].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, o + 4u, 0, 0));
+      out[j].z = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, o + 8u, 0, 0));
+      out[j].w = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, o + 12u, 0, 0));
+    }
+  }
+}
+
+template <int KS, int ACT>
+#ifndef CGC_SWC_WAVES
+#define CGC_SWC_WAVES 3
+#endif
+__global__ __launch_bounds__(256, CGC_SWC_WAVES) void k_sage_wide_cols(const float* __restrict__ agg, int lda, const float* __restrict__ W,
+                                                           const float* __restrict__ bias, int n, int K, int F,
+                                                           const float* __restrict__ rinv, float* __restrict__ hn, int ldh,
+                                                           float* __restrict__ ws, int row_tiles, int chunks, int ngroups) {
+  constexpr int NT = SWC_TILES;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int rc = blockIdx.x % chunks, grp = (blockIdx.x / chunks) * 4 + wave;
+  if (grp >= ngroups) return;                        // (no barrier anywhere in this kernel)
+  const int c_base = grp * NT * 32;
+  // B fragments: rows k < K of W, and the BIAS as row K (the A fragment carries a 1 there): the accumulators start from an inline
+  // zero -- a bias-initialised set of accumulators kept for every row tile costs NT x 16 registers -- and the bias is added last, as
+  // in the reference's matmul + bias.  Buffer loads: entries past F columns read as zero through the bounds check, no branches.
+  float bw[NT][KS], s1[NT], s2[NT], shift[NT];
+  {
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, K * F * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bias), 0, bias != nullptr ? F * 4 : 0, 0x00020000);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int col = c_base + t * 32 + l31;
+      const float bv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_b, (unsigned)col * 4u, 0, 0));
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const int k = 2 * s + lhi;
+        const float wv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_w, (col < F && k < K) ? (unsigned)(k * F + col) * 4u : 0x80000000u, 0, 0));
+        bw[t][s] = k == K ? bv : wv;
+      }
+      s1[t] = s2[t] = shift[t] = 0.f;
+    }
+  }
+  int seen = 0;
+  const __amdgpu_buffer_rsrc_t rsrc_hn = __builtin_amdgcn_make_buffer_rsrc(hn, 0, (int)((size_t)n * ldh * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_ri = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(rinv), 0, n * 4, 0x00020000);
+  // the next row tile's A fragments travel while this one is computed (rows past n: clamped)
+  // (one descriptor over agg, one lane offset per row tile, the k step as the instruction's immediate offset: a flat load per
+  // element needs a 64-bit address each; entries with k >= K are replaced below, reads past the last row's K entries return zero)
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(agg), 0, (int)(((size_t)(n - 1) * lda + K) * 4), 0x00020000);
+  float av_next[KS];
+  {
+    const unsigned ao = (unsigned)(min(rc * 32 + l31, n - 1) * lda + lhi) * 4u;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) av_next[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_a, ao + 8u * s, 0, 0));
+  }
+  for (int rt = rc; rt < row_tiles; rt += chunks) {
+    const int row0 = rt * 32;
+    float av[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) av[s] = (2 * s + lhi) < K ? av_next[s] : (2 * s + lhi) == K ? 1.f : 0.f;
+    floatx16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+#ifndef CGC_SWC_NOMFMA
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bw[t][s], acc[t], 0, 0, 0);
+#else
+      for (int t = 0; t < NT; ++t) acc[t][s % 16] += av[s] * bw[t][s];
+#endif
+    // This tile's row factors and the next tile's A fragments are requested behind this tile's MFMAs and waited for in front of its
+    // stores (vmcnt counts loads and stores in issue order: see k_sage_wide_fwd8).  (Requesting them INSIDE the chains -- step s's
+    // fragment as soon as step s has consumed the current one -- was measured: 67 -> 71 us.)
+    float4 rq[4];
+    load_rows(rsrc_ri, row0, n, lhi, rq);
+    {
+      const int nrt = rt + chunks < row_tiles ? rt + chunks : rt;
+      const unsigned ao = (unsigned)(min(nrt * 32 + l31, n - 1) * lda + lhi) * 4u;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) av_next[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_a, ao + 8u * s, 0, 0));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(av_next[s]));
+    float rin[16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      asm volatile("" : "+v"(rq[j].x), "+v"(rq[j].y), "+v"(rq[j].z), "+v"(rq[j].w));
+      rin[4 * j] = rq[j].x; rin[4 * j + 1] = rq[j].y; rin[4 * j + 2] = rq[j].z; rin[4 * j + 3] = rq[j].w;
+    }
+    const bool full = row0 + 32 <= n;
+    if (rt == rc) {
+      // The shift of the statistics: any value near the column's mean does (deviations from it are summed, nothing large cancels);
+      // each half wave takes its own first row of its first tile (the halves are folded as (count, mean, M2) at the end)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) shift[t] = act_fwd(acc[t][0] * rin[0], ACT);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // Stores: buffer stores off one descriptor over hn, a lane contributes a loop-invariant byte offset, the row is the instruction's
+    // scalar offset (k_sage_wide_fwd8).  Parking each 32 x 32 tile in a per-wave LDS patch and storing it as 16-byte pieces of whole
+    // 128-byte row segments (4 store instructions per tile instead of 16) was measured: 67 us either way -- and a 16-byte buffer
+    // store whose row offset sits in an SGPR left one piece in ~10^4 with its first word replaced by what the NEXT vector
+    // instruction wrote to that data register (the data is not read at issue in that form; with the whole offset in the VGPR it was
+    // correct).  Dword stores have no such hazard.
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int col = c_base + t * 32 + l31;
+      const bool colok = col < F;
+      const unsigned voff = colok ? (unsigned)(4 * lhi * ldh + col) * 4u : 0x80000000u;
+      float a1 = 0.f, a2 = 0.f;
+      if (full) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = acc[t][r] * rin[r];
+#ifndef CGC_SWC_NOSTATS
+          const float d = act_fwd(v, ACT) - shift[t];
+          a1 += d;
+          a2 = fmaf(d, d, a2);
+#endif
+#ifndef CGC_SWC_NOSTORE
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc_hn, voff,
+                                                (unsigned)(row0 + (r & 3) + 8 * (r >> 2)) * (unsigned)ldh * 4u, 0);
+#else
+          if (v == 123.456f) hn[0] = v;
+#endif
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = acc[t][r] * rin[r];
+          const bool ok = row0 + (r & 3) + 8 * (r >> 2) + 4 * lhi < n;
+          const float d = ok ? act_fwd(v, ACT) - shift[t] : 0.f;
+          a1 += d;
+          a2 = fmaf(d, d, a2);
+          // (rows past n are dropped by the LANE's own offset: the bounds check of a raw buffer does not include the scalar offset)
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc_hn, ok ? voff : 0x80000000u,
+                                                (unsigned)(row0 + (r & 3) + 8 * (r >> 2)) * (unsigned)ldh * 4u, 0);
+        }
+      }
+      if (colok) { s1[t] += a1; s2[t] += a2; }
+      __builtin_amdgcn_sched_barrier(0);          // one column tile at a time (keeps the scaled copies of one accumulator live, not three)
+    }
+    if (full) {
+      seen += 16;
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) seen += (row0 + (r & 3) + 8 * (r >> 2) + 4 * lhi) < n ? 1 : 0;
+    }
+  }
+  if (ws != nullptr) {
+    double* slot = reinterpret_cast<double*>(ws) + (size_t)rc * 2 * F;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const double cn = (double)seen, c = (double)shift[t], a1 = (double)s1[t], a2 = (double)s2[t];
+      const double mean = seen > 0 ? c + a1 / cn : 0.0, M2 = seen > 0 ? a2 - a1 * a1 / cn : 0.0;
+      double so = cn * mean, soo = M2 + cn * mean * mean;
+      so += __shfl_xor(so, 32);
+      soo += __shfl_xor(soo, 32);
+      const int col = c_base + t * 32 + l31;
+      if (lhi == 0 && col < F) {
+        slot[col] = so;
+        slot[F + col] = soo;
+      }
+    }
+  }
+}
+
 extern "C" int cgc_stats_blocks(int n, int F);
 int launch_stats_finalize(const float* ws, int slots, int F, double count, float eps, float momentum, float* running_mean,
                           float* running_var, float* mean, float* istd, int64_t* nbt, hipStream_t stream);   // rowops.hip
@@ -395,6 +679,38 @@ extern "C" int cgc_sage_wide_fwd(const float* agg, int lda, const float* W, cons
     float* wsp = stats ? ws : nullptr;
     const int ks = K <= 16 ? 8 : K <= 20 ? 10 : 16;
     // the single-pass 8-wave kernel when W fits the LDS next to nothing else ([2 ks][Fp] floats + 2 KB): one workgroup per CU
+    // round 5: row norms from the K x K quadratic form, then one wave per 32 rows x 96 columns (see k_sage_wide_cols)
+    static const int use_cols = getenv("CGC_SAGE_WIDE_COLS") ? atoi(getenv("CGC_SAGE_WIDE_COLS")) : 1;
+    static const int cols_chunks = getenv("CGC_SAGE_WIDE_CHUNKS") ? atoi(getenv("CGC_SAGE_WIDE_CHUNKS")) : 256;
+    if (use_cols && normalize && K <= 21 && n >= 64 && (long long)n * ldh * 4 < (1LL << 31) && (reinterpret_cast<uintptr_t>(hn) & 7u) == 0 &&
+        aligned16(rinv) && (size_t)n * ldh * 4 >= sizeof(double) * (size_t)(K * (K + 1) / 2 + K + 1) && ((long long)(n - 1) * lda + K) * 4 < (1LL << 31)) {
+      int per = ceil_div(row_tiles, cols_chunks > 0 ? cols_chunks : 256);
+      int chunks = ceil_div(row_tiles, per);
+      if (stats && chunks > cap) { chunks = cap > 0 ? cap : 1; }
+      const int ngroups = ceil_div(ceil_div(F, 32), SWC_TILES);
+      double* G = reinterpret_cast<double*>(hn);
+      hipLaunchKernelGGL(k_sage_gram, dim3(K * (K + 1) / 2 + K + 1), dim3(256), 0, st, W, bias, K, F, G);
+      if (ks == 8) hipLaunchKernelGGL((k_sage_rinv<16>), dim3(ceil_div(n, 256)), dim3(256), 0, st, agg, lda, n, K, G, rinv);
+      else if (ks == 10) hipLaunchKernelGGL((k_sage_rinv<20>), dim3(ceil_div(n, 256)), dim3(256), 0, st, agg, lda, n, K, G, rinv);
+      else hipLaunchKernelGGL((k_sage_rinv<32>), dim3(ceil_div(n, 256)), dim3(256), 0, st, agg, lda, n, K, G, rinv);
+      const dim3 grid(chunks * ceil_div(ngroups, 4));
+#define SWC_ONE(KS_, ACT_)                                                                                                         \
+  hipLaunchKernelGGL((k_sage_wide_cols<KS_, ACT_>), grid, dim3(256), 0, st, agg, lda, W, bias, n, K, F, rinv, hn, ldh, wsp, row_tiles, \
+                     chunks, ngroups)
+#define SWC_LAUNCH(KS_)                                             \
+  do {                                                              \
+    if (act == CGC_ACT_RELU) SWC_ONE(KS_, CGC_ACT_RELU);            \
+    else if (act == CGC_ACT_ELU) SWC_ONE(KS_, CGC_ACT_ELU);         \
+    else if (act == CGC_ACT_LEAKYRELU) SWC_ONE(KS_, CGC_ACT_LEAKYRELU); \
+    else SWC_ONE(KS_, CGC_ACT_IDENTITY);                            \
+  } while (0)
+      if (K <= 17) SWC_LAUNCH(9); else SWC_LAUNCH(11);      // K + 1 (the bias row) <= 2 KS
+#undef SWC_LAUNCH
+#undef SWC_ONE
+      CGC_RETURN_IF_LAUNCH_FAILED();
+      if (stats) return launch_stats_finalize(ws, chunks, F, count, eps, momentum, running_mean, running_var, mean, istd, num_batches_tracked, st);
+      return 0;
+    }
     static const int use8 = getenv("CGC_SAGE_WIDE8") ? atoi(getenv("CGC_SAGE_WIDE8")) : 1;
     const int ntw8 = F <= 8 * 5 * 32 ? 5 : 7, Fp = 8 * ntw8 * 32;
     const size_t lds8 = sizeof(float) * ((size_t)2 * ks * Fp + 512 + 256);
