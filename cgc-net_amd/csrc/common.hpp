@@ -124,4 +124,22 @@ template <> struct Vec<4> {
   __device__ __forceinline__ void store(float* p) const {
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
   }
+  // streaming read: the line is not kept in L2 / the Infinity Cache.  A 263 MB tensor that is read once per pass gains nothing from
+  // being cached, and the lines it would occupy are the ones the pass's own WRITES want: tools/probes/stream_rows_probe.hip --
+  // one read + one write of [57696, 1140] floats at 5.3 TB/s with plain loads (torch's copy_, hipMemcpy: the same), 6.8 TB/s with
+  // these.  (Nontemporal STORES cost 25 %.)
+  __device__ __forceinline__ void load_stream(const float* p) {
+    typedef float vf4 __attribute__((ext_vector_type(4)));
+    const vf4 t = __builtin_nontemporal_load(reinterpret_cast<const vf4*>(p));
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  }
 };
+// rows of more than 1024 floats (16-byte lanes, 5+ chunks per lane: the cluster-count-wide tensors) are read as streams
+template <int VEC, int MAXJ>
+__device__ __forceinline__ void load_wide(Vec<VEC>& x, const float* p) {
+#ifndef CGC_NO_STREAM_LOADS      // (-DCGC_NO_STREAM_LOADS: plain loads, for A/B timing through tools/variant_lib.sh)
+  if constexpr (VEC == 4 && MAXJ >= 5) x.load_stream(p);
+  else
+#endif
+    x.load(p);
+}

@@ -4,6 +4,8 @@
 //   * row reductions are wavefront shuffles, column reductions are per-lane register accumulators combined
 //     deterministically (wave -> LDS -> per-block slot -> second-stage kernel): no float atomics anywhere.
 // Reference arithmetic: see the citations in include/cgc_hip.h.
+#include <type_traits>
+
 #include "common.hpp"
 #include "groups.hpp"
 
@@ -278,7 +280,7 @@ __global__ __launch_bounds__(256) void k_l2norm_act_stats(const float* __restric
     for (int j = 0; j < MAXJ; ++j) {
       const int c = (rg.sl + lpr * j) * VEC;
       if (valid && c < F) {
-        x[j].load(h + (size_t)row * F + c);
+        load_wide<VEC, MAXJ>(x[j], h + (size_t)row * F + c);
 #pragma unroll
         for (int v = 0; v < VEC; ++v) ss += x[j].v[v] * x[j].v[v];
       } else {
@@ -483,31 +485,53 @@ __global__ __launch_bounds__(256) void k_bn_act_apply(const BnApplyPtrs p0, cons
   for (int j = 0; j < MAXJ; ++j)
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
-      const int c = (rg.sl + lpr * j) * VEC + v;
       mu[j][v] = 0.f;
       sc[j][v] = 1.f;
       sh[j][v] = 0.f;
-      if (mean != nullptr && c < F) {
+    }
+  if (mean != nullptr) {
+    // branch-free: a clamped index instead of a predicate per constant (20 conditional blocks, each with its own wait for four
+    // dependent-latency loads, were 15-20 us at the start of every wave); the values of lanes past F are never used
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j)
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        const int c = min((rg.sl + lpr * j) * VEC + v, F - 1);
         mu[j][v] = mean[c];
         sc[j][v] = istd[c] * gamma[c];
         sh[j][v] = beta[c];
       }
-    }
-  for (int base = rg.gwave * rg.rpw; base < n; base += rg.nwaves * rg.rpw) {
-    const int row = base + rg.sub;
-    if (row >= n) continue;
+  }
+  // The activation code is a run-time argument; as a switch inside the element loop it splits every chunk into its own basic blocks
+  // (load -> wait -> branch -> compute -> store, one chunk at a time: 118 us on [57.7k, 1140]).  Here the switch is outside the row
+  // loop, the loads of a row are unconditional (a chunk past F re-reads the row's last chunk) and all requested before the first
+  // value is used; only the stores are predicated.
+  auto rows = [&](auto act_c) {
+    constexpr int ACT = decltype(act_c)::value;
+    const int last = F - VEC;                            // (F >= VEC: F % VEC == 0 and F > 0)
+    for (int base = rg.gwave * rg.rpw; base < n; base += rg.nwaves * rg.rpw) {
+      const int row = min(base + rg.sub, n - 1);
+      const bool rowok = base + rg.sub < n;
+      Vec<VEC> x[MAXJ];
 #pragma unroll
-    for (int j = 0; j < MAXJ; ++j) {
-      const int c = (rg.sl + lpr * j) * VEC;
-      if (c < F) {
-        Vec<VEC> x;
-        x.load(hn + (size_t)row * F + c);
+      for (int j = 0; j < MAXJ; ++j) load_wide<VEC, MAXJ>(x[j], hn + (size_t)row * F + min((rg.sl + lpr * j) * VEC, last));
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) x.v[v] = fmaf(act_fwd(x.v[v], act) - mu[j][v], sc[j][v], sh[j][v]);
-        x.store(y + (size_t)row * ldy + c);
-        if (y2 != nullptr) x.store(y2 + (size_t)row * ldy2 + c);
+      for (int j = 0; j < MAXJ; ++j) {
+        const int c = (rg.sl + lpr * j) * VEC;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) x[j].v[v] = fmaf(act_fwd(x[j].v[v], ACT) - mu[j][v], sc[j][v], sh[j][v]);
+        if (rowok && c < F) {
+          x[j].store(y + (size_t)row * ldy + c);
+          if (y2 != nullptr) x[j].store(y2 + (size_t)row * ldy2 + c);
+        }
       }
     }
+  };
+  switch (act) {
+    case CGC_ACT_RELU: rows(std::integral_constant<int, CGC_ACT_RELU>()); break;
+    case CGC_ACT_ELU: rows(std::integral_constant<int, CGC_ACT_ELU>()); break;
+    case CGC_ACT_LEAKYRELU: rows(std::integral_constant<int, CGC_ACT_LEAKYRELU>()); break;
+    default: rows(std::integral_constant<int, CGC_ACT_IDENTITY>()); break;
   }
 }
 
@@ -558,10 +582,12 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const BnRedPtrs p0, const
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
       acc[0][j][v] = acc[1][j][v] = 0.f;
-      const int c = (rg.sl + lpr * j) * VEC + v;
-      mu[j][v] = c < F ? mean[c] : 0.f;
-      is[j][v] = c < F ? istd[c] : 0.f;
+      const int c = min((rg.sl + lpr * j) * VEC + v, F - 1);      // (clamped, not predicated: see k_bn_act_apply; unused past F)
+      mu[j][v] = mean[c];
+      is[j][v] = istd[c];
     }
+  // (the form of k_bn_act_apply -- activation switch outside the row loop, the row's ten loads requested up front -- was measured
+  // here: 90 -> 95 us; 50 more registers take a workgroup per CU away and this pass only reads: 526 MB at 5.8 TB/s)
   for (int base = rg.gwave * rg.rpw; base < n; base += rg.nwaves * rg.rpw) {
     const int row = base + rg.sub;
     if (row < n) {
@@ -570,8 +596,8 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const BnRedPtrs p0, const
         const int c = (rg.sl + lpr * j) * VEC;
         if (c < F) {
           Vec<VEC> d, x;
-          d.load(dy + (size_t)row * ldy + c);
-          x.load(hn + (size_t)row * F + c);
+          load_wide<VEC, MAXJ>(d, dy + (size_t)row * ldy + c);
+          load_wide<VEC, MAXJ>(x, hn + (size_t)row * F + c);
 #pragma unroll
           for (int v = 0; v < VEC; ++v) {
             const float xhat = (act_fwd(x.v[v], act) - mu[j][v]) * is[j][v];
@@ -663,70 +689,78 @@ __global__ __launch_bounds__(256) void k_bn_act_l2_bwd(const float* __restrict__
     }
     __syncthreads();
   }
-  for (int base = rg.gwave * rg.rpw; base < n; base += rg.nwaves * rg.rpw) {
-    const int row = base + rg.sub;
-    const bool valid = row < n;
-    Vec<VEC> g[MAXJ], x[MAXJ];
-    float dot = 0.f;
-#pragma unroll
-    for (int j = 0; j < MAXJ; ++j) {
-      const int c = (rg.sl + lpr * j) * VEC;
-      if (valid && c < F) {
-        g[j].load(dy + (size_t)row * ldy + c);
-        x[j].load(hn + (size_t)row * F + c);
+  // (the activation switch outside the row loop: see k_bn_act_apply)
+  auto rows = [&](auto act_c) {
+    constexpr int ACT = decltype(act_c)::value;
+    for (int base = rg.gwave * rg.rpw; base < n; base += rg.nwaves * rg.rpw) {
+      const int row = min(base + rg.sub, n - 1);
+      const bool valid = base + rg.sub < n;
+      Vec<VEC> g[MAXJ], x[MAXJ];
+      float dot = 0.f;
+  #pragma unroll
+      for (int j = 0; j < MAXJ; ++j) {           // unconditional (a chunk past F re-reads the row's last chunk; unused)
+        const int c = min((rg.sl + lpr * j) * VEC, F - VEC);
+        load_wide<VEC, MAXJ>(g[j], dy + (size_t)row * ldy + c);
+        load_wide<VEC, MAXJ>(x[j], hn + (size_t)row * F + c);
       }
-    }
-#pragma unroll
-    for (int j = 0; j < MAXJ; ++j) {
-      const int c = (rg.sl + lpr * j) * VEC;
-      if (valid && c < F) {
-        Vec<VEC> pa, pb, pc, pm, pi;      // wide rows: constants of these columns
-        if (!REGC && mode != 0) {
-          pa.load(lc + c);
-          if (mode == 2) { pb.load(lc + F + c); pc.load(lc + 2 * F + c); pm.load(lc + 3 * F + c); pi.load(lc + 4 * F + c); }
-        }
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) {
-          const float xv = x[j].v[v];
-          float a_, b_ = 0.f, c_ = 0.f, m_ = 0.f, i_ = 0.f;
-          if (REGC) {
-            a_ = ca[REGC ? j : 0][REGC ? v : 0]; b_ = cb[REGC ? j : 0][REGC ? v : 0]; c_ = cc[REGC ? j : 0][REGC ? v : 0];
-            m_ = mu[REGC ? j : 0][REGC ? v : 0]; i_ = is[REGC ? j : 0][REGC ? v : 0];
-          } else if (mode != 0) {
-            a_ = pa.v[v];
-            if (mode == 2) { b_ = pb.v[v]; c_ = pc.v[v]; m_ = pm.v[v]; i_ = pi.v[v]; }
-          } else {
-            a_ = 1.f;
+  #pragma unroll
+      for (int j = 0; j < MAXJ; ++j) {
+        const int c = (rg.sl + lpr * j) * VEC;
+        if (valid && c < F) {
+          Vec<VEC> pa, pb, pc, pm, pi;      // wide rows: constants of these columns
+          if (!REGC && mode != 0) {
+            pa.load(lc + c);
+            if (mode == 2) { pb.load(lc + F + c); pc.load(lc + 2 * F + c); pm.load(lc + 3 * F + c); pi.load(lc + 4 * F + c); }
           }
-          float go = a_ * g[j].v[v];
-          if (mode == 2) go = go - b_ - (act_fwd(xv, act) - m_) * i_ * c_;
-          go *= act_bwd(xv, act);
-          g[j].v[v] = go;                 // d(hn)
-          dot += xv * go;
+  #pragma unroll
+          for (int v = 0; v < VEC; ++v) {
+            const float xv = x[j].v[v];
+            float a_, b_ = 0.f, c_ = 0.f, m_ = 0.f, i_ = 0.f;
+            if (REGC) {
+              a_ = ca[REGC ? j : 0][REGC ? v : 0]; b_ = cb[REGC ? j : 0][REGC ? v : 0]; c_ = cc[REGC ? j : 0][REGC ? v : 0];
+              m_ = mu[REGC ? j : 0][REGC ? v : 0]; i_ = is[REGC ? j : 0][REGC ? v : 0];
+            } else if (mode != 0) {
+              a_ = pa.v[v];
+              if (mode == 2) { b_ = pb.v[v]; c_ = pc.v[v]; m_ = pm.v[v]; i_ = pi.v[v]; }
+            } else {
+              a_ = 1.f;
+            }
+            float go = a_ * g[j].v[v];
+            if (mode == 2) go = go - b_ - (act_fwd(xv, ACT) - m_) * i_ * c_;
+            go *= act_bwd(xv, ACT);
+            g[j].v[v] = go;                 // d(hn)
+            dot += xv * go;
+          }
+        } else {
+  #pragma unroll
+          for (int v = 0; v < VEC; ++v) g[j].v[v] = x[j].v[v] = 0.f;
         }
-      } else {
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) g[j].v[v] = x[j].v[v] = 0.f;
+      }
+      if (normalize) dot = group_sum(dot, lpr);
+      if (!valid) continue;
+      const float r = normalize ? rinv[row] : 1.f;
+      const bool clamped = normalize && !(r < 1.f / L2_EPS);   // ||h|| <= eps: F.normalize divided by the constant eps
+  #pragma unroll
+      for (int j = 0; j < MAXJ; ++j) {
+        const int c = (rg.sl + lpr * j) * VEC;
+        if (c < F) {
+          Vec<VEC> o;
+  #pragma unroll
+          for (int v = 0; v < VEC; ++v) {
+            const float gv = g[j].v[v];
+            o.v[v] = !normalize ? gv : (clamped ? gv * (1.f / L2_EPS) : r * (gv - x[j].v[v] * dot));
+            csum[0][j][v] += o.v[v];
+          }
+          o.store(dh + (size_t)row * F + c);
+        }
       }
     }
-    if (normalize) dot = group_sum(dot, lpr);
-    if (!valid) continue;
-    const float r = normalize ? rinv[row] : 1.f;
-    const bool clamped = normalize && !(r < 1.f / L2_EPS);   // ||h|| <= eps: F.normalize divided by the constant eps
-#pragma unroll
-    for (int j = 0; j < MAXJ; ++j) {
-      const int c = (rg.sl + lpr * j) * VEC;
-      if (c < F) {
-        Vec<VEC> o;
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) {
-          const float gv = g[j].v[v];
-          o.v[v] = !normalize ? gv : (clamped ? gv * (1.f / L2_EPS) : r * (gv - x[j].v[v] * dot));
-          csum[0][j][v] += o.v[v];
-        }
-        o.store(dh + (size_t)row * F + c);
-      }
-    }
+  };
+  switch (act) {
+    case CGC_ACT_RELU: rows(std::integral_constant<int, CGC_ACT_RELU>()); break;
+    case CGC_ACT_ELU: rows(std::integral_constant<int, CGC_ACT_ELU>()); break;
+    case CGC_ACT_LEAKYRELU: rows(std::integral_constant<int, CGC_ACT_LEAKYRELU>()); break;
+    default: rows(std::integral_constant<int, CGC_ACT_IDENTITY>()); break;
   }
   if (ws != nullptr) col_reduce_store<VEC, MAXJ, 1>(csum, F, lpr, smem, ws + (size_t)blockIdx.x * F);
 }
@@ -859,7 +893,7 @@ __global__ __launch_bounds__(256) void k_softmax_fwd_reg(const float* __restrict
     for (int j = 0; j < MAXJ; ++j) {
       const int c = (rg.sl + lpr * j) * VEC;
       if (valid && c < C) {
-        t[j].load(xr + c);
+        t[j].load(xr + c);          // (plain: streaming loads gain nothing on the in-place pass and cost the aggregation that reads S next 6 %)
 #pragma unroll
         for (int v = 0; v < VEC; ++v) m = fmaxf(m, t[j].v[v]);
       }
@@ -903,21 +937,25 @@ __global__ __launch_bounds__(256) void k_softmax_bwd(const float* __restrict__ S
 #pragma unroll
     for (int v = 0; v < VEC; ++v) csum[0][j][v] = 0.f;
   for (int base = rg.gwave * rg.rpw; base < n; base += rg.nwaves * rg.rpw) {
-    const int row = base + rg.sub;
-    const bool valid = row < n;
+    const int row = min(base + rg.sub, n - 1);
+    const bool valid = base + rg.sub < n;
     Vec<VEC> s[MAXJ], d[MAXJ];
     float dot = 0.f;
+    // unconditional loads, all requested before the first use (a chunk past C re-reads the row's last chunk and is zeroed below)
 #pragma unroll
     for (int j = 0; j < MAXJ; ++j) {
-      const int c = (rg.sl + lpr * j) * VEC;
-      if (valid && c < C) {
-        s[j].load(S + (size_t)row * ld + c);
-        d[j].load(dS + (size_t)row * ld + c);
+      const int c = min((rg.sl + lpr * j) * VEC, C - VEC);
+      load_wide<VEC, MAXJ>(s[j], S + (size_t)row * ld + c);
+      load_wide<VEC, MAXJ>(d[j], dS + (size_t)row * ld + c);
+    }
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) dot += s[j].v[v] * d[j].v[v];
-      } else {
+    for (int j = 0; j < MAXJ; ++j) {
+      const bool ok = valid && (rg.sl + lpr * j) * VEC < C;
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) s[j].v[v] = d[j].v[v] = 0.f;
+      for (int v = 0; v < VEC; ++v) {
+        s[j].v[v] = ok ? s[j].v[v] : 0.f;
+        d[j].v[v] = ok ? d[j].v[v] : 0.f;
+        dot += s[j].v[v] * d[j].v[v];
       }
     }
     dot = group_sum(dot, lpr);
@@ -1335,7 +1373,7 @@ __global__ __launch_bounds__(256) void k_adj_prep_fwd_reg(const float* __restric
     for (int j = 0; j < MAXJ; ++j) {
       const int c = (rg.sl + lpr * j) * VEC;
       if (valid && c < C) {
-        t[j].load(A + (size_t)row * C + c);
+        t[j].load(A + (size_t)row * C + c);      // (plain: no gain from a streaming load here)
 #pragma unroll
         for (int v = 0; v < VEC; ++v) s += (c + v == diag) ? 0.f : t[j].v[v];
       }
@@ -1394,13 +1432,13 @@ __global__ __launch_bounds__(256) void k_adj_prep_bwd_reg(const float* __restric
       const int c = (rg.sl + lpr * j) * VEC;
       if (valid && c < C) {
         Vec<VEC> an, a;
-        g[j].load(gAn + (size_t)row * C + c);
-        an.load(An + (size_t)row * C + c);
+        load_wide<VEC, MAXJ>(g[j], gAn + (size_t)row * C + c);
+        load_wide<VEC, MAXJ>(an, An + (size_t)row * C + c);
 #pragma unroll
         for (int v = 0; v < VEC; ++v) t1 += g[j].v[v] * an.v[v];
-        if (gAt != nullptr) h[j].load(gAt + (size_t)row * C + c);
+        if (gAt != nullptr) load_wide<VEC, MAXJ>(h[j], gAt + (size_t)row * C + c);
         if (renorm) {
-          a.load(A + (size_t)row * C + c);
+          load_wide<VEC, MAXJ>(a, A + (size_t)row * C + c);
 #pragma unroll
           for (int v = 0; v < VEC; ++v)
             if (c + v != diag) { s += a.v[v]; u += a.v[v] * g[j].v[v]; if (gAt != nullptr) w += a.v[v] * h[j].v[v]; }
