@@ -465,6 +465,9 @@ extern "C" int cgc_l2norm_act_bn(const float* h, int n, int F, int normalize, in
 // ------------------------------------------------------------------------------------------------
 // y = BN(act(hn))   (elementwise; y may be a column slice of a wider buffer: ldy)
 // ------------------------------------------------------------------------------------------------
+#ifndef CGC_BNAPPLY_UR
+#define CGC_BNAPPLY_UR 1
+#endif
 template <int VEC, int MAXJ>
 __global__ __launch_bounds__(256) void k_bn_act_apply(const BnApplyPtrs p0, const BnApplyPtrs p1, int n, int F, int lpr, int act, int ldy) {
   const BnApplyPtrs& p = blockIdx.y ? p1 : p0;
@@ -509,20 +512,28 @@ __global__ __launch_bounds__(256) void k_bn_act_apply(const BnApplyPtrs p0, cons
   auto rows = [&](auto act_c) {
     constexpr int ACT = decltype(act_c)::value;
     const int last = F - VEC;                            // (F >= VEC: F % VEC == 0 and F > 0)
-    for (int base = rg.gwave * rg.rpw; base < n; base += rg.nwaves * rg.rpw) {
-      const int row = min(base + rg.sub, n - 1);
-      const bool rowok = base + rg.sub < n;
-      Vec<VEC> x[MAXJ];
+    constexpr int UR = (VEC == 4 && MAXJ == 5) ? CGC_BNAPPLY_UR : 1;      // adjacent rows per pass (-DCGC_BNAPPLY_UR; 1: 96 us, 2: 103, 4: 91 on [57.7k, 1140])
+    for (int base = rg.gwave * rg.rpw * UR; base < n; base += rg.nwaves * rg.rpw * UR) {
+      Vec<VEC> x[UR][MAXJ];
 #pragma unroll
-      for (int j = 0; j < MAXJ; ++j) load_wide<VEC, MAXJ>(x[j], hn + (size_t)row * F + min((rg.sl + lpr * j) * VEC, last));
+      for (int u = 0; u < UR; ++u) {
+        const int row = min(base + u * rg.rpw + rg.sub, n - 1);
 #pragma unroll
-      for (int j = 0; j < MAXJ; ++j) {
-        const int c = (rg.sl + lpr * j) * VEC;
+        for (int j = 0; j < MAXJ; ++j) load_wide<VEC, MAXJ>(x[u][j], hn + (size_t)row * F + min((rg.sl + lpr * j) * VEC, last));
+      }
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) x[j].v[v] = fmaf(act_fwd(x[j].v[v], ACT) - mu[j][v], sc[j][v], sh[j][v]);
-        if (rowok && c < F) {
-          x[j].store(y + (size_t)row * ldy + c);
-          if (y2 != nullptr) x[j].store(y2 + (size_t)row * ldy2 + c);
+      for (int u = 0; u < UR; ++u) {
+        const int row = base + u * rg.rpw + rg.sub;
+        const bool rowok = row < n;
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j) {
+          const int c = (rg.sl + lpr * j) * VEC;
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) x[u][j].v[v] = fmaf(act_fwd(x[u][j].v[v], ACT) - mu[j][v], sc[j][v], sh[j][v]);
+          if (rowok && c < F) {
+            x[u][j].store(y + (size_t)row * ldy + c);
+            if (y2 != nullptr) x[u][j].store(y2 + (size_t)row * ldy2 + c);
+          }
         }
       }
     }
@@ -689,9 +700,14 @@ __global__ __launch_bounds__(256) void k_bn_act_l2_bwd(const float* __restrict__
     }
     __syncthreads();
   }
-  // (the activation switch outside the row loop: see k_bn_act_apply)
-  auto rows = [&](auto act_c) {
+  // (the activation switch outside the row loop: see k_bn_act_apply; the training configuration -- batch statistics + l2norm -- is a
+  // compile-time case of its own, every other combination keeps the run-time flags)
+  auto rows = [&](auto act_c, auto hot_c) {
     constexpr int ACT = decltype(act_c)::value;
+    constexpr bool HOT = decltype(hot_c)::value;
+    const int mode_rt = mode, normalize_rt = normalize;
+    const int mode = HOT ? 2 : mode_rt;
+    const int normalize = HOT ? 1 : normalize_rt;
     for (int base = rg.gwave * rg.rpw; base < n; base += rg.nwaves * rg.rpw) {
       const int row = min(base + rg.sub, n - 1);
       const bool valid = base + rg.sub < n;
@@ -756,11 +772,20 @@ __global__ __launch_bounds__(256) void k_bn_act_l2_bwd(const float* __restrict__
       }
     }
   };
-  switch (act) {
-    case CGC_ACT_RELU: rows(std::integral_constant<int, CGC_ACT_RELU>()); break;
-    case CGC_ACT_ELU: rows(std::integral_constant<int, CGC_ACT_ELU>()); break;
-    case CGC_ACT_LEAKYRELU: rows(std::integral_constant<int, CGC_ACT_LEAKYRELU>()); break;
-    default: rows(std::integral_constant<int, CGC_ACT_IDENTITY>()); break;
+  if (mode == 2 && normalize) {
+    switch (act) {
+      case CGC_ACT_RELU: rows(std::integral_constant<int, CGC_ACT_RELU>(), std::true_type()); break;
+      case CGC_ACT_ELU: rows(std::integral_constant<int, CGC_ACT_ELU>(), std::true_type()); break;
+      case CGC_ACT_LEAKYRELU: rows(std::integral_constant<int, CGC_ACT_LEAKYRELU>(), std::true_type()); break;
+      default: rows(std::integral_constant<int, CGC_ACT_IDENTITY>(), std::true_type()); break;
+    }
+  } else {
+    switch (act) {
+      case CGC_ACT_RELU: rows(std::integral_constant<int, CGC_ACT_RELU>(), std::false_type()); break;
+      case CGC_ACT_ELU: rows(std::integral_constant<int, CGC_ACT_ELU>(), std::false_type()); break;
+      case CGC_ACT_LEAKYRELU: rows(std::integral_constant<int, CGC_ACT_LEAKYRELU>(), std::false_type()); break;
+      default: rows(std::integral_constant<int, CGC_ACT_IDENTITY>(), std::false_type()); break;
+    }
   }
   if (ws != nullptr) col_reduce_store<VEC, MAXJ, 1>(csum, F, lpr, smem, ws + (size_t)blockIdx.x * F);
 }
