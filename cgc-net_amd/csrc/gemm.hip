@@ -71,8 +71,9 @@ struct KContigLoader {
     }
   }
   static __device__ __forceinline__ unsigned tile_soffset(int /*ld*/, int k0) { return (unsigned)k0 * 4u; }   // bytes from the operand base
+  template <int AUX = 0>
   __device__ __forceinline__ void load_buf_part(int i, __amdgpu_buffer_rsrc_t rsrc, const unsigned (&off)[PER_T], unsigned soff) {
-    reg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[i], soff, 0));
+    reg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[i], soff, AUX));
   }
   // Partial k-tile (k_lim % 4 == 0), still branch-free: units past the end of K re-read the last valid 16 bytes of their
   // row and are zeroed with a select -- the guarded loader above costs ~0.75 of a full tile's time on top of its own.
@@ -154,8 +155,9 @@ struct MnContigLoader {
     }
   }
   static __device__ __forceinline__ unsigned tile_soffset(int ld, int k0) { return (unsigned)k0 * (unsigned)ld * 4u; }
+  template <int AUX = 0>
   __device__ __forceinline__ void load_buf_part(int i, __amdgpu_buffer_rsrc_t rsrc, const unsigned (&off)[PER_T], unsigned soff) {
-    reg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[i], soff, 0));
+    reg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[i], soff, AUX));
   }
   // Partial k-tile: rows (k) past the end re-read row k_lim-1 and are zeroed.
   __device__ __forceinline__ void load_fast_masked(const float* __restrict__ base, int ld, int col0, int col_last4, int k0, int k_lim) {
@@ -194,6 +196,13 @@ __device__ __forceinline__ void fetch_frag(const float* __restrict__ tile, int k
 
 // FAST: every operand segment qualifies for the unguarded 16-byte loaders (decided on the host, gemm_all_fast): the kernel then
 // contains no guarded loader and no conditional inside a k-loop phase.  !FAST: the guarded element-wise loaders throughout.
+// cache policy of the pinned operand loads (buffer-load aux bits; 2 = nt: streaming) -- -DCGC_GEMM_A_AUX / _B_AUX for A/B timing
+#ifndef CGC_GEMM_A_AUX
+#define CGC_GEMM_A_AUX 0
+#endif
+#ifndef CGC_GEMM_B_AUX
+#define CGC_GEMM_B_AUX 0
+#endif
 template <int WGM, int WGN, int TM, int TN, bool TA, bool TB, bool FAST>
 __global__ __launch_bounds__(256, 2) void k_gemm_f32(const GemmArgs a) {   // 2 waves per SIMD = 2 workgroups per CU (the LDS budget)
   GT_MARK(0)
@@ -408,8 +417,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const GemmArgs a) {   // 2 
             if (kb < LoaderB::PER_T) ls_b.store_part(kb, bn);
           }
           if (t == 2) {
-            if (kb < LoaderA::PER_T) ll_a.load_buf_part(kb, rsrcA, offA, LoaderA::tile_soffset(a.lda, (kt + 2) * BK));
-            if (kb < LoaderB::PER_T) ll_b.load_buf_part(kb, rsrcB, offB, LoaderB::tile_soffset(a.ldb, (kt + 2) * BK));
+            if (kb < LoaderA::PER_T) ll_a.template load_buf_part<CGC_GEMM_A_AUX>(kb, rsrcA, offA, LoaderA::tile_soffset(a.lda, (kt + 2) * BK));
+            if (kb < LoaderB::PER_T) ll_b.template load_buf_part<CGC_GEMM_B_AUX>(kb, rsrcB, offB, LoaderB::tile_soffset(a.ldb, (kt + 2) * BK));
           }
           __builtin_amdgcn_sched_barrier(0);
         }

@@ -555,7 +555,7 @@ __global__ __launch_bounds__(256, CGC_SWC_WAVES) void k_sage_wide_cols(const flo
 #ifndef CGC_SWC_NOMFMA
       for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bw[t][s], acc[t], 0, 0, 0);
 #else
-      for (int t = 0; t < NT; ++t) acc[t][s % 16] += av[s] * bw[t][s];
+      for (int t = 0; t < NT; ++t) acc[t][s % 16] = av[s] + bw[t][s];        // (timing ablation: no matrix instruction, no chain)
 #endif
     // This tile's row factors and the next tile's A fragments are requested behind this tile's MFMAs and waited for in front of its
     // stores (vmcnt counts loads and stores in issue order: see k_sage_wide_fwd8).  (Requesting them INSIDE the chains -- step s's
@@ -610,7 +610,7 @@ __global__ __launch_bounds__(256, CGC_SWC_WAVES) void k_sage_wide_cols(const flo
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc_hn, voff,
                                                 (unsigned)(row0 + (r & 3) + 8 * (r >> 2)) * (unsigned)ldh * 4u, 0);
 #else
-          if (v == 123.456f) hn[0] = v;
+          asm volatile("" ::"v"(v));          // (timing ablation: the value stays computed, nothing is stored)
 #endif
         }
       } else {
@@ -682,7 +682,9 @@ extern "C" int cgc_sage_wide_fwd(const float* agg, int lda, const float* W, cons
     // round 5: row norms from the K x K quadratic form, then one wave per 32 rows x 96 columns (see k_sage_wide_cols)
     static const int use_cols = getenv("CGC_SAGE_WIDE_COLS") ? atoi(getenv("CGC_SAGE_WIDE_COLS")) : 1;
     static const int cols_chunks = getenv("CGC_SAGE_WIDE_CHUNKS") ? atoi(getenv("CGC_SAGE_WIDE_CHUNKS")) : 256;
-    if (use_cols && normalize && K <= 21 && n >= 64 && (long long)n * ldh * 4 < (1LL << 31) && (reinterpret_cast<uintptr_t>(hn) & 7u) == 0 &&
+    // (small launches keep the one-kernel form: at 7200 rows -- a 4-graph shard -- two more launches cost more than the wave-level kernel saves)
+    static const int cols_min_rows = getenv("CGC_SAGE_WIDE_COLS_MIN") ? atoi(getenv("CGC_SAGE_WIDE_COLS_MIN")) : 12288;
+    if (use_cols && normalize && K <= 21 && n >= cols_min_rows && n >= 64 && (long long)n * ldh * 4 < (1LL << 31) && (reinterpret_cast<uintptr_t>(hn) & 7u) == 0 &&
         aligned16(rinv) && (size_t)n * ldh * 4 >= sizeof(double) * (size_t)(K * (K + 1) / 2 + K + 1) && ((long long)(n - 1) * lda + K) * 4 < (1LL << 31)) {
       int per = ceil_div(row_tiles, cols_chunks > 0 ? cols_chunks : 256);
       int chunks = ceil_div(row_tiles, per);

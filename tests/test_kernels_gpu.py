@@ -605,7 +605,9 @@ def test_fused_statistics_and_finalize(n, F):
 
 @pytest.mark.parametrize('n,K_,F,lda', [(1, 20, 256, 20), (37, 20, 1140, 40), (1000, 16, 1600, 16), (4100, 20, 1140, 40), (300, 7, 257, 12),
                                          (50, 32, 200, 32), (50, 20, 1700, 20), (50, 33, 512, 36),
-                                         (1000, 20, 20, 40), (37, 16, 20, 16), (5, 32, 32, 32), (4100, 20, 18, 20), (1, 8, 4, 8)])
+                                         (1000, 20, 20, 40), (37, 16, 20, 16), (5, 32, 32, 32), (4100, 20, 18, 20), (1, 8, 4, 8),
+                                         # >= 12288 rows: the quadratic-form row norms + one wave per 32 x 96 block (k_sage_wide_cols)
+                                         (12301, 20, 1140, 40), (13000, 16, 1600, 16), (12800, 21, 320, 24), (12290, 7, 257, 12)])
 @pytest.mark.parametrize('stats,act', [(True, 1), (False, 1), (True, 2), (True, 3), (False, 0)])
 def test_fused_wide_sage_forward(n, K_, F, lda, stats, act):
     """cgc_sage_wide_fwd: rank-K projection + bias + L2 normalisation (+ BatchNorm statistics, running stats, batch counter) in one
@@ -634,7 +636,7 @@ def test_fused_wide_sage_forward(n, K_, F, lda, stats, act):
         close(res['hip'][i], res['ref'][i], TOL, 'sage_wide %d' % i)
 
 
-@pytest.mark.parametrize('n,F', [(1000, 200), (4100, 1140), (97, 1140), (65, 33)])
+@pytest.mark.parametrize('n,F', [(1000, 200), (4100, 1140), (97, 1140), (65, 33), (12301, 1140), (20011, 264)])
 def test_fused_wide_sage_forward_writes_nothing_past_its_rows(n, F):
     """The partial last row tile of cgc_sage_wide_fwd (n % 32 != 0): the rows of the tile that lie past n must not be stored -- hn
     sits inside a larger canary-filled allocation here (in the step: the next arena region)."""
@@ -649,6 +651,36 @@ def test_fused_wide_sage_forward_writes_nothing_past_its_rows(n, F):
     torch.cuda.synchronize()
     assert float(big[n:].min()) == 7.0 and float(big[n:].max()) == 7.0
     assert float((big[:n].norm(dim=1) - 1.0).abs().max()) < 1e-5          # the rows themselves were written (unit norm)
+
+
+def test_wide_sage_row_norms_from_the_quadratic_form():
+    """The large-launch route of cgc_sage_wide_fwd takes 1 / ||agg W + b|| from agg^T (W W^T) agg + 2 agg . (W b) + b . b in double
+    (k_sage_gram + k_sage_rinv) instead of from the projected row: rows of very different scales, rows whose projection is zero
+    (zero input under a zero bias: the reference's F.normalize divides by eps = 1e-12 and the row stays zero) and the no-bias form
+    must give the float64 norm to float32 rounding, and unit rows."""
+    k = hip()
+    n, K_, F = 12288 + 77, 20, 1140
+    g = torch.Generator().manual_seed(3)
+    agg = torch.randn(n, K_, generator=g)
+    agg[5] = 0.0
+    agg[100:200] *= 1e3
+    agg[200:300] *= 1e-3
+    agg[n - 1] = 0.0
+    W = torch.randn(K_, F, generator=g) * 0.2
+    for bias in (torch.zeros(F), torch.randn(F, generator=g) * 0.1, None):
+        hn, rinv = torch.full((n, F), 7.0, device=DEV), torch.empty(n, device=DEV)
+        assert k.sage_wide_fwd(agg.to(DEV), K_, W.to(DEV), None if bias is None else bias.to(DEV), n, K_, F, True, 1, hn, rinv, False, float(n),
+                               1e-5, 0.1, None, None, None, None, None)
+        torch.cuda.synchronize()
+        h = agg.double() @ W.double() + (0.0 if bias is None else bias.double())
+        nrm = h.norm(dim=1)
+        want = 1.0 / nrm.clamp_min(1e-12)
+        assert float((rinv.double().cpu() / want - 1.0).abs().max()) < 3e-7
+        ref = h / nrm.clamp_min(1e-12)[:, None]
+        assert float((hn.double().cpu() - ref).abs().max()) < 2e-7
+        zero = nrm == 0
+        if bool(zero.any()):
+            assert float(hn.cpu()[zero].abs().max()) == 0.0 and float(rinv.cpu()[zero].min()) == float(torch.tensor(1e12, dtype=torch.float32))
 
 
 @pytest.mark.parametrize('n,fin,F', [(1, 20, 20), (37, 16, 20), (1000, 20, 20), (4100, 20, 18), (333, 8, 32), (64, 32, 8), (50, 20, 33)])
@@ -1030,7 +1062,7 @@ def test_wide_spmm_and_softmax_with_padded_rows(width, ld):
 
 
 @pytest.mark.parametrize('path,n,Kin,F', [('rows', 3000, 0, 20), ('rows', 900, 0, 1140), ('narrow', 3000, 20, 20), ('narrow', 5000, 8, 8),
-                                          ('wide', 2500, 20, 1140), ('wide', 700, 16, 114)])
+                                          ('wide', 2500, 20, 1140), ('wide', 700, 16, 114), ('wide', 13000, 20, 1140)])
 def test_forward_bn_statistics_survive_small_variance(path, n, Kin, F):
     """BatchNorm's batch variance where the rows are nearly identical (std ~ 1/100 of the mean per column: the coarsened levels,
     whose clusters have near-identical content).  The statistics are a difference of sums: carried in fp32 they lose
