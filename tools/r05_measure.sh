@@ -15,7 +15,7 @@ bash tools/prof_gaps.sh r05_c3_nogc --no-split-leg --no-gc > /dev/null 2>&1
 bash tools/prof_gaps.sh r05_b4 --batch 4 --no-split-leg > /dev/null 2>&1
 PMC_PASSES=3 bash tools/pmc_run.sh r05_sq "" -- $B --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-split-leg > /dev/null 2>&1
 PMC_PASSES=3 bash tools/pmc_run.sh r05_sqs "" -- $B --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-split-leg --gemm-mode 1 > /dev/null 2>&1
-K='^kernel|^k_gemm_f32<2, 2, 2, 2|^k_spmm_wide|^k_jku_bwd<20|^k_jku_fwd<20|^k_gemm_f32<2, 2, 1, 1|^k_gemm_f32<4, 1, 1, 1|^k_gemm_f32_shortk<2, 2, 2, 2|^k_sage_wide_fwd|^k_gemm_fixup|^k_gemm_split'
+K='^kernel|^k_gemm_f32<2, 2, 2, 2|^k_spmm_wide|^k_jku_bwd<20|^k_jku_fwd<20|^k_gemm_f32<2, 2, 1, 1|^k_gemm_f32<4, 1, 1, 1|^k_gemm_f32_shortk<2, 2, 2, 2|^k_sage_wide|^k_sage_gram|^k_sage_rinv|^k_bn_act|^k_bn_bwd_reduce<4, 5|^k_softmax|^k_adj_prep|^k_gemm_fixup|^k_gemm_split'
 grep -E "$K" gpurun_out/r05_sq_pmc.txt > gpurun_out/r05_bench_c3_pmc_sq.txt
 grep -E "$K" gpurun_out/r05_sqs_pmc.txt > gpurun_out/r05_bench_c3_split_pmc_sq.txt
 python profiles/make_counters_json.py gpurun_out/r05_bench_c3_pmc_sq.txt gpurun_out/r05_bench_c3_split_pmc_sq.txt > gpurun_out/r05_counters.json
