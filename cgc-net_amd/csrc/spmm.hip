@@ -215,11 +215,7 @@ __global__ __launch_bounds__(256) void k_spmm_wide(const int* __restrict__ rowpt
     for (; k + U <= e; k += U) wide_batch<U, VAL, PERM, PRE>(col, perm, val, pre, xl, ld, k, acc);
     wide_tail<U - 1, VAL, PERM, PRE>(e - k, col, perm, val, pre, xl, ld, k, acc);   // exactly as many gathers as entries left
     if (post != nullptr) acc *= post[r];
-#ifndef CGC_SPMM_PLAIN_STORE      // (-DCGC_SPMM_PLAIN_STORE: A/B timing)
     __builtin_nontemporal_store(acc, reinterpret_cast<f4v*>(out + (size_t)r * ld + c0));
-#else
-    *reinterpret_cast<f4v*>(out + (size_t)r * ld + c0) = acc;
-#endif
     s = e;
   }
 }
