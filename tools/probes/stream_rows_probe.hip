@@ -91,6 +91,46 @@ __global__ __launch_bounds__(256) void k_flat(const float* __restrict__ x, const
   }
 }
 
+// the library kernel's form: unconditional loads from clamped addresses (a chunk past F re-reads the row's last chunk), stores predicated
+template <int ROWS, bool NTL>
+__global__ __launch_bounds__(256) void k_rows_clamped(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ scale,
+                                                      const float* __restrict__ shift, float* __restrict__ y, int n, int F, int ldy) {
+  const int lane = threadIdx.x & 63, gw = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
+  float mu[5][4], sc[5][4], sh[5][4];
+#pragma unroll
+  for (int j = 0; j < 5; ++j)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int c = min((lane + 64 * j) * 4 + v, F - 1);
+      mu[j][v] = mean[c]; sc[j][v] = scale[c]; sh[j][v] = shift[c];
+    }
+  const int last = F - 4;
+  for (int base = gw * ROWS; base < n; base += nw * ROWS) {
+    float4 v[ROWS][5];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      const int row = min(base + r, n - 1);
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        const float4* p = reinterpret_cast<const float4*>(x + (size_t)row * F + min((lane + 64 * j) * 4, last));
+        if (NTL) { const vf4 t = __builtin_nontemporal_load(reinterpret_cast<const vf4*>(p)); v[r][j] = make_float4(t.x, t.y, t.z, t.w); } else v[r][j] = *p;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        const int c = (lane + 64 * j) * 4;
+        float4 o;
+        o.x = fmaf(fmaxf(v[r][j].x, 0.f) - mu[j][0], sc[j][0], sh[j][0]);
+        o.y = fmaf(fmaxf(v[r][j].y, 0.f) - mu[j][1], sc[j][1], sh[j][1]);
+        o.z = fmaf(fmaxf(v[r][j].z, 0.f) - mu[j][2], sc[j][2], sh[j][2]);
+        o.w = fmaf(fmaxf(v[r][j].w, 0.f) - mu[j][3], sc[j][3], sh[j][3]);
+        if (c < F && base + r < n) *reinterpret_cast<float4*>(y + (size_t)(base + r) * ldy + c) = o;
+      }
+  }
+}
+
 template <typename L>
 static void timeit(const char* name, int blocks, L launch, double mb) {
   hipEvent_t e0, e1;
@@ -126,6 +166,13 @@ int main() {
     timeit("flat<1> constants in LDS", blocks, [&](int b) { hipLaunchKernelGGL((k_flat<1>), dim3(b), dim3(256), 3 * F * 4, 0, x, mean, scale, shift, y, n, F); }, mb);
     timeit("flat<4> constants in LDS", blocks, [&](int b) { hipLaunchKernelGGL((k_flat<4>), dim3(b), dim3(256), 3 * F * 4, 0, x, mean, scale, shift, y, n, F); }, mb);
     timeit("flat<8> constants in LDS", blocks, [&](int b) { hipLaunchKernelGGL((k_flat<8>), dim3(b), dim3(256), 3 * F * 4, 0, x, mean, scale, shift, y, n, F); }, mb);
+  }
+  for (int blocks : {1024, 2048}) {
+    timeit("rows<1> nontemporal loads", blocks, [&](int b) { hipLaunchKernelGGL((k_rows<1, true, false>), dim3(b), dim3(256), 0, 0, x, mean, scale, shift, y, n, F); }, mb);
+    timeit("rows<4> nontemporal loads", blocks, [&](int b) { hipLaunchKernelGGL((k_rows<4, true, false>), dim3(b), dim3(256), 0, 0, x, mean, scale, shift, y, n, F); }, mb);
+    timeit("clamped rows<1> plain loads", blocks, [&](int b) { hipLaunchKernelGGL((k_rows_clamped<1, false>), dim3(b), dim3(256), 0, 0, x, mean, scale, shift, y, n, F, F); }, mb);
+    timeit("clamped rows<1> nontemporal loads", blocks, [&](int b) { hipLaunchKernelGGL((k_rows_clamped<1, true>), dim3(b), dim3(256), 0, 0, x, mean, scale, shift, y, n, F, F); }, mb);
+    timeit("clamped rows<2> nontemporal loads", blocks, [&](int b) { hipLaunchKernelGGL((k_rows_clamped<2, true>), dim3(b), dim3(256), 0, 0, x, mean, scale, shift, y, n, F, F); }, mb);
   }
   timeit("flat<4> constants in LDS", 16384, [&](int b) { hipLaunchKernelGGL((k_flat<4>), dim3(b), dim3(256), 3 * F * 4, 0, x, mean, scale, shift, y, n, F); }, mb);
   CHECK(hipMemcpyAsync(y, x, (size_t)n * F * 4, hipMemcpyDeviceToDevice, 0));
