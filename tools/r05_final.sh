@@ -11,3 +11,4 @@ bash tools/r05_measure.sh > gpurun_out/r05_measure.log 2>&1
 python tools/stream_probe.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r05_stream.txt
 hipcc --offload-arch=gfx950 -O3 -o /tmp/stream_rows_probe tools/probes/stream_rows_probe.hip && /tmp/stream_rows_probe >> gpurun_out/r05_stream.txt 2>&1
 tail -12 gpurun_out/r05_measure.log
+(python tools/thin_probe.py; THIN_COLD=1 python tools/thin_probe.py) 2>&1 | grep "^N \|^read" > gpurun_out/r05_thin_products.txt
