@@ -22,6 +22,13 @@ __global__ void k_hist_rows(const int64_t* __restrict__ ei, int64_t E, int n, in
   }
 }
 
+__global__ __launch_bounds__(256) void k_zero_ints(int* __restrict__ p, int count) {
+  const int i = (blockIdx.x * 256 + threadIdx.x) * 4;
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+    if (i + u < count) p[i + u] = 0;
+}
+
 // exclusive scan of in[0..n) into out[0..n], out[n] = total.  One workgroup of 1024 threads, each owning a contiguous slice.
 __global__ __launch_bounds__(1024) void k_exclusive_scan(const int* __restrict__ in, int* __restrict__ out, int n) {
   __shared__ int wave_tot[16];
@@ -216,7 +223,9 @@ extern "C" int cgc_csr_build(const int64_t* edge_index, int64_t E, int n, int ad
   const int g_edges = (int)(ceil_div64(cap64 > 0 ? cap64 : 1, tb) < 4096 ? ceil_div64(cap64 > 0 ? cap64 : 1, tb) : 4096);
   const int g_rows = ceil_div(n, tb);
 
-  (void)hipMemsetAsync(cnt, 0, sizeof(int) * 3 * (size_t)(n + 1), stream);   // cnt, start, cursor
+  // (one launch each: hipMemsetAsync of a size that is not a multiple of its fill width is TWO runtime kernels -- six fill launches
+  // per build, 28 us of a step, for the three memsets that stood here)
+  hipLaunchKernelGGL(k_zero_ints, dim3(ceil_div(3 * (n + 1), 1024)), dim3(256), 0, stream, cnt, 3 * (n + 1));   // cnt, start, cursor
   hipLaunchKernelGGL(k_hist_rows, dim3(g_edges), dim3(tb), 0, stream, edge_index, E, n, add_diag, cnt);
   exclusive_scan(cnt, start, n, scan_ws, scan_ints, stream);
   hipLaunchKernelGGL(k_fill_rows, dim3(g_edges), dim3(tb), 0, stream, edge_index, E, n, add_diag, start, cursor, colraw);
@@ -226,8 +235,7 @@ extern "C" int cgc_csr_build(const int64_t* edge_index, int64_t E, int n, int ad
                      ws + cgc_csr_bad_edges_offset(E, n, add_diag));
   CGC_RETURN_IF_LAUNCH_FAILED();
 
-  (void)hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)(n + 1), stream);
-  (void)hipMemsetAsync(cursor, 0, sizeof(int) * (size_t)(n + 1), stream);
+  hipLaunchKernelGGL(k_zero_ints, dim3(ceil_div(3 * (n + 1), 1024)), dim3(256), 0, stream, cnt, 3 * (n + 1));   // cnt, (start: dead by now), cursor
   hipLaunchKernelGGL(k_hist_cols, dim3(g_edges), dim3(tb), 0, stream, rowptr, n, col, cap, cnt);
   exclusive_scan(cnt, t_rowptr, n, scan_ws, scan_ints, stream);
   hipLaunchKernelGGL(k_fill_cols, dim3(g_edges), dim3(tb), 0, stream, rowptr, n, col, rowidx, cap, t_rowptr, cursor, t_col, t_perm);
