@@ -793,7 +793,7 @@ def test_segment_max(D):
         assert torch.equal(full.cpu(), wdx)
 
 
-@pytest.mark.parametrize('B_,C', [(3, 4), (2, 16), (3, 60), (2, 114), (2, 180), (1, 1140)])
+@pytest.mark.parametrize('B_,C', [(3, 4), (2, 16), (3, 60), (2, 114), (2, 180), (1, 1140), (1, 1600)])
 def test_dense_adjacency_transforms(B_, C):
     R = B_ * C
     A = rnd(B_, C, C, seed=C).abs()
@@ -814,7 +814,7 @@ def test_dense_adjacency_transforms(B_, C):
         close(x, y, 2e-5, 'dense transform %d' % i)
 
 
-@pytest.mark.parametrize('B_,C', [(3, 4), (2, 18), (3, 60), (2, 114), (1, 1140)])
+@pytest.mark.parametrize('B_,C', [(3, 4), (2, 18), (3, 60), (2, 114), (1, 1140), (1, 1600)])
 @pytest.mark.parametrize('p', [None, 0.4])
 @pytest.mark.parametrize('second_stream', [False, True])
 def test_fused_adjacency_preparation(B_, C, p, second_stream):
