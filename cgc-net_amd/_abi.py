@@ -3,7 +3,7 @@ import ctypes as C
 
 P, I, F, D, L = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_int64
 
-ABI_VERSION = 3      # = CGC_ABI_VERSION of include/cgc_hip.h these prototypes were written against (tests compare the two)
+ABI_VERSION = 4      # = CGC_ABI_VERSION of include/cgc_hip.h these prototypes were written against (tests compare the two)
 
 PROTOTYPES = {
     'cgc_abi_version': [],
@@ -66,9 +66,6 @@ PROTOTYPES = {
     'cgc_dense_renorm_fwd': [P, I, I, F, P, P],
     'cgc_dense_renorm_bwd': [P, P, I, I, F, P, P],
     'cgc_adj_prep_fwd': [P, I, I, F, P, P, P, P, P],
-    'cgc_adj_prep_fwd2': [P, I, I, F, P, P, P, P, P, P],
-    'cgc_adj_grad_operands': [P, P, I, P, P, P, P, I, P, I, I, P, P, P, I, F, P, P, I, P],
-    'cgc_zero_diag': [P, I, I, P],
     'cgc_adj_prep_bwd': [P, P, P, P, P, P, I, I, F, P, P],
     'cgc_head_fwd': [P, I, I, I, I, I, I, P, P, P, P, P, F, C.c_uint64, P, P, P, P],
     'cgc_head_bwd': [P, I, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P],

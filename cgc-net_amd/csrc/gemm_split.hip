@@ -302,7 +302,11 @@ __global__ __launch_bounds__(256, 1) void k_gemm_split(const GemmArgs a) {
   const unsigned wa_off = LoaderA::wbase(), wb_off = 3 * S_PLA + LoaderB::wbase();
 
   SplitFrags fr;
-  // ---- prologue: tiles 0, 1 split into stages 0, 1; tiles 2, 3 in flight in the two sets; all fragments of tile 0 in registers
+  // ---- prologue: tiles 0, 1 split into stages 0, 1; tiles 2, 3 in flight in the two sets; all fragments of tile 0 in registers.
+  // An EMPTY k range (an empty graph of a ragged-K batch; a tail-split piece of a graph with fewer k-tiles than pieces) loads
+  // nothing -- there is no valid tile to clamp to (kbeg - 1 would be rows of the previous graph, or in front of the operand) --
+  // and goes straight to the epilogue / its slab with zero accumulators, as k_gemm_f32 does (gemm.hip: `if (kend > kbeg)`).
+  if (n > 0) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) {               // q: 0, 1 request tiles 0, 1; 2: split 0, request 2; 3: split 1, request 3
     const int set = q & 1;
@@ -330,6 +334,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_split(const GemmArgs a) {
 #pragma unroll
     for (int p = 0; p < 3; ++p) fr.b[j][p] = frag16(slds + fb_off + j * 32 * SROW + p * S_PLB);
   __syncthreads();                            // (step 0 writes tile 2 into stage 0: everybody has read tile 0 out of it)
+  }
 
   auto tile_step = [&](auto pos_c, auto full_c, int lt) {
     constexpr int POS = decltype(pos_c)::value;          // local tile index mod 2

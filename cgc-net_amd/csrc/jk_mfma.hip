@@ -48,7 +48,21 @@ __device__ __forceinline__ float fast_sigmoid(float x) { return 1.f / (1.f + exp
 __device__ __forceinline__ float fast_tanh(float x) { return tanhf(x); }
 #define JK_EXP expf
 #else
-__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.f + __expf(-x)); }
+// Reciprocal of d in [1, inf]: v_rcp_f32 (1 ulp) instead of the correctly rounded division sequence the library's compile flags
+// turn __frcp_rn / `1.f / d` into (v_div_scale x 2, v_rcp, five FMAs, v_div_fmas, v_div_fixup: ten instructions, five times per
+// hidden unit and recurrence step in kernels that issue 8 vector instructions per MFMA).  The error stays RELATIVE (what the
+// medium_shipped margins are sensitive to: see fast_tanh) and below that of the __expf in front of it.  JK_RCP_NEWTON adds one
+// Newton step (two FMAs, ~0.5 ulp; the argument is clamped so that d stays finite: rcp(inf) = 0 and 0 * inf would poison it).
+#ifdef JK_RCP_NEWTON
+__device__ __forceinline__ float jk_rcp(float d) {
+  const float r = __builtin_amdgcn_rcpf(d);
+  return fmaf(fmaf(-d, r, 1.f), r, r);
+}
+__device__ __forceinline__ float fast_sigmoid(float x) { return jk_rcp(1.f + __expf(fminf(-x, 87.f))); }
+#else
+__device__ __forceinline__ float jk_rcp(float d) { return __builtin_amdgcn_rcpf(d); }
+__device__ __forceinline__ float fast_sigmoid(float x) { return jk_rcp(1.f + __expf(-x)); }
+#endif
 // tanh with a few ulp of RELATIVE error everywhere.  The one-line form 2 / (1 + exp(-2x)) - 1 has ~2e-7 of ABSOLUTE error, i.e.
 // 2e-6 relative at |x| = 0.1 and 2e-4 at 1e-3 -- cell states and gate inputs of a freshly initialised LSTM are that small, and on
 // the reference-generated medium_shipped fixture the network amplifies it a thousandfold (a one-ulp perturbation of the parameters
@@ -58,7 +72,7 @@ __device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.f + 
 __device__ __forceinline__ float fast_tanh(float x) {
   const float ax = fabsf(x), x2 = x * x;
   const float e = __expf(-2.f * ax);
-  const float big = (1.f - e) * __frcp_rn(1.f + e);
+  const float big = (1.f - e) * jk_rcp(1.f + e);
   const float small = ax * fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, 62.f / 2835.f, -17.f / 315.f), 2.f / 15.f), -1.f / 3.f), 1.f);
   return copysignf(ax < 0.25f ? small : big, x);
 }

@@ -1276,8 +1276,7 @@ __global__ __launch_bounds__(256) void k_dense_renorm_bwd(const float* __restric
 // from L2 (a row is 4.5 KB).  p < 0: no re-normalisation (At is not written; pass At = NULL).
 template <int VEC>
 __global__ __launch_bounds__(256) void k_adj_prep_fwd(const float* __restrict__ A, int R, int C, int lpr, float p, float* __restrict__ At,
-                                                      float* __restrict__ An, float* __restrict__ invd, float* __restrict__ ge1,
-                                                      float* __restrict__ rq) {
+                                                      float* __restrict__ An, float* __restrict__ invd, float* __restrict__ ge1) {
   const RowGroup rg(lpr);
   const bool renorm = p >= 0.f;
   const float omp = 1.f - p;
@@ -1323,7 +1322,6 @@ __global__ __launch_bounds__(256) void k_adj_prep_fwd(const float* __restrict__ 
     if (rg.sl == 0) {
       invd[row] = inv;
       ge1[row] = st >= 1.f ? 1.f : 0.f;
-      if (rq != nullptr) rq[row] = 1.f / den;          // 1 / (off-diagonal row sum + eps): the re-normalisation's row factor is (1 - p) * rq
     }
   }
 }
@@ -1383,8 +1381,7 @@ __global__ __launch_bounds__(256) void k_adj_prep_bwd(const float* __restrict__ 
 // clusters of level 2): every input is read ONCE, the divisions are done once; same operations in the same order (same bits).
 template <int VEC, int MAXJ>
 __global__ __launch_bounds__(256) void k_adj_prep_fwd_reg(const float* __restrict__ A, int R, int C, int lpr, float p, float* __restrict__ At,
-                                                          float* __restrict__ An, float* __restrict__ invd, float* __restrict__ ge1,
-                                                          float* __restrict__ rq) {
+                                                          float* __restrict__ An, float* __restrict__ invd, float* __restrict__ ge1) {
   const RowGroup rg(lpr);
   const bool renorm = p >= 0.f;
   const float omp = 1.f - p;
@@ -1433,7 +1430,6 @@ __global__ __launch_bounds__(256) void k_adj_prep_fwd_reg(const float* __restric
     if (rg.sl == 0) {
       invd[row] = inv;
       ge1[row] = st >= 1.f ? 1.f : 0.f;
-      if (rq != nullptr) rq[row] = 1.f / den;          // 1 / (off-diagonal row sum + eps): the re-normalisation's row factor is (1 - p) * rq
     }
   }
 }
@@ -1561,25 +1557,19 @@ extern "C" int cgc_dense_renorm_bwd(const float* A, const float* dOut, int R, in
   return 0;
 }
 
-extern "C" int cgc_adj_prep_fwd2(const float* A, int R, int C, float p, float* At, float* An, float* invd, float* ge1, float* rq,
-                                 cgc_stream_t stream);
 extern "C" int cgc_adj_prep_fwd(const float* A, int R, int C, float p, float* At, float* An, float* invd, float* ge1, cgc_stream_t stream) {
-  return cgc_adj_prep_fwd2(A, R, C, p, At, An, invd, ge1, nullptr, stream);
-}
-extern "C" int cgc_adj_prep_fwd2(const float* A, int R, int C, float p, float* At, float* An, float* invd, float* ge1, float* rq,
-                                 cgc_stream_t stream) {
   if (R <= 0 || C <= 0) return 0;
   if (p >= 0.f && At == nullptr) return CGC_EINVAL;
   const bool vec = (C % 4 == 0) && aligned16(A) && aligned16(An) && (At == nullptr || aligned16(At));
   ColCfg cfg = col_cfg(R, C, vec);
   if (cfg.ok && cfg.maxj <= 8) {
     cfg.blocks = row_blocks(R, cfg.lpr);
-    DISPATCH_COL(k_adj_prep_fwd_reg, cfg, 0, as_stream(stream), A, R, C, cfg.lpr, p, At, An, invd, ge1, rq);
+    DISPATCH_COL(k_adj_prep_fwd_reg, cfg, 0, as_stream(stream), A, R, C, cfg.lpr, p, At, An, invd, ge1);
     CGC_RETURN_IF_LAUNCH_FAILED();
     return 0;
   }
   const int lpr = pick_lpr(vec ? C / 4 : C);
-  LAUNCH_ROW(k_adj_prep_fwd, vec, lpr, R, as_stream(stream), A, R, C, lpr, p, At, An, invd, ge1, rq);
+  LAUNCH_ROW(k_adj_prep_fwd, vec, lpr, R, as_stream(stream), A, R, C, lpr, p, At, An, invd, ge1);
   CGC_RETURN_IF_LAUNCH_FAILED();
   return 0;
 }
@@ -1596,145 +1586,6 @@ extern "C" int cgc_adj_prep_bwd(const float* A, const float* An, const float* in
   }
   const int lpr = pick_lpr(vec ? C / 4 : C);
   LAUNCH_ROW(k_adj_prep_bwd, vec, lpr, R, as_stream(stream), A, An, invd, ge1, gAn, gAt, R, C, lpr, p, dA);
-  CGC_RETURN_IF_LAUNCH_FAILED();
-  return 0;
-}
-
-
-// ------------------------------------------------------------------------------------------------
-// Levels 2-3, backward of the adjacency WITHOUT its N x N intermediates (round 4).
-//
-// With A~ = re-normalised adjacency (A~_ij = s_i A_ij off the diagonal, s_i = (1 - p) rq_i; A~_ii = p; or A~ = A without --norm_adj)
-// and A^ = A~ / d_i, d_i = max(rowsum A~, 1), the level uses agg_l = A^ B_l (three convolution aggregations, B_l the layer inputs)
-// and P = A~ S (DiffPool).  Upstream: dC_l = d L / d agg_l and dP = d L / d P.  The chain rule through the two row normalisations is
-//     d A_ij = s_i [ (dP S^T)_ij + (sum_l dC_l B_l^T)_ij / d_i ] - w_i          (j != i; d A_ii = 0 with --norm_adj)
-// where EVERY row-wise reduction the normalisations need collapses to a dot product of thin rows, because the N x N gradient
-// matrices are themselves products:  sum_k (sum_l dC_l B_l^T)_ik A^_ik = sum_l dC_l,i . agg_l,i = u_i,
-// sum_k (dP S^T)_ik A~_ik = dP_i . P_i = v_i, and the diagonal entries are dP_i . S_i = e_i and sum_l dC_l,i . B_l,i = f_i:
-//     T_i = v_i + [d_i == rowsum < 1 ? 1 : 0] u_i - p (e_i + f_i / d_i - ge1_i u_i / d_i),     w_i = s_i (ge1_i u_i / d_i + T_i / (1 - p))
-// (without --norm_adj: s_i = 1, w_i = ge1_i u_i / d_i, no diagonal rule).  So the whole gradient is ONE product over the concatenated
-// thin operands  [ s/d dC_2 | s/d dC_1 | s/d dC_0 | s dP | -w_hi | -w_lo ] . [ B_2 | B_1 | B_0 | S | 1 | 1 ]^T  written once -- instead of two N x N
-// products (dP S^T: 125 us, the rank-100 update: 130 us at C3) whose results a third kernel reads back together with A, A^ (163 us,
-// five passes over 166 MB).  This kernel forms the two operands: one wave per row.
-struct AdjGradArgs {
-  const float* gcat;      // [n, wt]  = [dC_2 | dC_1 | dC_0]
-  const float* xcat;      // [n, wt]  = [B_2 | B_1 | B_0]
-  const float* agg[3];    // agg_2 [n, w2], agg_1 [n, w1], agg_0 [n, w0]: the saved aggregation outputs, in gcat's column order
-  int aw[3];              // their widths (w2 + w1 + w0 = wt); row stride = width
-  const float* dP;        // [n, ldP] or NULL (no DiffPool at this level)
-  const float* P;         // [n, ldP]
-  const float* S;         // [n, ldS]
-  const float *invd, *ge1, *rq;
-  float* Lc;              // [n, ldK] out
-  float* Rc;              // [n, ldK] out
-  int n, wt, C, ldP, ldS, ldK;
-  float p;                // < 0: no re-normalisation
-};
-
-__device__ __forceinline__ double wave_sum_f64(double v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
-
-// Round 5: the four row reductions and the row term w run in DOUBLE, and w travels as TWO k columns (w_hi | w_lo, both against 1):
-// w_i is a constant along row i of d A, so whatever error it carries is the same for all N entries of the row and the next contraction
-// (softmax weights, all positive) adds it up N times instead of sqrt(N) -- in float it cost the fused route up to 3x in gradient
-// accuracy against the N x N route, whose row terms are sums over the very entries they centre.  With
-// w good to 2^-48 what is left of the difference is the rounding of the saved fp32 operands themselves.
-__global__ __launch_bounds__(256) void k_adj_grad_operands(const AdjGradArgs a) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= a.n) return;
-  const float* __restrict__ g = a.gcat + (size_t)row * a.wt;
-  const float* __restrict__ x = a.xcat + (size_t)row * a.wt;
-  double u = 0.0, f = 0.0, v = 0.0, e = 0.0;
-  for (int c = lane; c < a.wt; c += 64) {
-    const double gv = (double)g[c];
-    int k = c, part = 0;
-    if (k >= a.aw[0]) { k -= a.aw[0]; part = 1; }
-    if (part == 1 && k >= a.aw[1]) { k -= a.aw[1]; part = 2; }
-    const float* __restrict__ ag = part == 0 ? a.agg[0] : part == 1 ? a.agg[1] : a.agg[2];
-    const int w = part == 0 ? a.aw[0] : part == 1 ? a.aw[1] : a.aw[2];
-    u = fma(gv, (double)ag[(size_t)row * w + k], u);
-    f = fma(gv, (double)x[c], f);
-  }
-  const bool pool = a.dP != nullptr;
-  if (pool) {
-    const float* __restrict__ dp = a.dP + (size_t)row * a.ldP;
-    const float* __restrict__ pp = a.P + (size_t)row * a.ldP;
-    const float* __restrict__ ss = a.S + (size_t)row * a.ldS;
-    for (int c = lane; c < a.C; c += 64) {
-      const double d = (double)dp[c];
-      v = fma(d, (double)pp[c], v);
-      e = fma(d, (double)ss[c], e);
-    }
-  }
-  u = wave_sum_f64(u);
-  f = wave_sum_f64(f);
-  v = wave_sum_f64(v);
-  e = wave_sum_f64(e);
-  const bool renorm = a.p >= 0.f;
-  const float inv = a.invd[row], ge = a.ge1[row];
-  const float s = renorm ? (1.f - a.p) * a.rq[row] : 1.f;
-  double w;
-  if (renorm) {
-    const double p = (double)a.p;
-    const double T = v + (1.0 - (double)ge) * u - p * (e + f * (double)inv - (double)ge * u * (double)inv);
-    w = (double)s * ((double)ge * u * (double)inv + T / (1.0 - p));
-  } else {
-    w = (double)ge * u * (double)inv;
-  }
-  const float w_hi = (float)w, w_lo = (float)(w - (double)w_hi);
-  float* __restrict__ L = a.Lc + (size_t)row * a.ldK;
-  float* __restrict__ Rr = a.Rc + (size_t)row * a.ldK;
-  const float sc = s * inv;
-  for (int c = lane; c < a.wt; c += 64) {
-    L[c] = sc * g[c];
-    Rr[c] = x[c];
-  }
-  int o = a.wt;
-  if (pool) {
-    const float* __restrict__ dp = a.dP + (size_t)row * a.ldP;
-    const float* __restrict__ ss = a.S + (size_t)row * a.ldS;
-    for (int c = lane; c < a.C; c += 64) {
-      L[o + c] = s * dp[c];
-      Rr[o + c] = ss[c];
-    }
-    o += a.C;
-  }
-  for (int c = o + lane; c < a.ldK; c += 64) {       // the row term rides along as two more k: (-w_hi) * 1 + (-w_lo) * 1; padding: zeros
-    L[c] = c == o ? -w_hi : c == o + 1 ? -w_lo : 0.f;
-    Rr[c] = c <= o + 1 ? 1.f : 0.f;
-  }
-}
-
-// K of the product = wt + C + 2; ldK >= K (a multiple of 4 for the unguarded GEMM loaders).  agg[i] has row stride aw[i].
-extern "C" int cgc_adj_grad_operands(const float* gcat, const float* xcat, int wt, const float* const* agg, const int* aw, const float* dP,
-                                     const float* P, int ldP, const float* S, int ldS, int C, const float* invd, const float* ge1,
-                                     const float* rq, int n, float p, float* Lc, float* Rc, int ldK, cgc_stream_t stream) {
-  if (n <= 0) return 0;
-  if (wt <= 0 || aw[0] + aw[1] + aw[2] != wt || ldK < wt + (dP != nullptr ? C : 0) + 2) return CGC_EINVAL;
-  if (p >= 0.f && rq == nullptr) return CGC_EINVAL;
-  AdjGradArgs a;
-  a.gcat = gcat; a.xcat = xcat;
-  for (int i = 0; i < 3; ++i) { a.agg[i] = agg[i]; a.aw[i] = aw[i]; }
-  a.dP = dP; a.P = P; a.S = S; a.invd = invd; a.ge1 = ge1; a.rq = rq; a.Lc = Lc; a.Rc = Rc;
-  a.n = n; a.wt = wt; a.C = dP != nullptr ? C : 0; a.ldP = ldP; a.ldS = ldS; a.ldK = ldK; a.p = p;
-  hipLaunchKernelGGL(k_adj_grad_operands, dim3(ceil_div(n, 4)), dim3(256), 0, as_stream(stream), a);
-  CGC_RETURN_IF_LAUNCH_FAILED();
-  return 0;
-}
-
-// A[b, i, i] = 0 for a batch of B square [R, R] matrices (the re-normalisation overwrites the diagonal: no gradient reaches it)
-__global__ void k_zero_diag(float* __restrict__ A, int R, long long total) {
-  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  if (i < total) A[(size_t)(i / R) * R * R + (size_t)(i % R) * (R + 1)] = 0.f;
-}
-extern "C" int cgc_zero_diag(float* A, int B, int R, cgc_stream_t stream) {
-  if (B <= 0 || R <= 0) return 0;
-  const long long total = (long long)B * R;
-  hipLaunchKernelGGL(k_zero_diag, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, as_stream(stream), A, R, total);
   CGC_RETURN_IF_LAUNCH_FAILED();
   return 0;
 }

@@ -742,34 +742,6 @@ class HipKernels(KernelSpec):
         self._chk(self.lib.cgc_adj_prep_fwd(_ptr(A), R, C, ctypes.c_float(-1.0 if p is None else p), _ptr(At_out), _ptr(An_out),
                                             _ptr(invd_out), _ptr(ge1_out), self._stream()), 'cgc_adj_prep_fwd')
 
-    def adj_prep_fwd2(self, A, R, C, p, At_out, An_out, invd_out, ge1_out, rq_out):
-        """adj_prep_fwd that also returns rq = 1 / (off-diagonal row sum + 1e-15)."""
-        self._dev(A, At_out, An_out, invd_out, ge1_out, rq_out)
-        self._chk(self.lib.cgc_adj_prep_fwd2(_ptr(A), R, C, ctypes.c_float(-1.0 if p is None else p), _ptr(At_out), _ptr(An_out),
-                                             _ptr(invd_out), _ptr(ge1_out), _ptr(rq_out), self._stream()), 'cgc_adj_prep_fwd2')
-
-    def adj_grad_fused(self, gcat, xcat, aggs, dP, P, S, invd, ge1, rq, B, R, p, dA_out):
-        """The adjacency gradient of a dense level as ONE product of thin operands (cgc_adj_grad_operands + cgc_gemm_f32 +
-        cgc_zero_diag): what cgc_level_bwd issues.  gcat / xcat [B*R, wt]; aggs = three [B*R, w_i] tensors in gcat's column order;
-        dP / P / S [B*R, C] or None."""
-        n, wt = gcat.shape
-        C = dP.shape[1] if dP is not None else 0
-        self._dev(gcat, xcat, dP, P, S, invd, ge1, rq, dA_out, *aggs)
-        K = wt + C + 2                       # (+ the row term as two columns: w_hi | w_lo)
-        ldK = (K + 3) // 4 * 4
-        Lc = torch.empty(n, ldK, dtype=torch.float32, device=gcat.device)
-        Rc = torch.empty(n, ldK, dtype=torch.float32, device=gcat.device)
-        pa = (ctypes.c_void_p * 3)(*[a.data_ptr() for a in aggs])
-        aw = (ctypes.c_int * 3)(*[a.shape[1] for a in aggs])
-        assert all(a.is_contiguous() for a in aggs) and gcat.is_contiguous() and xcat.is_contiguous()
-        self._chk(self.lib.cgc_adj_grad_operands(_ptr(gcat), _ptr(xcat), wt, pa, aw, _ptr(dP), _ptr(P), dP.stride(0) if dP is not None else 0,
-                                                 _ptr(S), S.stride(0) if S is not None else 0, C, _ptr(invd), _ptr(ge1), _ptr(rq), n,
-                                                 ctypes.c_float(-1.0 if p is None else p), _ptr(Lc), _ptr(Rc), ldK, self._stream()),
-                  'cgc_adj_grad_operands')
-        self.gemm(Lc, Rc, dA_out, R, R, K, False, True, ldK, ldK, R, 1.0, 0.0, None, B, R * ldK, R * ldK, R * R)
-        if p is not None:
-            self._chk(self.lib.cgc_zero_diag(_ptr(dA_out), B, R, self._stream()), 'cgc_zero_diag')
-
     def adj_prep_bwd(self, A, An, invd, ge1, gAn, gAt, R, C, p, dA_out):
         self._dev(A, An, invd, ge1, gAn, gAt, dA_out)
         self._chk(self.lib.cgc_adj_prep_bwd(_ptr(A), _ptr(An), _ptr(invd), _ptr(ge1), _ptr(gAn), _ptr(gAt), R, C,

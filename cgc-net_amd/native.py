@@ -126,7 +126,7 @@ def prepared(enc, level, emb, pool, jk, fin):
                    for b in blocks if b.use_bn for k in (1, 2, 3))
     modes = (enc.training,) + tuple(m.training for b in blocks for m in _mode_modules(b))
     key = (tuple(id(t) for t in params), tuple(t.data_ptr() for t in params if t is not None), modes, enc.norm_adj, fin, bn_cfg,
-           emb.activation, bool(getattr(enc, 'adj_backward_fused', False)), int(getattr(enc, 'gemm_mode', 0)))
+           emb.activation, int(getattr(enc, 'gemm_mode', 0)))
     cache = enc.__dict__.setdefault('_native_prepared', {})
     hit = cache.get(level)
     if hit is not None and hit[0] == key:
@@ -188,7 +188,7 @@ def describe(enc, level, emb, pool, jk, B, n, rows_per_graph, nmax, npad, fin, c
     d.act, d.jk = ACT_CODES[emb.activation], int(jk is not None)
     d.renorm, d.renorm_p = int(enc.norm_adj), float(RENORM_P)
     d.eval = int(not enc.training)
-    d.flags = (1 if getattr(enc, 'adj_backward_fused', False) else 0) | (2 if int(getattr(enc, 'gemm_mode', 0)) == 1 else 0)
+    d.flags = 2 if int(getattr(enc, 'gemm_mode', 0)) == 1 else 0      # (bit 0 is reserved: include/cgc_hip.h)
     for b_i, blk in enumerate(blocks):
         if blk.use_bn:
             for k in range(3):

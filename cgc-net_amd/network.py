@@ -329,9 +329,6 @@ class SoftPoolingGcnEncoder(nn.Module):
         self.native = os.environ.get('CGC_NATIVE', '1') != '0'
         self.native_head = os.environ.get('CGC_NATIVE_HEAD', '1') != '0'     # classification head + loss as one kernel each way
         self.reorder_large = os.environ.get('CGC_REORDER', '1') != '0'       # see _spatially_ordered
-        # levels 2-3: the adjacency gradient as one product of thin operands (cgc_level_desc.flags bit 0; -1.4 % per step at C3, up
-        # to 3x the rounding error on the coarsened levels' gradients: off unless asked for)
-        self.adj_backward_fused = os.environ.get('CGC_ADJ_FUSED', '0') == '1'
         # 0 = kernels.GEMM_EXACT (fp32 matrix-core chain, the default); 1 = kernels.GEMM_SPLIT_BF16: the six dominant products of a
         # step (assignment Linear, S^T(AS), their backward: model/network.py:121-122,206-207) as six bf16 MFMA pairs per fp32 product
         # -- same results to fp32 rounding (include/cgc_hip.h: cgc_gemm_f32_ws), 1.3-1.6x faster on those products

@@ -41,8 +41,10 @@ typedef void* cgc_stream_t; /* hipStream_t */
  *   2: round 4 (head: labels outside [0, L) are ignored like F.cross_entropy's ignore_index; forward BatchNorm statistics in double:
  *      cgc_stats_ws_floats; additions listed in DESIGN.md)
  *   3: round 5 (cgc_gemm_f32_ws / cgc_gemm_f32_cat_ws take a `mode`; cgc_level_desc.flags bit 1; head: a label outside [0, L) other
- *      than -100 makes the loss NaN instead of being ignored) */
-#define CGC_ABI_VERSION 3
+ *      than -100 makes the loss NaN instead of being ignored)
+ *   4: round 6 (removed: cgc_adj_prep_fwd2, cgc_adj_grad_operands, cgc_zero_diag and cgc_level_desc.flags bit 0 -- the thin-operand
+ *      adjacency gradient; a descriptor with bit 0 set is refused) */
+#define CGC_ABI_VERSION 4
 int cgc_abi_version(void);
 
 /* ---- A1: graph structure.  Replaces to_dense_adj (model/utils.py:3-36, called at model/network.py:241).
@@ -335,18 +337,6 @@ int cgc_dense_renorm_bwd(const float* A, const float* dOut, int R, int C, float 
  * s = rowsum(At), d = max(s,1), An = At/d, invd = 1/d, ge1 = (s >= 1) -- one pass over the [R = B*C, C] adjacency
  * (model/network.py:183-191,259-262 + DenseSAGEConv's clamp(min=1)). */
 int cgc_adj_prep_fwd(const float* A, int R, int C, float p, float* At, float* An, float* invd, float* ge1, cgc_stream_t stream);
-/* the same, additionally writing rq[row] = 1 / (off-diagonal row sum + 1e-15) (NULL: not written): the row factor of the
- * re-normalisation is (1 - p) * rq -- what cgc_adj_grad_operands needs */
-int cgc_adj_prep_fwd2(const float* A, int R, int C, float p, float* At, float* An, float* invd, float* ge1, float* rq, cgc_stream_t stream);
-/* Backward of the two row normalisations WITHOUT N x N intermediates (csrc/rowops.hip, k_adj_grad_operands, has the derivation):
- * forms Lc, Rc [n, ldK] such that  d A[b] = Lc[b] Rc[b]^T  (K = wt + C + 2 columns -- the row term in double, carried as w_hi | w_lo; one batched NT product), to be followed by
- * cgc_zero_diag when p >= 0.  gcat / xcat [n, wt]: the gradients / inputs of the level's three aggregations side by side; agg[3] /
- * aw[3]: the saved aggregation outputs in the same column order and their widths; dP, P [n, ldP], S [n, ldS]: the DiffPool operands
- * (dP NULL: the level has no DiffPool; C is then ignored); invd, ge1 (cgc_adj_prep_fwd), rq (cgc_adj_prep_fwd2; needed when p >= 0). */
-int cgc_adj_grad_operands(const float* gcat, const float* xcat, int wt, const float* const* agg, const int* aw, const float* dP,
-                          const float* P, int ldP, const float* S, int ldS, int C, const float* invd, const float* ge1, const float* rq,
-                          int n, float p, float* Lc, float* Rc, int ldK, cgc_stream_t stream);
-int cgc_zero_diag(float* A /*[B, R, R]*/, int B, int R, cgc_stream_t stream);
 /* its backward: gAn = gradient w.r.t. An, gAt = gradient that reaches At directly (NULL if none; e.g. from At*S of _diff_pool):
  * dAt = invd*(gAn - ge1*<gAn,An>_row) + gAt, dA = backward of the re-normalisation at dAt (dA = dAt when p < 0). */
 int cgc_adj_prep_bwd(const float* A, const float* An, const float* invd, const float* ge1, const float* gAn, const float* gAt,
@@ -385,11 +375,8 @@ typedef struct {
   int eval;               /* 1: inference forward (model.eval() under no_grad; train.py:21-91): BatchNorm normalises with the running
                            * statistics and leaves them alone, nothing is kept for a backward (`saved` is working memory only);
                            * cgc_level_bwd refuses such a descriptor */
-  int flags;              /* bit 0: levels 2-3 compute the adjacency gradient as ONE product of thin operands (cgc_adj_grad_operands + one
-                           * batched GEMM + cgc_zero_diag) instead of two N x N products + cgc_adj_prep_bwd: 1.4 % faster per step at C3,
-                           * same value, but its row terms are no longer formed from the N x N matrices they centre -- a row-coherent
-                           * rounding error that costs up to 3x in gradient accuracy on the coarsened levels.
-                           * Off by default: the default schedule is the per-operator path's, bit for bit
+  int flags;              /* bit 0: reserved, must be 0 (rounds 4-5: an opt-in thin-operand form of the dense levels' adjacency gradient;
+                           * it missed the 1e-4 gradient bar on two reference fixtures and was removed with ABI 4 -- DESIGN.md section 8);
                            * bit 1: the level's products run with mode CGC_GEMM_SPLIT_BF16 (cgc_gemm_f32_ws): those on the 128 x 128
                            * route as six bf16 MFMA pairs per fp32 product.  Off by default */
 } cgc_level_desc;

@@ -435,10 +435,9 @@ def compare_with_reference_fp64(name, tol_grad=1e-4):
     torch.cuda.synchronize()
     assert kernels.is_native() and len(dec.winners) == 3
     assert torch.equal(logits, tl) and torch.equal(loss, tloss), 'sequencer and per-operator path disagree'
-    if not getattr(model, 'adj_backward_fused', False):       # (the opt-in fused adjacency backward exists in the sequencer only: same forward)
-        tg = dict(twin.named_parameters())
-        for k, p in model.named_parameters():
-            assert torch.equal(p.grad, tg[k].grad), ('sequencer and per-operator path disagree', k)
+    tg = dict(twin.named_parameters())
+    for k, p in model.named_parameters():
+        assert torch.equal(p.grad, tg[k].grad), ('sequencer and per-operator path disagree', k)
     assert rel_err(logits, fix['logits']) < 1e-4 and rel_err(loss, fix['loss']) < 1e-4
     STATS.clear()
     smooth = cfg.get('activation', 'relu') == 'elu'

@@ -1102,41 +1102,3 @@ def test_forward_bn_statistics_survive_small_variance(path, n, Kin, F):
     assert float(((mean.double() - m_ref).abs() / m_ref.abs().clamp_min(1e-3)).max()) < 1e-6
     rel = float(((var - v_ref).abs() / v_ref)[live].max())
     assert rel < 2e-5, rel
-
-
-@pytest.mark.parametrize('B,R,C,widths,p', [(3, 50, 12, (7, 7, 5), 0.4), (2, 114, 0, (20, 20, 20), 0.4), (4, 76, 20, (40, 40, 20), None),
-                                            (2, 260, 114, (40, 40, 20), 0.4)])
-def test_adjacency_gradient_as_one_thin_product(B, R, C, widths, p):
-    """cgc_adj_grad_operands + one batched product + cgc_zero_diag  ==  the N x N route it replaces (dAn = gcat xcat^T, gAt = dP S^T,
-    cgc_adj_prep_bwd -- itself checked against the torch restatement above), on random operands that satisfy the identities the
-    fused form relies on: agg_l = A^ B_l and P = A~ S are the forward's own products."""
-    k = hip()
-    n, wt = B * R, sum(widths)
-    rs = np.random.RandomState(R + C)
-    A = torch.from_numpy(rs.uniform(0.0, 1.0, (n, R)).astype(np.float32)).to(DEV)
-    A[: R // 3] *= 0.01                                   # rows whose re-normalised sum stays below / above 1: both clamp branches
-    At = torch.empty(n, R, device=DEV) if p is not None else None
-    An, invd, ge1, rq = torch.empty(n, R, device=DEV), torch.empty(n, device=DEV), torch.empty(n, device=DEV), torch.empty(n, device=DEV)
-    k.adj_prep_fwd2(A, n, R, p, At, An, invd, ge1, rq)
-    xcat = torch.from_numpy(rs.standard_normal((n, wt)).astype(np.float32)).to(DEV)
-    gcat = torch.from_numpy(rs.standard_normal((n, wt)).astype(np.float32)).to(DEV)
-    An3, x3 = An.view(B, R, R), xcat.view(B, R, wt)
-    aggcat = torch.bmm(An3, x3).view(n, wt)
-    offs = np.cumsum((0,) + widths)
-    aggs = [aggcat[:, offs[i]:offs[i + 1]].contiguous() for i in range(3)]
-    dP = P = S = gAt = None
-    if C:
-        S = torch.softmax(torch.from_numpy(rs.standard_normal((n, C)).astype(np.float32)), 1).to(DEV)
-        dP = torch.from_numpy(rs.standard_normal((n, C)).astype(np.float32)).to(DEV)
-        P = torch.bmm((At if p is not None else A).view(B, R, R), S.view(B, R, C)).view(n, C).contiguous()
-        gAt = torch.bmm(dP.view(B, R, C), S.view(B, R, C).transpose(1, 2)).reshape(n, R).contiguous()
-    gAn = torch.bmm(gcat.view(B, R, wt), x3.transpose(1, 2)).reshape(n, R).contiguous()
-    want = torch.empty(n, R, device=DEV)
-    k.adj_prep_bwd(A, An, invd, ge1, gAn, gAt, n, R, p, want)
-    got = torch.empty(n, R, device=DEV)
-    k.adj_grad_fused(gcat, xcat, aggs, dP, P, S, invd, ge1, rq, B, R, p, got)
-    torch.cuda.synchronize()
-    close(got, want, 2e-5, 'dA')
-    if p is not None:
-        d = got.view(B, R, R).diagonal(dim1=1, dim2=2)
-        assert float(d.abs().max()) == 0.0

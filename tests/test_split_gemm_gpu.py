@@ -181,9 +181,12 @@ def test_split_gemm_flat_with_two_extra_segments(kind):
 
 
 @pytest.mark.parametrize('kind', KINDS)
-@pytest.mark.parametrize('counts', [[300, 0, 513, 128, 77, 900, 250, 640], [1800, 1900, 1750]])
+@pytest.mark.parametrize('counts', [[300, 0, 513, 128, 77, 900, 250, 640], [1800, 1900, 1750],
+                                    [0, 300, 513, 128, 77, 900, 250, 640], [40, 300, 513, 128, 77, 900, 250, 640]])
 def test_split_gemm_ragged_k(counts, kind):
-    """out[b] = S_b^T P_b: the reduction runs over the rows of graph b (S^T (A S), S^T X)."""
+    """out[b] = S_b^T P_b: the reduction runs over the rows of graph b (S^T (A S), S^T X).  The last two lists put an EMPTY graph and
+    a graph of fewer k-tiles than tail-split pieces FIRST (row offset 0: a k range of no tiles must not load anything -- there is no
+    row in front of the operand to clamp to; the kernel skips its prologue and stores zeros)."""
     k = hip()
     n, nmax, batch, C = sum(counts), max(counts), len(counts), 1140
     gptr = torch.tensor(np.cumsum([0] + counts), dtype=torch.int32, device=DEV)
