@@ -685,7 +685,10 @@ extern "C" int cgc_sage_wide_fwd(const float* agg, int lda, const float* W, cons
     // (small launches keep the one-kernel form: at 7200 rows -- a 4-graph shard -- two more launches cost more than the wave-level kernel saves)
     static const int cols_min_rows = getenv("CGC_SAGE_WIDE_COLS_MIN") ? atoi(getenv("CGC_SAGE_WIDE_COLS_MIN")) : 12288;
     if (use_cols && normalize && K <= 21 && n >= cols_min_rows && n >= 64 && (long long)n * ldh * 4 < (1LL << 31) && (reinterpret_cast<uintptr_t>(hn) & 7u) == 0 &&
-        aligned16(rinv) && (size_t)n * ldh * 4 >= sizeof(double) * (size_t)(K * (K + 1) / 2 + K + 1) && ((long long)(n - 1) * lda + K) * 4 < (1LL << 31)) {
+        aligned16(rinv) && (size_t)n * ldh * 4 >= sizeof(double) * (size_t)(K * (K + 1) / 2 + K + 1) && ((long long)(n - 1) * lda + K) * 4 < (1LL << 31) &&
+        // G is parked in the first bytes of hn and overwritten by the projection: with hn a column window of a wider buffer (ldh > F)
+        // it must fit row 0's own F floats, or it would land in columns [F, ldh) that belong to the enclosing buffer
+        (ldh == F || (size_t)F * 4 >= sizeof(double) * (size_t)(K * (K + 1) / 2 + K + 1))) {
       int per = ceil_div(row_tiles, cols_chunks > 0 ? cols_chunks : 256);
       int chunks = ceil_div(row_tiles, per);
       if (stats && chunks > cap) { chunks = cap > 0 ? cap : 1; }

@@ -635,6 +635,8 @@ extern "C" int cgc_spmm_graphs_ordered(const int* rowptr, const int* col, const 
 #undef PATCH_LAUNCH
     hipError_t e__ = hipGetLastError();
     rc = e__ == hipSuccess ? 0 : (int)e__;
+    // (the experiment needs 2 x 81 KB of dynamic LDS per CU: a launch the device refuses falls back to the gather kernel)
+    if (rc != 0) rc = launch_gather(rowptr, col, perm, val, pre, post, x, out, n, width, ld, gptr, B, nmax, visit & 3, as_stream(stream), gorder);
   } else {
     rc = launch_gather(rowptr, col, perm, val, pre, post, x, out, n, width, ld, gptr, B, nmax, visit & 3, as_stream(stream), gorder);
   }

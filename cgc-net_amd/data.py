@@ -29,11 +29,16 @@ class Data(object):
 
     @property
     def keys(self):
-        return [k for k, v in self.__dict__.items() if v is not None]
+        """The data attributes, as torch_geometric lists them.  Underscore attributes (``_gptr``, ``_dense_rows``, ``_spatial`` ...) are
+        host-side notes of this package about the object -- they travel with ``to()`` / ``reorder_nodes`` but are not data."""
+        return [k for k, v in self.__dict__.items() if v is not None and not k.startswith('_')]
 
     def __iter__(self):  # dataflow/data.py:344 iterates ``for key, item in data``
         for k in self.keys:
             yield k, getattr(self, k)
+
+    def _all_items(self):
+        return [(k, v) for k, v in self.__dict__.items() if v is not None]
 
     def __getitem__(self, k):
         return getattr(self, k)
@@ -54,7 +59,7 @@ class Data(object):
 
     def to(self, device, non_blocking=False):
         out = self.__class__()
-        for k, v in self:
+        for k, v in self._all_items():
             out[k] = v.to(device, non_blocking=non_blocking) if torch.is_tensor(v) else v
         return out
 
@@ -280,7 +285,7 @@ def reorder_nodes(data, perm):
     out = data.__class__()
     inv = torch.empty(n, dtype=torch.long)
     inv[perm] = torch.arange(n)
-    for k, v in data:
+    for k, v in data._all_items():
         if k == 'edge_index':
             ei = inv[v]
             order = torch.argsort(ei[0] * n + ei[1])

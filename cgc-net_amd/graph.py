@@ -78,8 +78,10 @@ class BatchGraph(object):
     def from_batch(cls, batch, renorm_p=None):
         x, edge_index = batch.x, batch.edge_index
         g = cls(x.shape[0], cls.node_counts_of(batch), x.device, getattr(batch, '_dense_rows', None), getattr(batch, '_gptr', None))
-        # the nodes of every graph are listed grid cell by grid cell (data.spatial_order; the Batch says so): the wide aggregation
-        # stages the neighbour union of consecutive rows in LDS (cgc_spmm_graphs: visit bit 2).  A hint about speed, never about results.
+        # the nodes of every graph are listed grid cell by grid cell (data.spatial_order; the Batch says so).  What makes the wide
+        # aggregation faster on such a batch is the node ORDER itself (the gather's re-reads hit nearer caches); the note only
+        # travels on as cgc_spmm_graphs' visit bit 2, which the default gather kernel ignores (it selects the experimental LDS-staged
+        # kernel under CGC_SPMM_PATCH=1).  Never about results.
         g.spatial = bool(getattr(batch, '_spatial', False))
         g._build(edge_index.contiguous(), renorm_p)
         return g

@@ -876,3 +876,34 @@ def adj_prep(A, p=None):
     """Returns (A~, A_norm): A~ = _re_norm_adj(A, p) (model/network.py:183-191; A itself when p is None) and
     A_norm = A~ / clamp(rowsum(A~), min=1) (DenseSAGEConv's mean divisor folded into the adjacency)."""
     return _AdjPrep.apply(A, None if p is None else float(p))
+
+
+def _bind_gemm_mode():
+    """The GEMM mode of the per-operator path (kernels.GEMM_EXACT / GEMM_SPLIT_BF16) is a property of the ENCODER whose forward issued a
+    node, but the kernel table reads it from a process-wide attribute at call time: every node records the mode its forward ran
+    under and its backward re-installs that mode for its own duration -- two encoders in different modes (or a test toggling the
+    mode between forward and backward) cannot end up with the forward and the backward of one model on different GEMM kernels.
+    (The sequencer path carries the mode in cgc_level_desc.flags.)"""
+    def bind(cls):
+        fwd, bwd = cls.forward, cls.backward
+
+        def forward(ctx, *args):
+            ctx._gemm_mode = int(getattr(K(), 'gemm_mode', 0))
+            return fwd(ctx, *args)
+
+        def backward(ctx, *grads):
+            k = K()
+            old = getattr(k, 'gemm_mode', 0)
+            k.gemm_mode = ctx._gemm_mode
+            try:
+                return bwd(ctx, *grads)
+            finally:
+                k.gemm_mode = old
+        cls.forward, cls.backward = staticmethod(forward), staticmethod(backward)
+
+    for v in list(globals().values()):
+        if isinstance(v, type) and issubclass(v, Function) and v is not Function:
+            bind(v)
+
+
+_bind_gemm_mode()

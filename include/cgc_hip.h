@@ -124,11 +124,14 @@ int cgc_spmm(const int* rowptr, const int* col, const int* perm, const float* va
  * nmax = largest graph.  Wide rows are then swept one (graph, 1 KiB column tile) slab at a time per XCD so that the ~9x
  * re-read of neighbour rows is served by that XCD's L2.  visit = scheduling hint only (results identical): which graphs
  * of x the previous kernel left in the Infinity Cache -- bits 0-1: 0 unknown / ascending, 1 x was written in ascending row order,
- * 2 x was written by cgc_gemm_f32 as a ragged batch.  Bit 2 (+4, round 5): the nodes of every graph are listed grid cell by grid cell
- * (neighbours in space are neighbours in memory: data.spatial_order): the gather kernel's re-reads then hit nearer caches (+3 % at
- * C3, +30 % at C5).  Bit 3 (+8): EXPERIMENT -- rows wider than 256 floats take k_spmm_patch, which stages the neighbour UNION of 32
- * consecutive rows in LDS once per 512-byte column tile and gathers from there (a block whose union does not fit is gathered
- * directly: any row order gives the same result); measured slower than the gather kernel, kept for its test. */
+ * 2 x was written by cgc_gemm_f32 as a ragged batch.  Bit 2 (+4, round 5): a NOTE that the nodes of every graph are listed grid cell
+ * by grid cell (neighbours in space are neighbours in memory: data.spatial_order).  The default gather kernel does not read the bit
+ * -- it is the node order itself that makes its re-reads hit nearer caches (+3 % at C3, +30 % at C5) -- the bit only selects the
+ * experimental kernel below when the library runs with CGC_SPMM_PATCH=1.  Bit 3 (+8): EXPERIMENT -- rows wider than 256 floats take
+ * k_spmm_patch, which stages the neighbour UNION of 32 consecutive rows in LDS once per 512-byte column tile and gathers from there
+ * (a block whose union does not fit is gathered directly: any row order gives the same result); measured slower than the gather
+ * kernel, kept for its test.  If that kernel cannot be launched (its 2 x 81 KB of dynamic LDS refused), the
+ * call falls back to the gather kernel. */
 int cgc_spmm_graphs(const int* rowptr, const int* col, const int* perm, const float* val, const float* pre,
                     const float* post, const float* x, float* out, int n, int width, int ld /* row stride of x and out
                     (>= width): wide rows are kept at a multiple of 32 floats so that a 128-byte line never holds parts

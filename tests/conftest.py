@@ -42,3 +42,15 @@ def gemm_mode(request, monkeypatch):
             return int(K.lib.cgc_gemm_split_count()) - before
     yield Mode
     K.gemm_mode = kernels.GEMM_EXACT
+
+
+@pytest.fixture
+def forced_big_route():
+    """Every product of the test takes the 128 x 128 pipelined route (cgc_gemm_tuning(11)) -- the route CGC_GEMM_SPLIT_BF16 applies to --
+    at sizes a test can afford (automatically it is taken from ~450 output tiles up: none of the reference-generated fixtures gets
+    there by itself)."""
+    import cgc_net_amd.kernels as kernels
+    K = kernels.get()
+    old = K.lib.cgc_gemm_tuning(11)
+    yield
+    K.lib.cgc_gemm_tuning(old)

@@ -158,9 +158,13 @@ def hip_choices(dec, pre64, embeds64, counts):
         assert int(local.max()) < e.shape[1]
         picked = e.gather(1, local.unsqueeze(1)).squeeze(1)
         best, nat = e.max(dim=1)
-        gap = float(((best - picked) / best.abs().clamp_min(1e-6)).max())
+        gaps = (best - picked) / best.abs().clamp_min(1e-6)
+        gap = float(gaps.max())
         assert gap < MAX_TIE, ('a max-readout winner of the HIP path is not a co-winner in fp64', lvl, gap)
-        winner_flips += int((nat != local).sum())
+        flipped = nat != local
+        winner_flips += int(flipped.sum())
+        if bool(flipped.any()):                           # the largest float64 gap at which the HIP path took another winner (printed by every run)
+            STATS['winner_gap'] = max(STATS.get('winner_gap', 0.0), float(gaps[flipped].max()))
         routing.append(local)
     masks, relu_flips = {}, 0
     for name, v64 in pre64.items():
@@ -307,8 +311,8 @@ def compare_model(cpu_batch, maxn, feat, flags, tol_grad=1e-4, timer=None, seed=
         g64 = {k: p.grad.clone() for k, p in ref64.named_parameters()}
     print('pre-activations: max |hip - fp64| = %.2e; largest |fp64 value| whose sign the HIP path took differently = %.2e (RELU_TIE = %.0e)'
           % (STATS.get('preact_err', 0.0), STATS.get('flip_at', 0.0), RELU_TIE))
-    print('decisions differing from the fp64 evaluation: %d of %d readout winners, %d of %d ReLU signs'
-          % (winner_flips, sum(r.numel() for r in routing), relu_flips, sum(m.numel() for m in masks.values())))
+    print('decisions differing from the fp64 evaluation: %d of %d readout winners (largest relative fp64 gap at a differing winner %.2e, MAX_TIE = %.0e), %d of %d ReLU signs'
+          % (winner_flips, sum(r.numel() for r in routing), STATS.get('winner_gap', 0.0), MAX_TIE, relu_flips, sum(m.numel() for m in masks.values())))
     assert rel_err(logits, rl) < 1e-4 and elementwise_excess(logits, rl, 1e-4) <= 1.0, rel_err(logits, rl)
     assert rel_err(logits, l64) < 1e-4 and rel_err(loss, loss64) < 1e-4
     assert rel_err(loss, rloss) < 1e-4
@@ -448,8 +452,8 @@ def compare_with_reference_fp64(name, tol_grad=1e-4):
         l64r, _ = run_oracle_routed(ref64, inp64, routing, masks if not smooth else None)
         assert rel_err(l64r, fix['logits']) < 1e-6
         yard = {k: p.grad.clone() for k, p in ref64.named_parameters()}
-    print('%s: decisions differing from the reference fp64 fixture: %d readout winners, %d activation signs%s'
-          % (name, winner_flips, relu_flips, '' if not (winner_flips or relu_flips) else ' (all undecidable in fp32; yardstick re-routed)'))
+    print('%s: decisions differing from the reference fp64 fixture: %d readout winners (largest relative fp64 gap at a differing winner %.2e), %d activation signs%s'
+          % (name, winner_flips, STATS.get('winner_gap', 0.0), relu_flips, '' if not (winner_flips or relu_flips) else ' (all undecidable in fp32; yardstick re-routed)'))
 
     def strict(a, b):
         a, b = a.detach().double().cpu(), b.detach().double().cpu()

@@ -17,8 +17,9 @@ make_golden.py), casts the module to float64 and runs it through its dense tuple
   win64/<level>                   its argmax over the node axis, [B, D]
   ulp64/<parameter>               how far the reference's OWN float64 gradient of that parameter moves (max-norm, relative) when every
                                   parameter is perturbed by one float32 rounding (relative 2^-24, random signs; worst of 8 draws): what
-                                  no float32 evaluation of this network can be expected to beat on this input -- the gradient bar of
-                                  tests/discrete.py::compare_with_reference_fp64 is max(1e-4, 2 x this)
+                                  no float32 evaluation of this network can be expected to beat on this input.  Printed next to the
+                                  measured error by tests/discrete.py::compare_with_reference_fp64, whose bar is the plain 1e-4 on
+                                  every parameter (round 4's max(1e-4, 2 x this) widening was never needed and is gone)
 
 and asserts oracle/dense_ref.py (float64) == reference (float64) to 1e-11 on all of them.  Only the .npz files travel.
 """

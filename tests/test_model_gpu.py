@@ -12,7 +12,14 @@ from util import CASES, build_model, elementwise_excess, load_case, rel_err
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
-TOL, TOL_GRAD = 1e-4, 5e-4      # see tests/test_flat_formulation_cpu.py for the gradient tolerance
+TOL = 1e-4
+# THE GRADIENT CONTRACT IS 1e-4 STRICT AGAINST FLOAT64 (max|a-b| / max|b|, no absolute slack): the reference's float64 fixtures
+# (test_golden_gradients_within_1e4_of_the_reference_in_fp64*, all eight cases, default routing and the forced big route in both GEMM
+# modes) and the oracle in float64 (test_synthetic_cell_graphs_gradients_within_1e4_of_fp64, tests/test_bench_size_parity_gpu.py).
+# SANITY_GRAD_FP32 is NOT that contract: it is what two fp32 evaluations of the same network (HIP path, fp32 oracle) can be held to
+# against each other -- each is 2-3e-5 .. 3e-4 from the truth on these inputs (test_fp32_rounding_spread_of_the_reference_algorithm) --
+# and is used only by the module-level tests below that have no float64 yardstick (dense tuple input form, single operators).
+SANITY_GRAD_FP32 = 5e-4
 
 
 def strict(a, b):
@@ -34,12 +41,15 @@ def _reference_fp32_distance(name):
     return out
 
 
-@pytest.mark.parametrize('name', CASES)
-def test_golden_forward_backward(name):
+FP32_FIXTURE_BAR_CAP = 7e-4     # what round 3 held every parameter to; the data-derived bar below may be tighter, never looser
+
+
+def _golden_forward_backward(name):
     """Forward (logits, loss, assignment matrices: 1e-4, max-norm AND element-wise) against the reference's fp32 fixture.  Its fp32
-    GRADIENTS are a secondary check only: the contract for gradients is the next test (1e-4 against the reference in float64).  A
+    GRADIENTS are a secondary check only: the contract for gradients is the float64 test (1e-4 against the reference in float64).  A
     second fp32 evaluation cannot be held closer to the reference's fp32 numbers than those are to the truth, so the bar per parameter
-    is max(1e-4, 2.5 x the reference's own fp32-to-fp64 distance on that parameter) -- data from the two fixtures, no constant."""
+    is max(1e-4, 2.5 x the reference's own fp32-to-fp64 distance on that parameter) -- data from the two fixtures -- capped at 7e-4
+    (a regenerated fixture cannot widen it unnoticed; the computed bars are printed)."""
     cfg, batch, sd, out, grad, sd3 = load_case(name, DEV)
     model = build_model(network.SoftPoolingGcnEncoder, cfg, collect_assign=True)
     model.load_state_dict(sd)
@@ -55,12 +65,42 @@ def test_golden_forward_backward(name):
         assert rel_err(s, ref_s) < TOL and elementwise_excess(s, ref_s, TOL) <= 1.0, i         # measured excess <= 0.25
     loss.backward()
     own = _reference_fp32_distance(name)
+    bars = {}
     for k, p in model.named_parameters():
         if k.endswith('att.bias') or float(grad[k].abs().max()) < 1e-9:   # mathematically zero (attention bias under the softmax): absolute
             assert float(p.grad.abs().max()) < 1e-6, k
             continue
-        bar = max(1e-4, 2.5 * own[k])
+        bar = min(max(1e-4, 2.5 * own[k]), FP32_FIXTURE_BAR_CAP)
+        bars[k] = bar
         assert strict(p.grad, grad[k]) < bar, (k, strict(p.grad, grad[k]), bar)
+    wide = sorted(((b, k) for k, b in bars.items() if b > 1e-4), reverse=True)
+    print('%s: fp32-fixture gradient bars above 1e-4 (2.5 x the fp32-to-fp64 distance of the reference itself, cap %.0e): %s'
+          % (name, FP32_FIXTURE_BAR_CAP, [('%.1e' % b, k) for b, k in wide[:6]]))
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_golden_forward_backward(name):
+    _golden_forward_backward(name)
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_golden_forward_backward_on_the_big_route(name, gemm_mode, forced_big_route):
+    """The same fixtures with EVERY product forced onto the 128 x 128 pipelined route, in both GEMM modes: the reference-generated
+    numbers then go through k_gemm_f32<2,2,2,2> (exact) and through k_gemm_split (six bf16 MFMA pairs per fp32 product,
+    csrc/gemm_split.hip) -- the kernels that carry 60 % of the benchmarked step and that no fixture reaches by itself (their products
+    are far below the ~450-tile route).  Same bars as the default routing."""
+    _golden_forward_backward(name)
+    assert (gemm_mode.launches() > 0) == gemm_mode.is_split, (gemm_mode.name, gemm_mode.launches())
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_golden_gradients_within_1e4_of_the_reference_in_fp64_on_the_big_route(name, gemm_mode, forced_big_route):
+    """The north-star gradient bar (1e-4 strict against the REFERENCE's float64 gradients, decisions from the same fixture) with every
+    product forced onto the 128 x 128 route, exact and split: the split mode pinned to reference-produced numbers
+    (profiles/r06_gradients_vs_reference_fp64_split.txt has the per-case margins)."""
+    import discrete
+    discrete.compare_with_reference_fp64(name)
+    assert (gemm_mode.launches() > 0) == gemm_mode.is_split, (gemm_mode.name, gemm_mode.launches())
 
 
 @pytest.mark.parametrize('name', CASES)
@@ -119,9 +159,8 @@ def test_synthetic_cell_graphs_vs_oracle(flags):
     rloss.backward()
     assert rel_err(logits, rl) < TOL and rel_err(loss, rloss) < TOL
     gref = dict(ref.named_parameters())
-    # Gradients here are a sanity check against the fp32 oracle (5e-4 incl. absolute slack): the CONTRACT is 1e-4 against float64 --
-    # test_synthetic_cell_graphs_gradients_within_1e4_of_fp64 below for the SAGE variants, the reference-generated tiny_gin fixture
-    # (test_golden_gradients_within_1e4_of_the_reference_in_fp64) for GIN.
+    # Gradients: the CONTRACT is 1e-4 against float64 -- test_synthetic_cell_graphs_gradients_within_1e4_of_fp64 below for the SAGE
+    # variants, the reference-generated tiny_gin fixture (test_golden_gradients_within_1e4_of_the_reference_in_fp64) for GIN.
     if flags.get('gcn_name') == 'GIN':
         # GIN has no L2 normalisation and sums (not averages) neighbours: the network is ill-conditioned in fp32 -- the reference's
         # own fp32 gradients sit 6.3e-4 away from an fp64 evaluation on exactly this input.  The yardstick is therefore the fp64
@@ -137,9 +176,8 @@ def test_synthetic_cell_graphs_vs_oracle(flags):
         g64 = dict(ref64.named_parameters())
         for k, p in model.named_parameters():
             assert strict(p.grad, g64[k].grad) < 1e-3, (k, strict(p.grad, g64[k].grad), strict(gref[k].grad, g64[k].grad))
-    else:
-        for k, p in model.named_parameters():
-            assert rel_err(p.grad, gref[k].grad) < TOL_GRAD, k
+    # (SAGE variants: no fp32-vs-fp32 gradient assert here any more -- test_synthetic_cell_graphs_gradients_within_1e4_of_fp64 holds the
+    # same configurations to 1e-4 of float64)
     rbuf = dict(ref.named_buffers())
     for k, a in model.named_buffers():
         if a.dtype.is_floating_point:
@@ -200,7 +238,7 @@ def test_dense_tuple_padded_beyond_largest_graph():
     rloss.backward(), gloss.backward()
     gref = dict(ref.named_parameters())
     for k, p in model.named_parameters():
-        assert rel_err(p.grad, gref[k].grad) < TOL_GRAD, k
+        assert rel_err(p.grad, gref[k].grad) < SANITY_GRAD_FP32, k
     rbuf = dict(ref.named_buffers())
     for k, a in model.named_buffers():
         if a.dtype.is_floating_point:
@@ -240,10 +278,10 @@ def test_operator_modules_vs_oracle():
     w = torch.randn_like(want)
     (got * w.to(DEV)).sum().backward()
     (want * w).sum().backward()
-    assert rel_err(xg.grad, xr.grad) < TOL_GRAD and rel_err(ag.grad, ar.grad) < TOL_GRAD
+    assert rel_err(xg.grad, xr.grad) < SANITY_GRAD_FP32 and rel_err(ag.grad, ar.grad) < SANITY_GRAD_FP32
     rgrad = {k: q.grad for k, q in rb.named_parameters()}
     for k, p in pb.named_parameters():
-        assert rel_err(p.grad, rgrad[k]) < TOL_GRAD, k
+        assert rel_err(p.grad, rgrad[k]) < SANITY_GRAD_FP32, k
 
 
 def test_training_learns_a_separable_task():
