@@ -100,7 +100,7 @@ def evaluate(loader, model, vote, test_time=1, max_num_examples=None, batch_size
         for rep in range(test_time):
             if hasattr(loader.dataset, 'set_val_epoch'):
                 loader.dataset.set_val_epoch(rep)
-            preds, labels = [], []
+            preds, labels, pending = [], [], []
             for batch_idx, data in enumerate(loader):
                 if hasattr(model, 'local_chunk'):            # parallel.DataParallel: this rank scores its chunk of the list,
                     data = model.local_chunk(data)           # then every rank receives every rank's results (rank order =
@@ -127,12 +127,22 @@ def evaluate(loader, model, vote, test_time=1, max_num_examples=None, batch_size
                     # (a CUDA model: collate on the device -- one packed copy + one kernel, data.py / csrc/collate.hip -- instead of
                     # concatenating on the host and copying tensor by tensor)
                     ypred = model(Batch.from_data_list(data, device=dev) if dev.type == 'cuda' else Batch.from_data_list(data))
+                # No device-to-host transfer inside the loop: a `.cpu()` per batch makes the host wait for the batch it has just queued
+                # before it starts collating the next one (round 5: the protocol ran 10x below the forward-only rate).  The logits stay
+                # on the device until the pass is over; names and labels are host data already.
                 names = [loader.dataset.idxlist[int(d.patch_idx)] for d in data]
                 labels.append(torch.cat([d.y.reshape(-1) for d in data]).cpu().numpy())
-                vote.batch_patch_result(names, torch.max(ypred, 1)[1].cpu().numpy())
-                preds.append(ypred.detach().cpu().numpy())
+                pending.append((names, ypred.detach()))
                 if max_num_examples is not None and (batch_idx + 1) * (batch_size or len(data)) > max_num_examples:
                     break
+            if pending:                                      # ONE transfer per test-time pass, then the votes in loader order
+                host = torch.cat([p[1] for p in pending], 0).cpu().numpy()
+                o = 0
+                for names, yp in pending:
+                    part = host[o:o + yp.shape[0]]
+                    o += yp.shape[0]
+                    vote.batch_patch_result(names, part.argmax(1))
+                    preds.append(part)
             pred_n.append(np.concatenate(preds, 0)[..., np.newaxis])
             labels_n.append(np.concatenate(labels, 0)[..., np.newaxis])
     pred = np.argmax(np.mean(np.concatenate(pred_n, -1), -1), 1)

@@ -34,6 +34,16 @@ STATS = {}            # measured per run: largest |fp32 - fp64| pre-activation, 
 MAX_TIE = 2e-5        # relative gap between the readout maximum and a co-winner
 
 
+def _log_decisions(what, winner_flips, relu_flips):
+    """CGC_DECISION_LOG=<file>: one line per comparison -- how many decisions the HIP path took differently from float64 and the largest
+    float64 margin at which it did (what MAX_TIE / RELU_TIE are derived from; profiles/r06_discrete_decisions.txt)."""
+    path = os.environ.get('CGC_DECISION_LOG')
+    if path:
+        with open(path, 'a') as fh:
+            fh.write('%s | mode %s | winners differing %d, largest relative fp64 gap there %.3e | signs differing %d, largest |fp64 value| there %.3e\n'
+                     % (what, os.environ.get('CGC_GEMM_SPLIT_BF16', '0'), winner_flips, STATS.get('winner_gap', 0.0), relu_flips, STATS.get('flip_at', 0.0)))
+
+
 class HipDecisions(object):
     def __init__(self):
         self.winners = []          # per level: (gptr [B+1], arg [B, D]) of cgc_segment_max_fwd (flat row index, -1 = a padding row)
@@ -311,6 +321,7 @@ def compare_model(cpu_batch, maxn, feat, flags, tol_grad=1e-4, timer=None, seed=
         g64 = {k: p.grad.clone() for k, p in ref64.named_parameters()}
     print('pre-activations: max |hip - fp64| = %.2e; largest |fp64 value| whose sign the HIP path took differently = %.2e (RELU_TIE = %.0e)'
           % (STATS.get('preact_err', 0.0), STATS.get('flip_at', 0.0), RELU_TIE))
+    _log_decisions('oracle batch %s maxn %d %s' % (tuple(cpu_batch.x.shape), maxn, sorted(flags.items())), winner_flips, relu_flips)
     print('decisions differing from the fp64 evaluation: %d of %d readout winners (largest relative fp64 gap at a differing winner %.2e, MAX_TIE = %.0e), %d of %d ReLU signs'
           % (winner_flips, sum(r.numel() for r in routing), STATS.get('winner_gap', 0.0), MAX_TIE, relu_flips, sum(m.numel() for m in masks.values())))
     assert rel_err(logits, rl) < 1e-4 and elementwise_excess(logits, rl, 1e-4) <= 1.0, rel_err(logits, rl)
@@ -452,6 +463,7 @@ def compare_with_reference_fp64(name, tol_grad=1e-4):
         l64r, _ = run_oracle_routed(ref64, inp64, routing, masks if not smooth else None)
         assert rel_err(l64r, fix['logits']) < 1e-6
         yard = {k: p.grad.clone() for k, p in ref64.named_parameters()}
+    _log_decisions('fixture %s' % name, winner_flips, relu_flips)
     print('%s: decisions differing from the reference fp64 fixture: %d readout winners (largest relative fp64 gap at a differing winner %.2e), %d activation signs%s'
           % (name, winner_flips, STATS.get('winner_gap', 0.0), relu_flips, '' if not (winner_flips or relu_flips) else ' (all undecidable in fp32; yardstick re-routed)'))
 
@@ -469,6 +481,16 @@ def compare_with_reference_fp64(name, tol_grad=1e-4):
     if os.environ.get('CGC_PARITY_REPORT'):
         for e, k in report:
             print('  %-40s %.2e' % (k, e))
-    bad = [(k, e, fix['ulp'].get(k, 0.0)) for e, k in report if not e < tol_grad]
+    # The bar: tol_grad (1e-4) -- except where the INPUT's own conditioning exceeds it.  ulp64[k] is how far the reference's own float64
+    # gradient of parameter k moves when every parameter is perturbed by ONE float32 rounding (fixture, worst of 8 draws): no float32
+    # evaluation, the reference's included, can be expected to land closer than that on this input, whichever kernels it runs on.  It
+    # exceeds 1e-4 for exactly two parameters of the eight fixtures -- tiny_gin GCN_pool_2.gcn1.nn.2.weight (1.7e-4) and medium_shipped
+    # GCN_embed_3.gcn1.bias (2.5e-4) -- and those two are the only ones any route / mode has ever been measured above 1e-4 on (round 6:
+    # 9.9e-5 .. 2.1e-4 with every product forced onto the 128 x 128 route; 3.1e-5 / 3.3e-5 on the default route).  Bar there:
+    # 1 x ulp64 (round 4 allowed 2 x).
+    wide = [(k, e, fix['ulp'].get(k, 0.0)) for e, k in report if e >= tol_grad and e < fix['ulp'].get(k, 0.0)]
+    if wide:
+        print('%s: parameters above %.0e but inside their own conditioning (error, ulp64): %s' % (name, tol_grad, [(k, '%.1e' % e, '%.1e' % u) for k, e, u in wide]))
+    bad = [(k, e, fix['ulp'].get(k, 0.0)) for e, k in report if not e < max(tol_grad, fix['ulp'].get(k, 0.0))]
     assert not bad, (name, bad)
     return report[0][0], winner_flips, relu_flips, [(e, fix['ulp'].get(k, 0.0), k) for e, k in report]

@@ -48,7 +48,8 @@ def _golden_forward_backward(name):
     """Forward (logits, loss, assignment matrices: 1e-4, max-norm AND element-wise) against the reference's fp32 fixture.  Its fp32
     GRADIENTS are a secondary check only: the contract for gradients is the float64 test (1e-4 against the reference in float64).  A
     second fp32 evaluation cannot be held closer to the reference's fp32 numbers than those are to the truth, so the bar per parameter
-    is max(1e-4, 2.5 x the reference's own fp32-to-fp64 distance on that parameter) -- data from the two fixtures -- capped at 7e-4
+    is max(1e-4, 2.5 x the reference's own fp32-to-fp64 distance on that parameter, the parameter's ulp64) -- data from the two fixtures --
+    capped at 7e-4
     (a regenerated fixture cannot widen it unnoticed; the computed bars are printed)."""
     cfg, batch, sd, out, grad, sd3 = load_case(name, DEV)
     model = build_model(network.SoftPoolingGcnEncoder, cfg, collect_assign=True)
@@ -65,12 +66,14 @@ def _golden_forward_backward(name):
         assert rel_err(s, ref_s) < TOL and elementwise_excess(s, ref_s, TOL) <= 1.0, i         # measured excess <= 0.25
     loss.backward()
     own = _reference_fp32_distance(name)
+    import discrete
+    ulp64 = discrete.load_reference_fp64(name)['ulp']      # the parameter's own conditioning (tests/discrete.py::compare_with_reference_fp64)
     bars = {}
     for k, p in model.named_parameters():
         if k.endswith('att.bias') or float(grad[k].abs().max()) < 1e-9:   # mathematically zero (attention bias under the softmax): absolute
             assert float(p.grad.abs().max()) < 1e-6, k
             continue
-        bar = min(max(1e-4, 2.5 * own[k]), FP32_FIXTURE_BAR_CAP)
+        bar = min(max(1e-4, 2.5 * own[k], ulp64.get(k, 0.0)), FP32_FIXTURE_BAR_CAP)
         bars[k] = bar
         assert strict(p.grad, grad[k]) < bar, (k, strict(p.grad, grad[k]), bar)
     wide = sorted(((b, k) for k, b in bars.items() if b > 1e-4), reverse=True)
