@@ -445,8 +445,6 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const GemmArgs a) {   // 2 
     }
 #ifdef CGC_X_NOBAR
     if (MODE != PH_FULL) __syncthreads();
-#elif defined(CGC_GEMM_LDS_BARRIER)      // experiment (round 6): the phase barrier without the release fence's s_waitcnt lgkmcnt(0)
-    lds_barrier();
 #else
     __syncthreads();
 #endif

@@ -58,19 +58,6 @@ __device__ __forceinline__ const float* sgpr_ptr(const float* p) {     // a wave
   return reinterpret_cast<const float*>(((uintptr_t)hi << 32) | lo);
 }
 
-// Workgroup barrier that orders LDS accesses ONLY.  __syncthreads() is fence + s_barrier + fence over every address space, and the
-// release fence becomes `s_waitcnt lgkmcnt(0)` in front of the barrier: the wave sits out the completion of the LDS writes it issued a
-// few cycles earlier before it even arrives.  For LDS -> LDS ordering that wait is not needed: the LDS executes the operations of all
-// waves of a workgroup in one total order (LLVM's AMDGPU memory model says so in SIMemoryLegalizer: "an S_WAITCNT lgkmcnt(0) is not
-// needed as LDS operations for all waves are executed in a total global ordering as observed by all waves"), so a write issued before
-// the barrier is ahead of any read another wave issues behind it.  The empty asm statements keep the COMPILER from moving memory
-// operations across the barrier (the builtin alone is memory(none)); they emit nothing.  Not for hand-offs through global memory.
-__device__ __forceinline__ void lds_barrier() {
-  asm volatile("" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-}
-
 // Branch-free fetch of ANY k-tile -- a full or partial tile of the main operand pair or of an extra K segment -- for the
 // prologue and the tail of the k loop of k_gemm_f32<FAST>: the segment (base pointers, row strides, reduction length) is picked
 // with scalar selects and both operands take the masked unguarded loads.  A free function over a table of VALUES: as a lambda

@@ -43,39 +43,12 @@ typedef unsigned uint4v __attribute__((ext_vector_type(4)));
 #define SBK 16                          // k-tile
 #define SROW 48                         // bytes per LDS row of a plane: 16 bf16 + 16 bytes of padding (16-byte-aligned rows for ds_read_b128)
 constexpr int S_BM = 256, S_BN = 128;
-#ifndef S_BAR_AT
-#define S_BAR_AT 5                      // the k-tile's barrier sits behind this MFMA of the NEXT step (k_gemm_split: tile_step); -1: at the tile's end (round 5)
-#endif
-#ifdef S_BAR_FENCED                     // experiments: the k loop's barrier as __syncthreads() (round 5) instead of lds_barrier()
-#define S_KBARRIER() __syncthreads()
-#else
-#define S_KBARRIER() lds_barrier()
-#endif
 
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {      // v_cvt_pk_bf16_f32: round to nearest even, a in the low half
   float2v t;
   t[0] = a;
   t[1] = b;
   return __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2));
-}
-// x - (low / high half of a packed bf16 pair) as ONE instruction: v_dot2c_f32_bf16  d += p.lo * c.lo + p.hi * c.hi  with the constant pair
-// (-1, 0) or (0, -1) -- instead of expanding the half to fp32 (a shift or a mask) and subtracting.  Both products are exact, one is a
-// zero, and the result (a residual of the split) is exactly representable: no rounding happens whatever the instruction's internal
-// order.  12 vector instructions less per group of four values (22 -> 14).
-#ifndef S_SPLIT_DOT2
-#define S_SPLIT_DOT2 1
-#endif
-__device__ __forceinline__ float residual_lo(unsigned packed, float x) {
-  bf16x2 c;
-  c[0] = (__bf16)-1.0f;
-  c[1] = (__bf16)0.0f;
-  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, packed), c, x, false);
-}
-__device__ __forceinline__ float residual_hi(unsigned packed, float x) {
-  bf16x2 c;
-  c[0] = (__bf16)0.0f;
-  c[1] = (__bf16)-1.0f;
-  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, packed), c, x, false);
 }
 __device__ __forceinline__ float comp(const float4& v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
 
@@ -206,28 +179,18 @@ __device__ __forceinline__ void split_micro(int sidx, GroupState (&gs)[6], const
     s.hp[1] = pack_bf16(s.x[2], s.x[3]);
   } else if (st == 1 || st == 2) {
     const int h = st - 1;
-#if S_SPLIT_DOT2
-    s.r1[2 * h] = residual_lo(s.hp[h], s.x[2 * h]);
-    s.r1[2 * h + 1] = residual_hi(s.hp[h], s.x[2 * h + 1]);
-#else
     const float e0 = __builtin_bit_cast(float, s.hp[h] << 16), e1 = __builtin_bit_cast(float, s.hp[h] & 0xffff0000u);
     s.r1[2 * h] = s.x[2 * h] - e0;
     s.r1[2 * h + 1] = s.x[2 * h + 1] - e1;
-#endif
     asm volatile("" : "+v"(s.r1[2 * h]), "+v"(s.r1[2 * h + 1]));
   } else if (st == 3) {
     s.mp[0] = pack_bf16(s.r1[0], s.r1[1]);
     s.mp[1] = pack_bf16(s.r1[2], s.r1[3]);
   } else if (st == 4 || st == 5) {
     const int h = st - 4;
-#if S_SPLIT_DOT2
-    s.r2[2 * h] = residual_lo(s.mp[h], s.r1[2 * h]);
-    s.r2[2 * h + 1] = residual_hi(s.mp[h], s.r1[2 * h + 1]);
-#else
     const float e0 = __builtin_bit_cast(float, s.mp[h] << 16), e1 = __builtin_bit_cast(float, s.mp[h] & 0xffff0000u);
     s.r2[2 * h] = s.r1[2 * h] - e0;
     s.r2[2 * h + 1] = s.r1[2 * h + 1] - e1;
-#endif
     asm volatile("" : "+v"(s.r2[2 * h]), "+v"(s.r2[2 * h + 1]));
   } else if (st == 6) {
     s.lp[0] = pack_bf16(s.r2[0], s.r2[1]);
@@ -259,17 +222,17 @@ struct SplitFrags {
 };
 __device__ __forceinline__ uint4v frag16(const unsigned char* p) { return *reinterpret_cast<const uint4v*>(p); }
 
-// One tile (or one K piece of a tail tile): id `lin` of the launch's 1-D id space (TileMap).  Every early exit is workgroup-uniform.
 template <bool TA, bool TB>
-__device__ __forceinline__ void split_one_tile(const GemmArgs& a, const unsigned lin, unsigned char* const slds) {
+__global__ __launch_bounds__(256, 1) void k_gemm_split(const GemmArgs a) {
   constexpr int TM = 4, TN = 2, WGN = 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char slds[];
 
   int b, tile_id, piece, S;
   unsigned tj;
   {
     TileMap<S_BM> map;
     map.init(a, threadIdx.x & 63);
-    if (!map.select(a, lin, threadIdx.x & 63, b, tile_id, tj, piece, S)) return;
+    if (!map.select(a, blockIdx.x, threadIdx.x & 63, b, tile_id, tj, piece, S)) return;
   }
   b = __builtin_amdgcn_readfirstlane(b);
   tile_id = __builtin_amdgcn_readfirstlane(tile_id);
@@ -400,16 +363,10 @@ __device__ __forceinline__ void split_one_tile(const GemmArgs& a, const unsigned
       const int t = m / 8, ij = m % 8, i = ij >> 1, j = ij & 1;
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fr.b[j][PB_[t]]), __builtin_bit_cast(bf16x8, fr.a[i][PA_[t]]),
                                                           acc[i][j], 0, 0, 0);
-      // THE barrier of the k-tile sits behind MFMA S_BAR_AT, not at the tile's end: the last group's LDS writes are issued behind MFMA
-      // 47, and a barrier right there made every wave sit out their completion (s_waitcnt lgkmcnt(0) one MFMA after the writes) before
-      // it even reached the barrier.  Here the writes have S_BAR_AT + 1 MFMAs to land.  Legal because a step's LDS traffic is ordered
-      // around that point: every fragment read of tile lt + 1 (written during step lt - 1) comes after it, and so does every write of
-      // tile lt + 2 (the first group's is behind MFMA 7) into the stage whose last reads were step lt - 1's (behind its MFMA 41).
-      if (m == S_BAR_AT) S_KBARRIER();
       // the next tile's fragments, 18 reads of 16 bytes, each plane as soon as this tile's copy is dead
-      if (m >= 8 && m < 12) fr.a[m - 8][2] = frag16(rstage + fa_off + (m - 8) * 32 * SROW + 2 * S_PLA);        // A.lo (pair 0 only)
-      else if (m >= 12 && m < 16) fr.a0n[m - 12] = frag16(rstage + fa_off + (m - 12) * 32 * SROW);              // A.hi' (second copy)
-      else if (m >= 16 && m < 18) fr.b0n[m - 16] = frag16(rstage + fb_off + (m - 16) * 32 * SROW);              // B.hi' (second copy)
+      if (m < 4) fr.a0n[m] = frag16(rstage + fa_off + m * 32 * SROW);                                        // A.hi' (second copy)
+      else if (m < 6) fr.b0n[m - 4] = frag16(rstage + fb_off + (m - 4) * 32 * SROW);                         // B.hi' (second copy)
+      else if (m >= 8 && m < 12) fr.a[m - 8][2] = frag16(rstage + fa_off + (m - 8) * 32 * SROW + 2 * S_PLA);   // A.lo (pair 0 only)
       else if (m >= 24 && m < 28) fr.a[m - 24][1] = frag16(rstage + fa_off + (m - 24) * 32 * SROW + S_PLA);   // A.mid (pairs 1, 2)
       else if (m >= 32 && m < 34) fr.b[m - 32][2] = frag16(rstage + fb_off + (m - 32) * 32 * SROW + 2 * S_PLB);   // B.lo (pair 3)
       else if (m >= 40 && m < 42) fr.b[m - 40][1] = frag16(rstage + fb_off + (m - 40) * 32 * SROW + S_PLB);   // B.mid (pairs 1, 4)
@@ -428,7 +385,7 @@ __device__ __forceinline__ void split_one_tile(const GemmArgs& a, const unsigned
     for (int i = 0; i < 4; ++i) fr.a[i][0] = fr.a0n[i];
     fr.b[0][0] = fr.b0n[0];
     fr.b[1][0] = fr.b0n[1];
-    if (S_BAR_AT < 0) S_KBARRIER();
+    __syncthreads();
   };
   typedef std::true_type FULL_;
   typedef std::false_type ANY_;
@@ -446,10 +403,7 @@ __device__ __forceinline__ void split_one_tile(const GemmArgs& a, const unsigned
   }
 #undef SPLIT_POS
 
-  // Everybody is through its last k step before anybody goes on: the NEXT tile of this workgroup (persistent launch) writes the stages
-  // the other waves' last step still reads.  (With the barrier at the end of every step this is that barrier.)
-  if (S_BAR_AT >= 0) __syncthreads();
-  float* const lds_f = reinterpret_cast<float*>(slds + S_LDS);      // the epilogue's strips have an LDS area of their own: see S_LDS_ALL
+  float* const lds_f = reinterpret_cast<float*>(slds);
   if (S > 1) {
     float* slab = a.ws + ((size_t)tj * S + piece) * (size_t)(S_BM * S_BN) + (size_t)wave * (TM * TN * 16 * 64) + lane * 4;
 #pragma unroll
@@ -463,37 +417,6 @@ __device__ __forceinline__ void split_one_tile(const GemmArgs& a, const unsigned
     return;
   }
   gemm_epilogue<TM, TN>(a, C, M, N, m0 + wm * TM * 32, n0 + wn * TN * 32, acc, lds_f + wave * 32 * (TN * 32 + 4), lane);
-}
-
-// PERSISTENT launch (round 6): one workgroup per CU walks the ids lin = blockIdx.x, + gridDim.x, ... (gridDim.x a multiple of 8: an
-// id keeps its XCD, which is what TileMap's dealing assumes; tiles of one round take the same time, so the static walk is the order the
-// dispatcher would produce anyway).  What it buys: a tile's epilogue ends with 32 store instructions per wave and NOTHING waits for
-// them -- the next tile's prologue (four k-tiles of loads, two splits, the first fragment reads: ~3.5 us before the first MFMA) runs
-// while the stores drain, where a fresh workgroup per tile first had to wait for the old one to retire and for its own launch.  The
-// epilogue's wave-private strips live behind the two stages (LDS: 108 KB + 34 KB of 160 KB), so a wave that is still storing does not
-// collide with the waves that already split the next tile's operands into the stages.
-constexpr int S_STRIPS = 4 * 32 * (2 * 32 + 4) * 4, S_LDS_ALL = S_LDS + S_STRIPS;      // 34816 bytes of strips: 145408 in all
-#ifndef S_PERSISTENT
-#define S_PERSISTENT 1
-#endif
-template <bool TA, bool TB>
-__global__ __launch_bounds__(256, 1) void k_gemm_split(const GemmArgs a, const unsigned ids) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char slds[];
-  // The argument block is re-read from the kernarg segment for every tile (scalar loads out of the constant cache), behind an opaque
-  // copy of the segment's address: left to itself the compiler hoists everything that depends on `a` alone out of the tile loop and
-  // keeps it alive across a body that already uses every register it has (74 spilled scalars, 16 spilled vectors).
-  typedef const __attribute__((address_space(4))) GemmArgs* KArgs;
-  for (unsigned lin = blockIdx.x; lin < ids; lin += gridDim.x) {
-#ifdef __HIP_DEVICE_COMPILE__
-    KArgs ap = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(ap));
-    const GemmArgs at = *ap;
-#else
-    const GemmArgs at = a;              // (the host pass only parses this body)
-#endif
-    split_one_tile<TA, TB>(at, lin, slds);
-  }
-  (void)a;
 }
 
 // Workgroups the chip holds at once: one per CU
@@ -540,14 +463,12 @@ int gemm_split_launch(const GemmArgs& a0, int transA, int transB, int batch, int
   for (int i = 0; i < a.nx; ++i) xk += a.xK[i];
   const int trec = cgc_timing_begin(CGC_TAG_GEMM_128, a.M, a.N, a.K, batch, a.ragged, a.ragged ? (a.ragged == 1 ? m_extent : k_extent) : 0,
                                     xk, stream);
-  const unsigned ids = (unsigned)(tiles + extra);
-  static const int persistent = getenv("CGC_SPLIT_PERSISTENT") ? atoi(getenv("CGC_SPLIT_PERSISTENT")) : S_PERSISTENT;
-  dim3 grid(persistent && ids > (unsigned)kSplitResident ? (unsigned)kSplitResident : ids), block(256);
+  dim3 grid((unsigned)(tiles + extra)), block(256);
 #define SPLIT_LAUNCH(TA_, TB_)                                                                              \
   do {                                                                                                      \
     static bool attr__[CGC_MAX_DEVICES] = {};                                                               \
-    cgc_allow_lds(reinterpret_cast<const void*>(&k_gemm_split<TA_, TB_>), S_LDS_ALL, attr__);               \
-    hipLaunchKernelGGL((k_gemm_split<TA_, TB_>), grid, block, S_LDS_ALL, stream, a, ids);                   \
+    cgc_allow_lds(reinterpret_cast<const void*>(&k_gemm_split<TA_, TB_>), S_LDS, attr__);                   \
+    hipLaunchKernelGGL((k_gemm_split<TA_, TB_>), grid, block, S_LDS, stream, a);                            \
   } while (0)
   if (!transA && !transB) SPLIT_LAUNCH(false, false);
   else if (!transA) SPLIT_LAUNCH(false, true);

@@ -60,3 +60,13 @@ torch.cuda.synchronize()
 el = time.perf_counter() - t0
 print('evaluation protocol (the loop of evalio.evaluate): %d graphs x 5 test-time passes in %.2f s = %.0f graph-passes/s (host collate + H2D + '
       'D2H of the predictions included; one untimed warm-up pass)' % (G, el, 5 * G / el))
+
+if os.environ.get('EVAL_PROFILE'):                        # where the host spends a pass (cProfile, cumulative)
+    import cProfile
+    import pstats
+    pr = cProfile.Profile()
+    pr.enable()
+    protocol(2)
+    torch.cuda.synchronize()
+    pr.disable()
+    pstats.Stats(pr).sort_stats('cumulative').print_stats(28)
