@@ -178,7 +178,14 @@ def _collate_on_device(data_list, device, knn, mean, std, spatial=False):
     stage, turn = _stager.get(off, device.type == 'cuda')
     for k, parts, dim, shape, dtype, o, nbytes in segs:
         if nbytes:
-            torch.cat(parts, dim=dim, out=stage[o:o + nbytes].view(dtype).view(shape))
+            dst = stage[o:o + nbytes].view(dtype).view(shape)
+            if dim == 1 and len(shape) == 2:
+                # edge_index [2, E_i] side by side: row by row, each a contiguous run of the staging buffer (torch.cat along dim 1 into
+                # a 2-row destination walks 2 x 32 strided pieces through its generic path: 9 ms per 32-graph batch, 90 % of the collate)
+                for r in range(shape[0]):
+                    torch.cat([p[r] for p in parts], dim=0, out=dst[r])
+            else:
+                torch.cat(parts, dim=dim, out=dst)
     dbuf = stage.to(device, non_blocking=True) if device.type != 'cpu' else stage.clone()    # the ONE host-to-device copy
     _stager.sent(turn, device)
     dv = {k: dbuf[o:o + nbytes].view(dtype).view(shape) for k, _, _, shape, dtype, o, nbytes in segs}

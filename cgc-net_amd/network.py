@@ -329,10 +329,13 @@ class SoftPoolingGcnEncoder(nn.Module):
         self.native = os.environ.get('CGC_NATIVE', '1') != '0'
         self.native_head = os.environ.get('CGC_NATIVE_HEAD', '1') != '0'     # classification head + loss as one kernel each way
         self.reorder_large = os.environ.get('CGC_REORDER', '1') != '0'       # see _spatially_ordered
-        # 0 = kernels.GEMM_EXACT (fp32 matrix-core chain, the default); 1 = kernels.GEMM_SPLIT_BF16: the six dominant products of a
-        # step (assignment Linear, S^T(AS), their backward: model/network.py:121-122,206-207) as six bf16 MFMA pairs per fp32 product
-        # -- same results to fp32 rounding (include/cgc_hip.h: cgc_gemm_f32_ws), 1.3-1.6x faster on those products
-        self.gemm_mode = int(os.environ.get('CGC_GEMM_SPLIT_BF16', '0'))
+        # 1 = kernels.GEMM_SPLIT_BF16 (the module's default since round 6): the products that take the 128 x 128 route -- from ~450
+        # output tiles up: the six dominant products of a step (assignment Linear, S^T(AS), their backward: model/network.py:121-122,
+        # 206-207) -- run as six bf16 MFMA pairs per fp32 product: same results to fp32 rounding (include/cgc_hip.h: cgc_gemm_f32_ws;
+        # tests/test_split_gemm_gpu.py has the bounds, the reference's fixtures run through it with every product forced onto that
+        # route), 1.3-1.4x faster on those products, the step 1.18x.  0 = kernels.GEMM_EXACT (CGC_GEMM_SPLIT_BF16=0): the fp32
+        # matrix-core chain for every product -- what bench.py's headline `value` is measured with.  Smaller products are exact either way.
+        self.gemm_mode = int(os.environ.get('CGC_GEMM_SPLIT_BF16', '1'))
         self._unorder = None
 
     def __getstate__(self):
@@ -541,9 +544,20 @@ class SoftPoolingGcnEncoder(nn.Module):
         return out2, out3
 
     def forward(self, data):
+        if not kernels.is_native():
+            return self._forward(data)
+        # the per-operator path reads the GEMM mode from the kernel table at call time: installed for this forward only (every
+        # autograd node remembers the mode it ran under for its backward: ops._bind_gemm_mode), restored so that it does not leak
+        # into whatever uses the table next
+        K = kernels.get()
+        keep, K.gemm_mode = K.gemm_mode, int(getattr(self, 'gemm_mode', 0))
+        try:
+            return self._forward(data)
+        finally:
+            K.gemm_mode = keep
+
+    def _forward(self, data):
         self.assign_matrix = []
-        if kernels.is_native():
-            kernels.get().gemm_mode = int(getattr(self, 'gemm_mode', 0))
         if self.load_data_sparse:
             label = data.y
         else:

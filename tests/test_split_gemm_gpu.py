@@ -257,12 +257,15 @@ def test_split_gemm_uniform_k_chunks(kind):
     check(both_modes(run, want, mag), 'uniform chunks %s' % kind, M * N, Kd + parts)
 
 
-@pytest.mark.parametrize('kind', ['normal', 'skewk', 'tiny'])
+@pytest.mark.parametrize('kind', ['normal', 'skewk'])
 def test_split_gemm_dropped_pairs_are_bounded(kind):
     """Term (a) of skew_bars, checked on the operands themselves: the three planes of the kernel's split are re-formed with torch's own
     round-to-nearest-even bf16 conversion (the same rounding as v_cvt_pk_bf16_f32): hi + mid + lo == x EXACTLY, |mid| <= 2^-8 |x|,
     |lo| <= 2^-16 |x|, and the three pairs the kernel drops -- summed in float64 -- stay below 3 U of sum |a||b| on every output.  The
-    kernel's result is then compared with the float64 product MINUS those pairs: what is left is its accumulation error alone."""
+    kernel's result is then compared with the float64 product MINUS those pairs: what is left is its accumulation error alone.
+    (Inputs in the normal range: at 2^-100 -- family 'tiny' -- the lo plane of the smaller elements falls below 2^-126 and the
+    identity hi + mid + lo == x holds only to the denormal flush of whichever unit forms it; that family is held by the error bars of
+    the other tests, as the kernel's header says.)"""
     k = hip()
     M, N, K = 700, 300, 1140
     A, B = gen((M, K), 11, kind), gen((K, N), 12, 'normal' if kind == 'tiny' else kind, -1)

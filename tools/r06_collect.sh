@@ -1,0 +1,17 @@
+#!/bin/bash
+# copy the round-6 measurements (tools/r06_measure.sh -> gpurun_out/r06_*) into profiles/ under the names DESIGN.md cites
+G=gpurun_out; P=profiles
+cp $G/r06_default.json $P/r06_bench_default.json
+cp $G/r06_b4.json $P/r06_bench_b4_line.json
+cp $G/r06_c5_draw.json $P/r06_c5_line.json
+cp $G/r06_c3_trace.txt $P/r06_bench_c3_shipped_kernel_trace.txt
+cp $G/r06_c3_split_trace.txt $P/r06_bench_c3_split_kernel_trace.txt
+cp $G/r06_b4_trace.txt $P/r06_bench_c3_batch4_kernel_trace.txt
+cp $G/r06_c5_trace.txt $P/r06_c5_draw_order_kernel_trace.txt
+(echo "# GPU idle time inside steady-state steps (rocprofv3 kernel trace of bench.py --steps 10 --warmup 3; profiles/gaps_rocpd.py), round 6"; echo "## 32 graphs, default"; cat $G/r06_c3_gaps.txt; echo "## 32 graphs, Python's cyclic garbage collector off during the timed steps (bench.py --no-gc)"; cat $G/r06_c3_nogc_gaps.txt; echo "## 4 graphs per GPU"; cat $G/r06_b4_gaps.txt) > $P/r06_step_gaps.txt
+cp $G/r06_bench_c3_pmc_sq.txt $G/r06_bench_c3_split_pmc_sq.txt $G/r06_bench_c3_pmc_traffic.txt $G/r06_counters.json $G/r06_traffic.json $P/
+cp $G/r06_gemm_calls_by_shape.txt $G/r06_split_gemm_standalone.txt $G/r06_split_gemm_ksweep.txt $P/
+cp $G/r06_eval.txt $P/r06_eval_throughput.txt
+(echo "# HIP path vs the REFERENCE's float64 gradients (tests/golden/*_fp64.npz), all eight fixtures, bar 1e-4 strict (no ulp64 widening); tools/golden_fp64_report.py on 1xMI355X, round 6"; grep -v "amdgpu.ids" $G/r06_fp64_report.txt | grep -v "^  ") > $P/r06_gradients_vs_reference_fp64.txt
+(echo "# round 6 configurations, 1xMI355X (tools/final_measure.sh r06): headline = exact fp32 GEMM; 'split mode' = the second leg of the same bench run with the six dominant products in CGC_GEMM_SPLIT_BF16"; tail -10 $G/r06_configurations_raw.txt) > $P/r06_configurations.txt
+if [ -f $G/r06_split_gemm_error_table.txt ]; then (echo "# cgc_gemm_f32_ws mode CGC_GEMM_SPLIT_BF16 (csrc/gemm_split.hip) next to the exact fp32 MFMA kernel, every form the step uses; error of every output against float64 relative to sum_k |a||b|; inputs: normal = N(0,1); wide = every OUTPUT row / column scaled by 2^-30..2^+30; skewk = the same scales along K in both operands (one or two terms are the sum); tiny = scaled by 2^-100.  tests/test_split_gemm_gpu.py on 1xMI355X, round 6"; cat $G/r06_split_gemm_error_table.txt) > $P/r06_split_gemm_error_table.txt; fi
