@@ -110,6 +110,13 @@ class Batch(Data):
         # per-graph row offsets: travel to the device with the batch (.to()), so that the model does not start every step with a
         # blocking host-to-device copy of its own
         out._gptr = torch.tensor([0] + list(np.cumsum(out._node_counts)), dtype=torch.int32)
+        # the edges of graph g are edge_index[:, _eptr[g]:_eptr[g+1]] (this collate concatenates per graph): lets the CSR build work
+        # graph by graph in two launches (graph.BatchGraph -> cgc_graph_build_local); _etotal guards against an edge_index that
+        # was replaced afterwards
+        if 'edge_index' in keys and all(torch.is_tensor(d.edge_index) for d in data_list):
+            ec = [int(d.edge_index.shape[1]) for d in data_list]
+            out._eptr = torch.tensor([0] + list(np.cumsum(ec)), dtype=torch.int32)
+            out._etotal = int(sum(ec))
         # every item says its nodes are listed grid cell by grid cell (spatial_order): the wide aggregation may stage neighbour unions
         # of consecutive rows in LDS (graph.BatchGraph.spatial -> cgc_spmm_graphs visit bit 2)
         if all(getattr(d, '_spatial', False) for d in data_list):
@@ -224,6 +231,9 @@ def _collate_on_device(data_list, device, knn, mean, std, spatial=False):
     out.num_graphs = B
     out._node_counts = counts
     out._gptr = dv['_gptr']
+    if has_edges and knn is None:                      # (see the host collate: the edge list is grouped by graph)
+        out._eptr = dv['_eptr']
+        out._etotal = int(sum(ecounts))
     if spatial or all(getattr(d, '_spatial', False) for d in data_list):
         out._spatial = True
     return out

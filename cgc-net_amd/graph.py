@@ -83,13 +83,19 @@ class BatchGraph(object):
         # travels on as cgc_spmm_graphs' visit bit 2, which the default gather kernel ignores (it selects the experimental LDS-staged
         # kernel under CGC_SPMM_PATCH=1).  Never about results.
         g.spatial = bool(getattr(batch, '_spatial', False))
-        g._build(edge_index.contiguous(), renorm_p)
+        # the collate's note that the edge list is grouped by graph (Batch._eptr), if it still describes this edge_index
+        eptr = getattr(batch, '_eptr', None)
+        if not (torch.is_tensor(eptr) and eptr.dtype == torch.int32 and eptr.device == edge_index.device and eptr.numel() == g.B + 1
+                and getattr(batch, '_etotal', -1) == edge_index.shape[1]):
+            eptr = None
+        g._build(edge_index.contiguous(), renorm_p, eptr)
         return g
 
-    def _build(self, edge_index, renorm_p):
+    def _build(self, edge_index, renorm_p, eptr=None):
         K = kernels.get()
         if hasattr(K, 'graph_build'):          # the library's composite entry point: one call, two allocations
-            s = K.graph_build(edge_index, self.n, None if renorm_p is None else float(renorm_p))
+            s = K.graph_build(edge_index, self.n, None if renorm_p is None else float(renorm_p),
+                              gptr=self.gptr if eptr is not None else None, eptr=eptr, num_graphs=self.B, nmax=self.nmax)
             self.rowptr, self.col, self.rowidx = s['rowptr'], s['col'], s['rowidx']
             self.t_rowptr, self.t_col, self.t_perm = s['t_rowptr'], s['t_col'], s['t_perm']
             self.cap, self.bad_edges = s['cap'], s['bad_edges']

@@ -246,6 +246,7 @@ def get():
     return _instance
 
 
+_EINVAL = -1                            # include/cgc_hip.h: CGC_EINVAL (nothing was launched)
 GEMM_EXACT, GEMM_SPLIT_BF16 = 0, 1      # include/cgc_hip.h: CGC_GEMM_EXACT / CGC_GEMM_SPLIT_BF16
 
 
@@ -361,6 +362,9 @@ class HipKernels(KernelSpec):
     # GEMM_SPLIT_BF16 -- the big products as six bf16 MFMA pairs per fp32 product (csrc/gemm_split.hip).  The encoder sets it from
     # its own ``gemm_mode`` at the top of forward(); the sequencer gets the same choice through cgc_level_desc.flags bit 1.
     gemm_mode = 0
+    # graph structure graph by graph in two launches when the Batch says how its edge list is grouped (cgc_graph_build_local;
+    # CGC_GRAPH_LOCAL=0 / False: always the general build -- A-B timing, tests)
+    graph_local = os.environ.get('CGC_GRAPH_LOCAL', '1') != '0'
 
     def __init__(self):
         path = lib_path()
@@ -374,6 +378,7 @@ class HipKernels(KernelSpec):
         from . import _abi
         _abi.declare(self.lib)
         self._ws_cache = {}
+        self._graph_local_max = int(self.lib.cgc_graph_local_max_nodes())
 
     # -- helpers
     @staticmethod
@@ -421,9 +426,12 @@ class HipKernels(KernelSpec):
         out['bad_edges'] = ws[o:o + 1]              # device-side count of dropped out-of-range edges (no sync here)
         return out
 
-    def graph_build(self, edge_index, n, renorm_p):
+    def graph_build(self, edge_index, n, renorm_p, gptr=None, eptr=None, num_graphs=0, nmax=0):
         """csr_build (+ edge_renorm + csr_transpose_vals when renorm_p is not None) + csr_invdeg behind ONE library call, all
-        outputs carved out of two allocations.  Returns the dict of csr_build plus val / t_val (None without renorm) and inv_d."""
+        outputs carved out of two allocations.  Returns the dict of csr_build plus val / t_val (None without renorm) and inv_d.
+        With ``gptr`` / ``eptr`` (int32 [B+1] on the device: node and edge ranges of the graphs, the edge list grouped by graph as
+        Batch.from_data_list emits it) the structure is built graph by graph in two launches (cgc_graph_build_local: same arrays bit
+        for bit); graphs beyond its node limit take the general build."""
         self._dev(edge_index)
         edge_index = edge_index.to(torch.int64).contiguous()
         E = edge_index.shape[1]
@@ -442,9 +450,19 @@ class HipKernels(KernelSpec):
         val = fbuf[:cap] if renorm else None
         t_val = fbuf[a(cap):a(cap) + cap] if renorm else None
         inv_d = fbuf[2 * a(cap):] if renorm else fbuf
-        self._chk(self.lib.cgc_graph_build(_ptr(edge_index), ctypes.c_int64(E), n, ctypes.c_float(-1.0 if renorm_p is None else renorm_p),
-                                           _ptr(rowptr), _ptr(col), _ptr(rowidx), _ptr(t_rowptr), _ptr(t_col), _ptr(t_perm), _ptr(val),
-                                           _ptr(t_val), _ptr(inv_d), _ptr(ws), self._stream()), 'cgc_graph_build')
+        rc = _EINVAL
+        if gptr is not None and eptr is not None and self.graph_local and 0 < nmax <= self._graph_local_max:
+            self._dev(gptr, eptr)
+            rc = self.lib.cgc_graph_build_local(_ptr(edge_index), ctypes.c_int64(E), n, _ptr(gptr), _ptr(eptr), int(num_graphs), int(nmax),
+                                                ctypes.c_float(-1.0 if renorm_p is None else renorm_p), _ptr(rowptr), _ptr(col), _ptr(rowidx),
+                                                _ptr(t_rowptr), _ptr(t_col), _ptr(t_perm), _ptr(val), _ptr(t_val), _ptr(inv_d), _ptr(ws),
+                                                self._stream())
+            if rc != _EINVAL:
+                self._chk(rc, 'cgc_graph_build_local')
+        if rc == _EINVAL:                                  # no graph ranges, or outside the graph-local build's envelope
+            self._chk(self.lib.cgc_graph_build(_ptr(edge_index), ctypes.c_int64(E), n, ctypes.c_float(-1.0 if renorm_p is None else renorm_p),
+                                               _ptr(rowptr), _ptr(col), _ptr(rowidx), _ptr(t_rowptr), _ptr(t_col), _ptr(t_perm), _ptr(val),
+                                               _ptr(t_val), _ptr(inv_d), _ptr(ws), self._stream()), 'cgc_graph_build')
         bo = int(self.lib.cgc_csr_bad_edges_offset(ctypes.c_int64(E), n, int(renorm)))
         return dict(rowptr=rowptr, t_rowptr=t_rowptr, col=col, rowidx=rowidx, t_col=t_col, t_perm=t_perm, cap=E + (n if renorm else 0),
                     bad_edges=ws[bo:bo + 1], val=val, t_val=t_val, inv_d=inv_d)

@@ -43,7 +43,7 @@ typedef void* cgc_stream_t; /* hipStream_t */
  *   3: round 5 (cgc_gemm_f32_ws / cgc_gemm_f32_cat_ws take a `mode`; cgc_level_desc.flags bit 1; head: a label outside [0, L) other
  *      than -100 makes the loss NaN instead of being ignored)
  *   4: round 6 (removed: cgc_adj_prep_fwd2, cgc_adj_grad_operands, cgc_zero_diag and cgc_level_desc.flags bit 0 -- the thin-operand
- *      adjacency gradient; a descriptor with bit 0 set is refused) */
+ *      adjacency gradient; a descriptor with bit 0 set is refused.  Added: cgc_graph_build_local, cgc_graph_local_max_nodes) */
 #define CGC_ABI_VERSION 4
 int cgc_abi_version(void);
 
@@ -111,6 +111,17 @@ int cgc_csr_invdeg(const int* rowptr, const float* val, int n, float* out, cgc_s
  * when renorm_p < 0.  ws as cgc_csr_build. */
 int cgc_graph_build(const int64_t* edge_index, int64_t E, int n, float renorm_p, int* rowptr, int* col, int* rowidx, int* t_rowptr,
                     int* t_col, int* t_perm, float* val, float* t_val, float* inv_d, int* ws, cgc_stream_t stream);
+/* The same arrays, bit for bit, for a batch whose edge list is GROUPED BY GRAPH -- what Batch.from_data_list emits: the edges of graph
+ * g are edge_index[:, eptr[g] .. eptr[g+1]) and both end points lie in its node range gptr[g] .. gptr[g+1] (gptr, eptr: int32
+ * [B + 1] on the device; nmax = the largest graph, known on the host).  One workgroup per graph with its counters in LDS: TWO
+ * launches instead of ~20 (csrc/csr.hip: k_graph_local_rows, k_graph_local_finish).  An edge that leaves its own graph's node range is
+ * dropped and counted like an out-of-range id (cgc_graph_build would keep an edge between two graphs of the batch; the reference's
+ * dense indexing, model/utils.py:28-33, cannot represent one).  Returns CGC_EINVAL -- nothing launched, use cgc_graph_build -- when
+ * nmax > cgc_graph_local_max_nodes(), B > 65535 or 2 B > n + 1.  Outputs and ws as cgc_graph_build. */
+int cgc_graph_local_max_nodes(void);
+int cgc_graph_build_local(const int64_t* edge_index, int64_t E, int n, const int* gptr, const int* eptr, int B, int nmax, float renorm_p,
+                          int* rowptr, int* col, int* rowidx, int* t_rowptr, int* t_col, int* t_perm, float* val, float* t_val,
+                          float* inv_d, int* ws, cgc_stream_t stream);
 
 /* ---- A4 / A8: neighbour aggregation.  Replaces torch.matmul(adj, x) inside DenseSAGEConv
  * (model/network.py:114-116) and the inner product of (S^T A) S (model/network.py:207):

@@ -100,6 +100,111 @@ def test_csr_build_bit_exact(counts, add_diag):
         assert torch.equal(got[k].cpu()[:nnz], want[k][:nnz]), k
 
 
+def grouped_graph(counts, deg, seed, heavy_column=False):
+    """A batch as Batch.from_data_list emits it: per graph an unsorted edge list with duplicates, the lists concatenated in graph
+    order.  Returns (edge_index int64 [2, E], n, gptr, eptr)."""
+    rng = np.random.RandomState(seed)
+    parts, off, ecount = [], 0, []
+    for n in counts:
+        if n > 0:
+            r, c = rng.randint(0, n, size=n * deg), rng.randint(0, n, size=n * deg)
+            if n > 3:
+                keep = r != 1                                     # an empty row
+                r, c = r[keep], c[keep]
+            if heavy_column and n > 40:
+                c[: min(40, len(c))] = 2                          # one column with more sources than the in-LDS sort holds
+                r[: min(40, len(r))] = np.arange(min(40, len(r))) % n
+            e = np.stack([r, c]) + off
+            e = np.concatenate([e, e[:, :5]], axis=1)             # duplicates
+            e = e[:, rng.permutation(e.shape[1])]
+        else:
+            e = np.zeros((2, 0), dtype=np.int64)
+        parts.append(e)
+        ecount.append(e.shape[1])
+        off += n
+    ei = torch.from_numpy(np.concatenate(parts, axis=1).astype(np.int64))
+    gptr = torch.tensor(np.concatenate([[0], np.cumsum(counts)]), dtype=torch.int32)
+    eptr = torch.tensor(np.concatenate([[0], np.cumsum(ecount)]), dtype=torch.int32)
+    return ei, off, gptr, eptr
+
+
+@pytest.mark.parametrize('counts,deg,heavy', [([5, 9, 12], 3, False), ([300, 0, 257, 64], 6, True), ([1800, 2100, 1500, 1, 4096], 9, True),
+                                               ([0, 40], 20, False)])
+@pytest.mark.parametrize('renorm_p', [None, 0.4])
+def test_graph_build_graph_by_graph_equals_the_general_build(counts, deg, heavy, renorm_p):
+    """cgc_graph_build_local (one workgroup per graph, two launches) against cgc_graph_build on the same batch: every array bit for
+    bit -- rows longer than the in-LDS sort's depth, a column with 40 sources, empty graphs, a one-node graph, a graph at the node
+    limit, duplicates, with and without the diagonal / edge weights of _re_norm_adj.  Then the same list with three edges that leave
+    their graph: dropped and counted, everything else unchanged."""
+    k = hip()
+    ei, n, gptr, eptr = grouped_graph(counts, deg, seed=len(counts) + deg, heavy_column=heavy)
+    B, nmax = len(counts), max(counts)
+    before = k.graph_local
+    try:
+        k.graph_local = False
+        want = k.graph_build(g(ei), n, renorm_p)
+        k.graph_local = True
+        got = k.graph_build(g(ei), n, renorm_p, gptr=g(gptr), eptr=g(eptr), num_graphs=B, nmax=nmax)
+    finally:
+        k.graph_local = before
+    torch.cuda.synchronize()
+    nnz = int(want['rowptr'][n])
+    assert int(got['bad_edges']) == 0 and int(want['bad_edges']) == 0
+    assert torch.equal(got['rowptr'], want['rowptr']) and torch.equal(got['t_rowptr'], want['t_rowptr'])
+    for key in ('col', 'rowidx', 't_col', 't_perm'):
+        assert torch.equal(got[key][:nnz], want[key][:nnz]), key
+    assert torch.equal(got['inv_d'], want['inv_d'])
+    if renorm_p is not None:
+        assert torch.equal(got['val'][:nnz], want['val'][:nnz]) and torch.equal(got['t_val'][:nnz], want['t_val'][:nnz])
+    # the oracle too (the general build is itself checked against it above)
+    ref = REF.csr_build(ei, n, renorm_p is not None)
+    assert torch.equal(got['rowptr'].cpu(), ref['rowptr']) and torch.equal(got['col'].cpu()[:nnz], ref['col'][:nnz])
+    real = [i for i, c in enumerate(counts) if c > 0]
+    if len(real) >= 2 and eptr[real[0] + 1] - eptr[real[0]] > 3:
+        e0 = int(eptr[real[0]])
+        dirty = ei.clone()
+        other = int(gptr[real[1]])                                    # a node of ANOTHER graph, an id past the batch, a negative id
+        dirty[1, e0] = other
+        dirty[0, e0 + 1] = n + 3
+        dirty[1, e0 + 2] = -2
+        clean = torch.cat([ei[:, :e0], ei[:, e0 + 3:]], dim=1)
+        ref2 = REF.csr_build(clean, n, renorm_p is not None)
+        got2 = k.graph_build(g(dirty), n, renorm_p, gptr=g(gptr), eptr=g(eptr), num_graphs=B, nmax=nmax)
+        torch.cuda.synchronize()
+        nnz2 = int(ref2['rowptr'][n])
+        assert int(got2['bad_edges']) == 3
+        assert torch.equal(got2['rowptr'].cpu(), ref2['rowptr']) and torch.equal(got2['t_rowptr'].cpu(), ref2['t_rowptr'])
+        for key in ('col', 'rowidx', 't_col', 't_perm'):
+            assert torch.equal(got2[key].cpu()[:nnz2], ref2[key][:nnz2]), key
+
+
+def test_graph_build_takes_the_general_route_outside_the_local_envelope():
+    """A graph beyond cgc_graph_local_max_nodes(), and a Batch whose edge_index was replaced after the collate (the note about the
+    grouping no longer describes it): the general build runs, results as always."""
+    from cgc_net_amd.data import Batch, SyntheticCellGraphs
+    from cgc_net_amd.graph import BatchGraph
+    k = hip()
+    limit = int(k.lib.cgc_graph_local_max_nodes())
+    ei, n, gptr, eptr = grouped_graph([limit + 1, 30], 4, seed=1)
+    got = k.graph_build(g(ei), n, None, gptr=g(gptr), eptr=g(eptr), num_graphs=2, nmax=limit + 1)
+    ref = REF.csr_build(ei, n, False)
+    torch.cuda.synchronize()
+    nnz = int(ref['rowptr'][n])
+    assert torch.equal(got['rowptr'].cpu(), ref['rowptr']) and torch.equal(got['col'].cpu()[:nnz], ref['col'][:nnz])
+    ds = SyntheticCellGraphs(3, 120, 4, base_seed=5)
+    b = Batch.from_data_list([ds[i] for i in range(3)]).to(DEV)
+    assert b._eptr.device.type == 'cuda' and b._etotal == b.edge_index.shape[1]
+    g1 = BatchGraph.from_batch(b, 0.4)
+    b2 = Batch.from_data_list([ds[i] for i in range(3)]).to(DEV)
+    b2.edge_index = b2.edge_index[:, torch.randperm(b2.edge_index.shape[1], device=DEV)][:, :-4]      # regrouped and shortened behind the collate's back
+    g2 = BatchGraph.from_batch(b2, 0.4)
+    ref2 = REF.csr_build(b2.edge_index.cpu(), b2.x.shape[0], True)
+    torch.cuda.synchronize()
+    assert torch.equal(g2.rowptr.cpu(), ref2['rowptr'])
+    ref1 = REF.csr_build(b.edge_index.cpu(), b.x.shape[0], True)
+    assert torch.equal(g1.rowptr.cpu(), ref1['rowptr']) and int(g1.bad_edges) == 0
+
+
 def test_csr_presorted_knn_input():
     from cgc_net_amd.data import Batch, SyntheticCellGraphs
     ds = SyntheticCellGraphs(3, 200, 4, base_seed=2)
