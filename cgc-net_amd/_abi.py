@@ -19,7 +19,7 @@ PROTOTYPES = {
     'cgc_csr_transpose_vals': [P, P, P, I, P, P],
     'cgc_csr_invdeg': [P, P, I, P, P],
     'cgc_graph_build': [P, L, I, F, P, P, P, P, P, P, P, P, P, P, P],
-    'cgc_graph_build_local': [P, L, I, P, P, I, I, F, P, P, P, P, P, P, P, P, P, P, P],
+    'cgc_graph_build_local': [P, L, I, P, P, I, I, I, F, P, P, P, P, P, P, P, P, P, P, P],
     'cgc_graph_local_max_nodes': [],
     'cgc_spmm': [P, P, P, P, P, P, P, P, I, I, P],
     'cgc_spmm_graphs': [P, P, P, P, P, P, P, P, I, I, I, P, I, I, I, P],

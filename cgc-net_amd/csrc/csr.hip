@@ -320,37 +320,41 @@ extern "C" int cgc_graph_build(const int64_t* edge_index, int64_t E, int n, floa
 // ------------------------------------------------------------------------------------------------
 // The same structure for a batch whose edge list is GROUPED BY GRAPH (round 6): what Batch.from_data_list emits -- the edges of
 // graph g are edge_index[:, eptr[g] .. eptr[g+1]) and stay inside its node range gptr[g] .. gptr[g+1].  Then nothing crosses a
-// graph: ONE workgroup builds one graph's rows with its counters in LDS (histogram, scan, fill, per-row sort + de-duplication,
-// unique counts), and a second launch -- it needs every graph's unique count for its place in the compacted arrays -- compacts,
-// transposes (again histogram / scan / fill / per-column sort in LDS) and forms the edge weights of _re_norm_adj, their transposed
-// copy and the mean divisor.  TWO launches instead of the 19-23 of cgc_graph_build (0.24 ms of a 32-graph step, ~20 launches of
-// pure latency at 4 graphs per GPU).  Every array comes out bit for bit as cgc_graph_build writes it (sorted rows: the order in
-// which the atomics hand out slots does not survive the sort).
+// graph: ONE workgroup builds one graph's rows with everything it indexes at random in LDS (histogram, scan, fill, per-row sort +
+// de-duplication, unique counts), and a second launch -- it needs every graph's unique count for its place in the compacted arrays --
+// compacts, transposes (again histogram / scan / fill / per-column sort in LDS) and forms the edge weights of _re_norm_adj, their
+// transposed copy and the mean divisor.  TWO launches instead of the 19-23 of cgc_graph_build.  Every array comes out bit for bit as
+// cgc_graph_build writes it (sorted rows: the order in which the atomics hand out slots does not survive the sort).
+// What the first version of these kernels taught (57 + 132 us per batch with 32 workgroups -- no faster than the 20 launches): a lone
+// workgroup per graph is a chain of memory round trips unless every pass over global memory is SLOT-parallel -- lane k touches element
+// k: coalesced, independent, several in flight per thread -- and everything indexed by row or column lives in LDS.  A thread that
+// walks "its" row in global memory pays a round trip per element, and a wave storing 64 ten-element runs touches 64 cache lines per
+// instruction.
 // Differences by design: (1) an edge whose end points are not both inside its own graph's node range is dropped and counted as a bad
 // edge (the general build keeps an edge between two graphs of the batch; the reference's dense indexing cannot represent one);
-// (2) graphs are limited to GL_MAXN nodes (the LDS counters) -- the entry point refuses larger ones and the caller takes the
-// general build.
-#define GL_MAXN 4096
-#define GL_DEPTH 16        // entries of one row / column the in-LDS insertion sort holds per thread (longer ones: sorted in place in memory)
+// (2) the envelope: nmax <= 4095 nodes, emax + nmax <= 32767 entries per graph, and both kernels' LDS (20 (nmax + 1) + 4 (emax + nmax)
+// bytes + 4 KB) within the 160 KB of a CU -- the entry point refuses anything else and the caller takes the general build.
+#define GL_MAXN 4095
+#define GL_MAXE 32767
+#define GL_T 1024
 
 struct GlArgs {
   const int64_t* ei;
   int64_t E;
-  int n, B, add_diag;
+  int n, B, add_diag, n1, ec;  // n1 = nmax + 1 rounded up to 4 ints, ec = emax + nmax rounded up to 64 entries
   float p;                     // < 0: no edge weights
   const int* gptr;
   const int* eptr;
   int *rowptr, *col, *rowidx, *t_rowptr, *t_col, *t_perm;
   float *val, *t_val, *inv_d;
-  int *start, *gnnz, *gbad, *colraw, *bad_out;
+  int *gnnz, *gbad, *colraw, *bad_out;
 };
 
-// exclusive scan of v[0 .. m) (m <= GL_MAXN) into out[0 .. m], out[m] = total; T threads, every thread a contiguous slice.
-// `tot` : T / 64 ints of LDS.  Ends with a barrier.
-template <int T>
+// exclusive scan of v[0 .. m) into out[0 .. m], out[m] = total; GL_T threads, every thread a contiguous slice.  `tot`: 16 ints of LDS.
+// Ends with a barrier (and needs one in front of it if v was just written).
 __device__ __forceinline__ int block_scan_lds(const int* __restrict__ v, int* __restrict__ out, int m, int* __restrict__ tot) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int per = (m + T - 1) / T;
+  const int per = (m + GL_T - 1) / GL_T;
   const int lo = min(t * per, m), hi = min(lo + per, m);
   int s = 0;
   for (int i = lo; i < hi; ++i) s += v[i];
@@ -362,7 +366,7 @@ __device__ __forceinline__ int block_scan_lds(const int* __restrict__ v, int* __
   if (lane == 63) tot[wave] = incl;
   __syncthreads();
   int wbase = 0, total = 0;
-  for (int w = 0; w < T / 64; ++w) {
+  for (int w = 0; w < GL_T / 64; ++w) {
     if (w < wave) wbase += tot[w];
     total += tot[w];
   }
@@ -377,211 +381,248 @@ __device__ __forceinline__ int block_scan_lds(const int* __restrict__ v, int* __
   return total;
 }
 
-__global__ __launch_bounds__(1024) void k_graph_local_rows(const GlArgs a) {
-  __shared__ int cnt[GL_MAXN + 1], start[GL_MAXN + 1], cur[GL_MAXN + 1];
-  __shared__ int strip[GL_DEPTH * 1024];
+// blk[b] = the segment (row of ptr[0 .. m]) that holds element 64 b, for b = 0 .. ceil(total / 64); then owner(k) walks a few
+// segments from blk[k >> 6] instead of bisecting all of ptr for every element.
+__device__ __forceinline__ void build_block_index(const int* __restrict__ ptr, int m, int total, unsigned short* __restrict__ blk) {
+  for (int b = threadIdx.x; b * 64 < total; b += GL_T) {
+    const int k = b * 64;
+    int lo = 0, hi = m;                              // largest i with ptr[i] <= k
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (ptr[mid] <= k) lo = mid; else hi = mid;
+    }
+    blk[b] = (unsigned short)lo;
+  }
+}
+__device__ __forceinline__ int owner_of(const int* __restrict__ ptr, const unsigned short* __restrict__ blk, int k) {
+  int i = blk[k >> 6];
+  while (ptr[i + 1] <= k) ++i;
+  return i;
+}
+
+__global__ __launch_bounds__(GL_T) void k_graph_local_rows(const GlArgs a) {
+  extern __shared__ __attribute__((aligned(16))) int gl_lds[];
+  int* const cnt = gl_lds;
+  int* const start = cnt + a.n1;
+  int* const cur = start + a.n1;
+  unsigned short* const craw = reinterpret_cast<unsigned short*>(cur + a.n1);      // [ec] local column ids, row by row
+  unsigned short* const blk = craw + a.ec;                                          // [ec / 64 + 1]
   __shared__ int tot[16];
   const int g = blockIdx.x, t = threadIdx.x;
   const int g0 = a.gptr[g], ng = a.gptr[g + 1] - g0;
   const int e0 = a.eptr[g], e1 = a.eptr[g + 1];
   const int base = e0 + (a.add_diag ? g0 : 0);            // this graph's segment of colraw (capacity order = the general build's)
-  for (int i = t; i <= ng; i += 1024) { cnt[i] = a.add_diag && i < ng ? 1 : 0; cur[i] = 0; }
+  for (int i = t; i <= ng; i += GL_T) { cnt[i] = a.add_diag && i < ng ? 1 : 0; cur[i] = 0; }
   __syncthreads();
   int bad = 0;
-  for (int e = e0 + t; e < e1; e += 1024) {
-    const int64_t r = a.ei[e] - g0, c = a.ei[a.E + e] - g0;
-    if (r < 0 || r >= ng || c < 0 || c >= ng) ++bad;
-    else atomicAdd(&cnt[(int)r], 1);
+  for (int e = e0 + t; e < e1; e += 4 * GL_T) {           // four independent edge loads in flight per thread
+    int64_t r[4], c[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = min(e + u * GL_T, e1 - 1);
+      r[u] = a.ei[idx];
+      c[u] = a.ei[a.E + idx];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (e + u * GL_T >= e1) continue;
+      const int64_t rl = r[u] - g0, cl = c[u] - g0;
+      if (rl < 0 || rl >= ng || cl < 0 || cl >= ng) ++bad;
+      else atomicAdd(&cnt[(int)rl], 1);
+    }
   }
   __syncthreads();
-  block_scan_lds<1024>(cnt, start, ng, tot);
-  for (int e = e0 + t; e < e1; e += 1024) {
-    const int64_t r = a.ei[e] - g0, c = a.ei[a.E + e] - g0;
-    if (r < 0 || r >= ng || c < 0 || c >= ng) continue;
-    a.colraw[base + start[(int)r] + atomicAdd(&cur[(int)r], 1)] = (int)c + g0;
+  block_scan_lds(cnt, start, ng, tot);
+  for (int e = e0 + t; e < e1; e += 4 * GL_T) {
+    int64_t r[4], c[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = min(e + u * GL_T, e1 - 1);
+      r[u] = a.ei[idx];
+      c[u] = a.ei[a.E + idx];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (e + u * GL_T >= e1) continue;
+      const int64_t rl = r[u] - g0, cl = c[u] - g0;
+      if (rl < 0 || rl >= ng || cl < 0 || cl >= ng) continue;
+      craw[start[(int)rl] + atomicAdd(&cur[(int)rl], 1)] = (unsigned short)cl;
+    }
   }
   if (a.add_diag)
-    for (int i = t; i < ng; i += 1024) a.colraw[base + start[i] + atomicAdd(&cur[i], 1)] = g0 + i;
-  __syncthreads();                                         // (workgroup-scope fence included: the fills are visible to every wave)
-  // sort every row by column and drop duplicates; the unique count goes where the histogram was
-  for (int i = t; i < ng; i += 1024) {
-    int* row = a.colraw + base + start[i];
+    for (int i = t; i < ng; i += GL_T) craw[start[i] + atomicAdd(&cur[i], 1)] = (unsigned short)i;
+  __syncthreads();
+  // sort every row by column and drop duplicates, in place in LDS; the unique count goes where the histogram was
+  for (int i = t; i < ng; i += GL_T) {
+    unsigned short* row = craw + start[i];
     const int len = start[i + 1] - start[i];
-    int u = 0;
-    if (len <= GL_DEPTH) {
-      for (int k = 0; k < len; ++k) strip[k * 1024 + t] = row[k];
-      for (int k = 1; k < len; ++k) {
-        const int v = strip[k * 1024 + t];
-        int j = k - 1;
-        while (j >= 0 && strip[j * 1024 + t] > v) { strip[(j + 1) * 1024 + t] = strip[j * 1024 + t]; --j; }
-        strip[(j + 1) * 1024 + t] = v;
-      }
-      for (int k = 0; k < len; ++k)
-        if (k == 0 || strip[k * 1024 + t] != strip[(k - 1) * 1024 + t]) row[u++] = strip[k * 1024 + t];
-    } else {
-      for (int k = 1; k < len; ++k) {
-        const int v = row[k];
-        int j = k - 1;
-        while (j >= 0 && row[j] > v) { row[j + 1] = row[j]; --j; }
-        row[j + 1] = v;
-      }
-      for (int k = 0; k < len; ++k)
-        if (k == 0 || row[k] != row[k - 1]) row[u++] = row[k];
+    for (int k = 1; k < len; ++k) {
+      const unsigned short v = row[k];
+      int j = k - 1;
+      while (j >= 0 && row[j] > v) { row[j + 1] = row[j]; --j; }
+      row[j + 1] = v;
     }
+    int u = 0;
+    for (int k = 0; k < len; ++k)
+      if (k == 0 || row[k] != row[k - 1]) row[u++] = row[k];
     cnt[i] = u;
   }
   __syncthreads();
-  const int ug = block_scan_lds<1024>(cnt, cur, ng, tot);  // cur := the graph's LOCAL row pointers (its offset in the batch: second launch)
-  for (int i = t; i < ng; i += 1024) {
-    a.rowptr[g0 + i] = cur[i];
-    a.start[g0 + i] = start[i];
+  const int ug = block_scan_lds(cnt, cur, ng, tot);       // cur := the graph's LOCAL row pointers (its offset in the batch: second launch)
+  build_block_index(cur, ng, ug, blk);
+  for (int i = t; i < ng; i += GL_T) a.rowptr[g0 + i] = cur[i];
+  __syncthreads();
+  for (int k = t; k < ug; k += GL_T) {                    // the compacted rows, element k by lane k
+    const int i = owner_of(cur, blk, k);
+    a.colraw[base + k] = g0 + (int)craw[start[i] + (k - cur[i])];
   }
   for (int o = 32; o > 0; o >>= 1) bad += __shfl_xor(bad, o);
   if ((t & 63) == 0) tot[t >> 6] = bad;
   __syncthreads();
   if (t == 0) {
     int bsum = 0;
-    for (int w = 0; w < 16; ++w) bsum += tot[w];
+    for (int w = 0; w < GL_T / 64; ++w) bsum += tot[w];
     a.gnnz[g] = ug;
     a.gbad[g] = bsum;
   }
 }
 
-__global__ __launch_bounds__(512) void k_graph_local_finish(const GlArgs a) {
-  __shared__ int lrp[GL_MAXN + 1], tcnt[GL_MAXN + 1], tstart[GL_MAXN + 1];
-  __shared__ unsigned long long strip[GL_DEPTH * 512];
-  __shared__ int tot[8];
+__global__ __launch_bounds__(GL_T) void k_graph_local_finish(const GlArgs a) {
+  extern __shared__ __attribute__((aligned(16))) int gl_lds[];
+  int* const lrp = gl_lds;                                // local row pointers
+  int* const tc = lrp + a.n1;                             // column histogram, then the fill cursors
+  int* const ts = tc + a.n1;                              // local transposed row pointers
+  int* const dl = ts + a.n1;                              // per row: has a diagonal entry (bit 0 ..), entries in front of it (<< 16)
+  float* const w = reinterpret_cast<float*>(dl + a.n1);   // per row: the off-diagonal weight of _re_norm_adj
+  unsigned* const tpair = reinterpret_cast<unsigned*>(w + a.n1);                    // [ec] (source row << 15) | forward slot, column by column
+  unsigned short* const blk = reinterpret_cast<unsigned short*>(tpair + a.ec);      // [ec / 64 + 1]
+  __shared__ int tot[16];
   __shared__ int s_G, s_bad;
   const int g = blockIdx.x, t = threadIdx.x;
   const int g0 = a.gptr[g], ng = a.gptr[g + 1] - g0;
   const int base = a.eptr[g] + (a.add_diag ? g0 : 0);
   {                                                        // place of this graph in the compacted arrays: unique counts of the graphs before it
     int s = 0, b = 0;
-    for (int j = t; j < a.B; j += 512) {
+    for (int j = t; j < a.B; j += GL_T) {
       if (j < g) s += a.gnnz[j];
       b += a.gbad[j];
     }
     for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); b += __shfl_xor(b, o); }
-    __shared__ int ps[8], pb[8];
+    __shared__ int ps[16], pb[16];
     if ((t & 63) == 0) { ps[t >> 6] = s; pb[t >> 6] = b; }
     __syncthreads();
     if (t == 0) {
       int S = 0, Bd = 0;
-      for (int w = 0; w < 8; ++w) { S += ps[w]; Bd += pb[w]; }
+      for (int q = 0; q < GL_T / 64; ++q) { S += ps[q]; Bd += pb[q]; }
       s_G = S;
       s_bad = Bd;
     }
     __syncthreads();
   }
-  const int G = s_G;
-  for (int i = t; i <= ng; i += 512) {
-    lrp[i] = i < ng ? a.rowptr[g0 + i] : a.gnnz[g];
-    tcnt[i] = 0;
+  const int G = s_G, ug = a.gnnz[g];
+  for (int i = t; i <= ng; i += GL_T) {
+    lrp[i] = i < ng ? a.rowptr[g0 + i] : ug;
+    tc[i] = 0;
+    dl[i] = 0;
   }
   __syncthreads();
   if (g == a.B - 1 && t == 0) {
-    a.rowptr[a.n] = G + lrp[ng];
-    a.t_rowptr[a.n] = G + lrp[ng];
+    a.rowptr[a.n] = G + ug;
+    a.t_rowptr[a.n] = G + ug;
   }
   if (g == 0 && t == 0) *a.bad_out = s_bad + (int)(a.E - ((int64_t)a.eptr[a.B] - a.eptr[0]));    // + edges outside every graph's range of the list
+  build_block_index(lrp, ng, ug, blk);
+  __syncthreads();
   const bool weights = a.p >= 0.f;
-  for (int i = t; i < ng; i += 512) {                      // compaction + edge weights + mean divisor, a row per thread (degree ~10)
-    const int* row = a.colraw + base + a.start[g0 + i];
-    const int d = G + lrp[i], u = lrp[i + 1] - lrp[i];
-    int off = 0;
-    for (int k = 0; k < u; ++k) {
-      const int c = row[k];
-      a.col[d + k] = c;
-      a.rowidx[d + k] = g0 + i;
-      off += (c != g0 + i);
-      atomicAdd(&tcnt[c - g0], 1);
-    }
-    float sum = (float)u;
+  for (int k = t; k < ug; k += GL_T) {                    // pass 1 over the slots: column histogram, where each row's diagonal sits
+    const int c = a.colraw[base + k] - g0;
+    const int i = owner_of(lrp, blk, k);
+    atomicAdd(&tc[c], 1);
+    if (c == i) atomicAdd(&dl[i], 1);
+    else if (c < i) atomicAdd(&dl[i], 1 << 16);
+  }
+  __syncthreads();
+  for (int i = t; i < ng; i += GL_T) {                    // per row: weight, mean divisor (the sum in slot order, as cgc_csr_invdeg forms it)
+    const int u = lrp[i + 1] - lrp[i], diag = dl[i] & 0xffff, less = dl[i] >> 16;
+    float sum = (float)u, wv = 0.f;
     if (weights) {
-      const float w = (1.f / ((float)off + RENORM_EPS)) * (1.f - a.p);
+      wv = (1.f / ((float)(u - diag) + RENORM_EPS)) * (1.f - a.p);
       sum = 0.f;
-      for (int k = 0; k < u; ++k) {
-        const float v = (row[k] == g0 + i) ? a.p : w;
-        a.val[d + k] = v;
-        sum += v;
-      }
+      for (int k = 0; k < u; ++k) sum += (diag && k == less) ? a.p : wv;
     }
+    w[i] = wv;
     a.inv_d[g0 + i] = 1.f / fmaxf(sum, 1.f);
-    a.rowptr[g0 + i] = d;
+    a.rowptr[g0 + i] = G + lrp[i];
+  }
+  block_scan_lds(tc, ts, ng, tot);                         // (starts with its own reads of tc: the barrier above covers them)
+  for (int i = t; i <= ng; i += GL_T) tc[i] = 0;
+  for (int i = t; i < ng; i += GL_T) a.t_rowptr[g0 + i] = G + ts[i];
+  __syncthreads();
+  for (int k = t; k < ug; k += GL_T) {                    // pass 2 over the slots: the forward arrays out, the transposed fill into LDS
+    const int cg = a.colraw[base + k], c = cg - g0;
+    const int i = owner_of(lrp, blk, k);
+    a.col[G + k] = cg;
+    a.rowidx[G + k] = g0 + i;
+    if (weights) a.val[G + k] = (c == i) ? a.p : w[i];
+    tpair[ts[c] + atomicAdd(&tc[c], 1)] = ((unsigned)i << 15) | (unsigned)k;
   }
   __syncthreads();
-  block_scan_lds<512>(tcnt, tstart, ng, tot);
-  for (int i = t; i <= ng; i += 512) tcnt[i] = 0;          // now the fill cursors
-  for (int i = t; i < ng; i += 512) a.t_rowptr[g0 + i] = G + tstart[i];
-  __syncthreads();
-  for (int i = t; i < ng; i += 512) {
-    const int* row = a.colraw + base + a.start[g0 + i];
-    const int d = G + lrp[i], u = lrp[i + 1] - lrp[i];
-    for (int k = 0; k < u; ++k) {
-      const int c = row[k] - g0;
-      const int pos = G + tstart[c] + atomicAdd(&tcnt[c], 1);
-      a.t_col[pos] = g0 + i;
-      a.t_perm[pos] = d + k;
+  for (int j = t; j < ng; j += GL_T) {                    // every column's sources ascending (the key's high bits; unique per column)
+    unsigned* seg = tpair + ts[j];
+    const int len = ts[j + 1] - ts[j];
+    for (int k = 1; k < len; ++k) {
+      const unsigned v = seg[k];
+      int q = k - 1;
+      while (q >= 0 && seg[q] > v) { seg[q + 1] = seg[q]; --q; }
+      seg[q + 1] = v;
     }
   }
-  __syncthreads();                                         // (fence: t_col / t_perm / val of this graph are visible to all its waves)
-  for (int j = t; j < ng; j += 512) {                      // every column's sources ascending (keys are unique), slots carried along
-    const int s = G + tstart[j], len = tstart[j + 1] - tstart[j];
-    if (len <= GL_DEPTH) {
-      for (int k = 0; k < len; ++k) strip[k * 512 + t] = ((unsigned long long)(unsigned)a.t_col[s + k] << 32) | (unsigned)a.t_perm[s + k];
-      for (int k = 1; k < len; ++k) {
-        const unsigned long long v = strip[k * 512 + t];
-        int q = k - 1;
-        while (q >= 0 && strip[q * 512 + t] > v) { strip[(q + 1) * 512 + t] = strip[q * 512 + t]; --q; }
-        strip[(q + 1) * 512 + t] = v;
-      }
-      for (int k = 0; k < len; ++k) {
-        const unsigned long long v = strip[k * 512 + t];
-        a.t_col[s + k] = (int)(v >> 32);
-        a.t_perm[s + k] = (int)(unsigned)v;
-        if (weights) a.t_val[s + k] = a.val[(int)(unsigned)v];
-      }
-    } else {
-      for (int k = 1; k < len; ++k) {
-        const int v = a.t_col[s + k], p = a.t_perm[s + k];
-        int q = k - 1;
-        while (q >= 0 && a.t_col[s + q] > v) { a.t_col[s + q + 1] = a.t_col[s + q]; a.t_perm[s + q + 1] = a.t_perm[s + q]; --q; }
-        a.t_col[s + q + 1] = v;
-        a.t_perm[s + q + 1] = p;
-      }
-      if (weights)
-        for (int k = 0; k < len; ++k) a.t_val[s + k] = a.val[a.t_perm[s + k]];
-    }
+  build_block_index(ts, ng, ug, blk);                      // (blk's readers of pass 2 are behind the barrier above)
+  __syncthreads();
+  for (int k = t; k < ug; k += GL_T) {                    // the transposed arrays out, element k by lane k
+    const unsigned key = tpair[k];
+    const int i = (int)(key >> 15), slot = (int)(key & 32767u);
+    a.t_col[G + k] = g0 + i;
+    a.t_perm[G + k] = G + slot;
+    if (weights) a.t_val[G + k] = (owner_of(ts, blk, k) == i) ? a.p : w[i];
   }
 }
 
 extern "C" int cgc_graph_local_max_nodes(void) { return GL_MAXN; }
 
 // Same outputs and workspace as cgc_graph_build (ws: 3 * (n + 1) + 2 * max(cap, 1) ints; the bad-edge count at the same offset).
-// gptr [B + 1], eptr [B + 1] (device, int32), nmax = the largest graph (host).  CGC_EINVAL -- nothing launched, take cgc_graph_build --
-// when a graph exceeds cgc_graph_local_max_nodes(), B > 65535 or 2 B > n + 1 (the per-graph counts live in the workspace's node part).
-extern "C" int cgc_graph_build_local(const int64_t* edge_index, int64_t E, int n, const int* gptr, const int* eptr, int B, int nmax,
+// gptr [B + 1], eptr [B + 1] (device, int32); nmax = the largest graph, emax = the most edges of one graph (host).  CGC_EINVAL --
+// nothing launched, take cgc_graph_build -- outside the envelope described above (or B > 65535, 2 B > n + 1: the per-graph counts
+// live in the workspace's node part).
+extern "C" int cgc_graph_build_local(const int64_t* edge_index, int64_t E, int n, const int* gptr, const int* eptr, int B, int nmax, int emax,
                                      float renorm_p, int* rowptr, int* col, int* rowidx, int* t_rowptr, int* t_col, int* t_perm, float* val,
                                      float* t_val, float* inv_d, int* ws, cgc_stream_t stream_) {
   hipStream_t stream = as_stream(stream_);
   const bool renorm = renorm_p >= 0.f;
-  if (n <= 0 || E < 0 || B <= 0 || gptr == nullptr || eptr == nullptr) return CGC_EINVAL;
-  if (nmax > GL_MAXN || B > 65535 || 2 * (int64_t)B > (int64_t)n + 1) return CGC_EINVAL;
+  if (n <= 0 || E < 0 || B <= 0 || nmax <= 0 || emax < 0 || gptr == nullptr || eptr == nullptr) return CGC_EINVAL;
+  if (nmax > GL_MAXN || (int64_t)emax + nmax > GL_MAXE || B > 65535 || 2 * (int64_t)B > (int64_t)n + 1) return CGC_EINVAL;
   if (renorm && (val == nullptr || t_val == nullptr)) return CGC_EINVAL;
   const int64_t cap64 = E + (renorm ? n : 0);
   if (cap64 > 0x7fffffff) return CGC_EINVAL;
   GlArgs a;
   a.ei = edge_index; a.E = E; a.n = n; a.B = B; a.add_diag = renorm ? 1 : 0; a.p = renorm_p;
+  a.n1 = (nmax + 1 + 3) & ~3;
+  a.ec = (emax + nmax + 63) & ~63;
+  const size_t lds_rows = sizeof(int) * 3 * (size_t)a.n1 + sizeof(unsigned short) * ((size_t)a.ec + a.ec / 64 + 8);
+  const size_t lds_fin = sizeof(int) * 5 * (size_t)a.n1 + sizeof(unsigned) * (size_t)a.ec + sizeof(unsigned short) * ((size_t)a.ec / 64 + 8);
+  if (lds_fin > 156 * 1024 || lds_rows > 156 * 1024) return CGC_EINVAL;
   a.gptr = gptr; a.eptr = eptr;
   a.rowptr = rowptr; a.col = col; a.rowidx = rowidx; a.t_rowptr = t_rowptr; a.t_col = t_col; a.t_perm = t_perm;
   a.val = val; a.t_val = t_val; a.inv_d = inv_d;
-  a.start = ws;                                    // [n]      where a row sits inside its graph's segment of colraw
-  a.gnnz = ws + (n + 1);                           // [B]      unique entries per graph
-  a.gbad = ws + (n + 1) + B;                       // [B]      dropped edges per graph
-  a.colraw = ws + 3 * (n + 1);                     // [cap]    as in cgc_csr_build
+  a.gnnz = ws;                                     // [B]      unique entries per graph
+  a.gbad = ws + B;                                 // [B]      dropped edges per graph
+  a.colraw = ws + 3 * (n + 1);                     // [cap]    as in cgc_csr_build: here every graph's compacted rows at its capacity offset
   a.bad_out = ws + cgc_csr_bad_edges_offset(E, n, a.add_diag);
-  hipLaunchKernelGGL(k_graph_local_rows, dim3(B), dim3(1024), 0, stream, a);
-  hipLaunchKernelGGL(k_graph_local_finish, dim3(B), dim3(512), 0, stream, a);
+  static bool attr_rows[CGC_MAX_DEVICES] = {}, attr_fin[CGC_MAX_DEVICES] = {};
+  cgc_allow_lds(reinterpret_cast<const void*>(&k_graph_local_rows), 156 * 1024, attr_rows);
+  cgc_allow_lds(reinterpret_cast<const void*>(&k_graph_local_finish), 156 * 1024, attr_fin);
+  hipLaunchKernelGGL(k_graph_local_rows, dim3(B), dim3(GL_T), lds_rows, stream, a);
+  hipLaunchKernelGGL(k_graph_local_finish, dim3(B), dim3(GL_T), lds_fin, stream, a);
   CGC_RETURN_IF_LAUNCH_FAILED();
   return 0;
 }

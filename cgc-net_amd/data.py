@@ -116,7 +116,7 @@ class Batch(Data):
         if 'edge_index' in keys and all(torch.is_tensor(d.edge_index) for d in data_list):
             ec = [int(d.edge_index.shape[1]) for d in data_list]
             out._eptr = torch.tensor([0] + list(np.cumsum(ec)), dtype=torch.int32)
-            out._etotal = int(sum(ec))
+            out._etotal, out._emax = int(sum(ec)), int(max(ec))
         # every item says its nodes are listed grid cell by grid cell (spatial_order): the wide aggregation may stage neighbour unions
         # of consecutive rows in LDS (graph.BatchGraph.spatial -> cgc_spmm_graphs visit bit 2)
         if all(getattr(d, '_spatial', False) for d in data_list):
@@ -233,7 +233,7 @@ def _collate_on_device(data_list, device, knn, mean, std, spatial=False):
     out._gptr = dv['_gptr']
     if has_edges and knn is None:                      # (see the host collate: the edge list is grouped by graph)
         out._eptr = dv['_eptr']
-        out._etotal = int(sum(ecounts))
+        out._etotal, out._emax = int(sum(ecounts)), int(max(ecounts))
     if spatial or all(getattr(d, '_spatial', False) for d in data_list):
         out._spatial = True
     return out

@@ -88,14 +88,14 @@ class BatchGraph(object):
         if not (torch.is_tensor(eptr) and eptr.dtype == torch.int32 and eptr.device == edge_index.device and eptr.numel() == g.B + 1
                 and getattr(batch, '_etotal', -1) == edge_index.shape[1]):
             eptr = None
-        g._build(edge_index.contiguous(), renorm_p, eptr)
+        g._build(edge_index.contiguous(), renorm_p, eptr, int(getattr(batch, '_emax', 0)))
         return g
 
-    def _build(self, edge_index, renorm_p, eptr=None):
+    def _build(self, edge_index, renorm_p, eptr=None, emax=0):
         K = kernels.get()
         if hasattr(K, 'graph_build'):          # the library's composite entry point: one call, two allocations
             s = K.graph_build(edge_index, self.n, None if renorm_p is None else float(renorm_p),
-                              gptr=self.gptr if eptr is not None else None, eptr=eptr, num_graphs=self.B, nmax=self.nmax)
+                              gptr=self.gptr if eptr is not None else None, eptr=eptr, num_graphs=self.B, nmax=self.nmax, emax=emax)
             self.rowptr, self.col, self.rowidx = s['rowptr'], s['col'], s['rowidx']
             self.t_rowptr, self.t_col, self.t_perm = s['t_rowptr'], s['t_col'], s['t_perm']
             self.cap, self.bad_edges = s['cap'], s['bad_edges']

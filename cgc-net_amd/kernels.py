@@ -365,6 +365,7 @@ class HipKernels(KernelSpec):
     # graph structure graph by graph in two launches when the Batch says how its edge list is grouped (cgc_graph_build_local;
     # CGC_GRAPH_LOCAL=0 / False: always the general build -- A-B timing, tests)
     graph_local = os.environ.get('CGC_GRAPH_LOCAL', '1') != '0'
+    graph_local_count = 0      # batches built that way by this process (tests: did the route apply?)
 
     def __init__(self):
         path = lib_path()
@@ -426,12 +427,13 @@ class HipKernels(KernelSpec):
         out['bad_edges'] = ws[o:o + 1]              # device-side count of dropped out-of-range edges (no sync here)
         return out
 
-    def graph_build(self, edge_index, n, renorm_p, gptr=None, eptr=None, num_graphs=0, nmax=0):
+    def graph_build(self, edge_index, n, renorm_p, gptr=None, eptr=None, num_graphs=0, nmax=0, emax=0):
         """csr_build (+ edge_renorm + csr_transpose_vals when renorm_p is not None) + csr_invdeg behind ONE library call, all
         outputs carved out of two allocations.  Returns the dict of csr_build plus val / t_val (None without renorm) and inv_d.
         With ``gptr`` / ``eptr`` (int32 [B+1] on the device: node and edge ranges of the graphs, the edge list grouped by graph as
-        Batch.from_data_list emits it) the structure is built graph by graph in two launches (cgc_graph_build_local: same arrays bit
-        for bit); graphs beyond its node limit take the general build."""
+        Batch.from_data_list emits it; ``nmax`` / ``emax``: the largest graph's nodes, the most edges of one graph) the structure is built
+        graph by graph in two launches (cgc_graph_build_local: same arrays bit for bit); batches outside its envelope take the general
+        build."""
         self._dev(edge_index)
         edge_index = edge_index.to(torch.int64).contiguous()
         E = edge_index.shape[1]
@@ -453,12 +455,13 @@ class HipKernels(KernelSpec):
         rc = _EINVAL
         if gptr is not None and eptr is not None and self.graph_local and 0 < nmax <= self._graph_local_max:
             self._dev(gptr, eptr)
-            rc = self.lib.cgc_graph_build_local(_ptr(edge_index), ctypes.c_int64(E), n, _ptr(gptr), _ptr(eptr), int(num_graphs), int(nmax),
+            rc = self.lib.cgc_graph_build_local(_ptr(edge_index), ctypes.c_int64(E), n, _ptr(gptr), _ptr(eptr), int(num_graphs), int(nmax), int(emax),
                                                 ctypes.c_float(-1.0 if renorm_p is None else renorm_p), _ptr(rowptr), _ptr(col), _ptr(rowidx),
                                                 _ptr(t_rowptr), _ptr(t_col), _ptr(t_perm), _ptr(val), _ptr(t_val), _ptr(inv_d), _ptr(ws),
                                                 self._stream())
             if rc != _EINVAL:
                 self._chk(rc, 'cgc_graph_build_local')
+                self.graph_local_count += 1
         if rc == _EINVAL:                                  # no graph ranges, or outside the graph-local build's envelope
             self._chk(self.lib.cgc_graph_build(_ptr(edge_index), ctypes.c_int64(E), n, ctypes.c_float(-1.0 if renorm_p is None else renorm_p),
                                                _ptr(rowptr), _ptr(col), _ptr(rowidx), _ptr(t_rowptr), _ptr(t_col), _ptr(t_perm), _ptr(val),

@@ -113,15 +113,16 @@ int cgc_graph_build(const int64_t* edge_index, int64_t E, int n, float renorm_p,
                     int* t_col, int* t_perm, float* val, float* t_val, float* inv_d, int* ws, cgc_stream_t stream);
 /* The same arrays, bit for bit, for a batch whose edge list is GROUPED BY GRAPH -- what Batch.from_data_list emits: the edges of graph
  * g are edge_index[:, eptr[g] .. eptr[g+1]) and both end points lie in its node range gptr[g] .. gptr[g+1] (gptr, eptr: int32
- * [B + 1] on the device; nmax = the largest graph, known on the host).  One workgroup per graph with its counters in LDS: TWO
- * launches instead of ~20 (csrc/csr.hip: k_graph_local_rows, k_graph_local_finish).  An edge that leaves its own graph's node range is
- * dropped and counted like an out-of-range id (cgc_graph_build would keep an edge between two graphs of the batch; the reference's
- * dense indexing, model/utils.py:28-33, cannot represent one).  Returns CGC_EINVAL -- nothing launched, use cgc_graph_build -- when
- * nmax > cgc_graph_local_max_nodes(), B > 65535 or 2 B > n + 1.  Outputs and ws as cgc_graph_build. */
+ * [B + 1] on the device; nmax = the largest graph, emax = the most edges of one graph: known on the host).  One workgroup per graph
+ * with everything it indexes at random in LDS: TWO launches instead of ~20 (csrc/csr.hip: k_graph_local_rows, k_graph_local_finish).
+ * An edge that leaves its own graph's node range is dropped and counted like an out-of-range id (cgc_graph_build would keep an edge
+ * between two graphs of the batch; the reference's dense indexing, model/utils.py:28-33, cannot represent one).  Returns CGC_EINVAL
+ * -- nothing launched, use cgc_graph_build -- outside its envelope: nmax <= cgc_graph_local_max_nodes() (4095), emax + nmax <= 32767,
+ * 20 (nmax + 1) + 4 (emax + nmax) + 4096 bytes of LDS <= 156 KB, B <= 65535, 2 B <= n + 1.  Outputs and ws as cgc_graph_build. */
 int cgc_graph_local_max_nodes(void);
-int cgc_graph_build_local(const int64_t* edge_index, int64_t E, int n, const int* gptr, const int* eptr, int B, int nmax, float renorm_p,
-                          int* rowptr, int* col, int* rowidx, int* t_rowptr, int* t_col, int* t_perm, float* val, float* t_val,
-                          float* inv_d, int* ws, cgc_stream_t stream);
+int cgc_graph_build_local(const int64_t* edge_index, int64_t E, int n, const int* gptr, const int* eptr, int B, int nmax, int emax,
+                          float renorm_p, int* rowptr, int* col, int* rowidx, int* t_rowptr, int* t_col, int* t_perm, float* val,
+                          float* t_val, float* inv_d, int* ws, cgc_stream_t stream);
 
 /* ---- A4 / A8: neighbour aggregation.  Replaces torch.matmul(adj, x) inside DenseSAGEConv
  * (model/network.py:114-116) and the inner product of (S^T A) S (model/network.py:207):

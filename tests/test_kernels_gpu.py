@@ -125,28 +125,31 @@ def grouped_graph(counts, deg, seed, heavy_column=False):
     ei = torch.from_numpy(np.concatenate(parts, axis=1).astype(np.int64))
     gptr = torch.tensor(np.concatenate([[0], np.cumsum(counts)]), dtype=torch.int32)
     eptr = torch.tensor(np.concatenate([[0], np.cumsum(ecount)]), dtype=torch.int32)
-    return ei, off, gptr, eptr
+    return ei, off, gptr, eptr, max(ecount)
 
 
-@pytest.mark.parametrize('counts,deg,heavy', [([5, 9, 12], 3, False), ([300, 0, 257, 64], 6, True), ([1800, 2100, 1500, 1, 4096], 9, True),
+@pytest.mark.parametrize('counts,deg,heavy', [([5, 9, 12], 3, False), ([300, 0, 257, 64], 6, True), ([1800, 2100, 1500, 1, 2500], 9, True), ([4095, 3], 3, False), ([4095, 3], 6, False),
                                                ([0, 40], 20, False)])
 @pytest.mark.parametrize('renorm_p', [None, 0.4])
 def test_graph_build_graph_by_graph_equals_the_general_build(counts, deg, heavy, renorm_p):
     """cgc_graph_build_local (one workgroup per graph, two launches) against cgc_graph_build on the same batch: every array bit for
-    bit -- rows longer than the in-LDS sort's depth, a column with 40 sources, empty graphs, a one-node graph, a graph at the node
-    limit, duplicates, with and without the diagonal / edge weights of _re_norm_adj.  Then the same list with three edges that leave
+    bit -- a column with 40 sources, empty graphs, a one-node graph, a graph at the node limit, duplicates, with and without the
+    diagonal / edge weights of _re_norm_adj.  Then the same list with three edges that leave
     their graph: dropped and counted, everything else unchanged."""
     k = hip()
-    ei, n, gptr, eptr = grouped_graph(counts, deg, seed=len(counts) + deg, heavy_column=heavy)
+    ei, n, gptr, eptr, emax = grouped_graph(counts, deg, seed=len(counts) + deg, heavy_column=heavy)
     B, nmax = len(counts), max(counts)
     before = k.graph_local
     try:
         k.graph_local = False
         want = k.graph_build(g(ei), n, renorm_p)
         k.graph_local = True
-        got = k.graph_build(g(ei), n, renorm_p, gptr=g(gptr), eptr=g(eptr), num_graphs=B, nmax=nmax)
+        n_local = k.graph_local_count
+        got = k.graph_build(g(ei), n, renorm_p, gptr=g(gptr), eptr=g(eptr), num_graphs=B, nmax=nmax, emax=emax)
     finally:
         k.graph_local = before
+    fits = 20 * (nmax + 1) + 4 * (emax + nmax) + 4096 <= 156 * 1024 and emax + nmax <= 32767       # the envelope of the two-launch build
+    assert (k.graph_local_count == n_local + 1) == fits, (nmax, emax, fits)
     torch.cuda.synchronize()
     nnz = int(want['rowptr'][n])
     assert int(got['bad_edges']) == 0 and int(want['bad_edges']) == 0
@@ -169,7 +172,7 @@ def test_graph_build_graph_by_graph_equals_the_general_build(counts, deg, heavy,
         dirty[1, e0 + 2] = -2
         clean = torch.cat([ei[:, :e0], ei[:, e0 + 3:]], dim=1)
         ref2 = REF.csr_build(clean, n, renorm_p is not None)
-        got2 = k.graph_build(g(dirty), n, renorm_p, gptr=g(gptr), eptr=g(eptr), num_graphs=B, nmax=nmax)
+        got2 = k.graph_build(g(dirty), n, renorm_p, gptr=g(gptr), eptr=g(eptr), num_graphs=B, nmax=nmax, emax=emax)
         torch.cuda.synchronize()
         nnz2 = int(ref2['rowptr'][n])
         assert int(got2['bad_edges']) == 3
@@ -185,8 +188,8 @@ def test_graph_build_takes_the_general_route_outside_the_local_envelope():
     from cgc_net_amd.graph import BatchGraph
     k = hip()
     limit = int(k.lib.cgc_graph_local_max_nodes())
-    ei, n, gptr, eptr = grouped_graph([limit + 1, 30], 4, seed=1)
-    got = k.graph_build(g(ei), n, None, gptr=g(gptr), eptr=g(eptr), num_graphs=2, nmax=limit + 1)
+    ei, n, gptr, eptr, emax = grouped_graph([limit + 1, 30], 4, seed=1)
+    got = k.graph_build(g(ei), n, None, gptr=g(gptr), eptr=g(eptr), num_graphs=2, nmax=limit + 1, emax=emax)
     ref = REF.csr_build(ei, n, False)
     torch.cuda.synchronize()
     nnz = int(ref['rowptr'][n])
