@@ -400,6 +400,10 @@ __device__ __forceinline__ int owner_of(const int* __restrict__ ptr, const unsig
   return i;
 }
 
+// EPT = elements per thread: every thread's share of the graph's edges (rows kernel) / compacted slots (finish kernel) is requested
+// in ONE batch of independent loads and stays in registers for all passes -- a load per loop iteration next to the loop's stores and
+// atomics is a memory round trip per iteration (the second version of these kernels: 50 + 50 us per batch; the first: 57 + 132).
+template <int EPT>
 __global__ __launch_bounds__(GL_T) void k_graph_local_rows(const GlArgs a) {
   extern __shared__ __attribute__((aligned(16))) int gl_lds[];
   int* const cnt = gl_lds;
@@ -412,43 +416,47 @@ __global__ __launch_bounds__(GL_T) void k_graph_local_rows(const GlArgs a) {
   const int g0 = a.gptr[g], ng = a.gptr[g + 1] - g0;
   const int e0 = a.eptr[g], e1 = a.eptr[g + 1];
   const int base = e0 + (a.add_diag ? g0 : 0);            // this graph's segment of colraw (capacity order = the general build's)
-  for (int i = t; i <= ng; i += GL_T) { cnt[i] = a.add_diag && i < ng ? 1 : 0; cur[i] = 0; }
-  __syncthreads();
-  int bad = 0;
-  for (int e = e0 + t; e < e1; e += 4 * GL_T) {           // four independent edge loads in flight per thread
-    int64_t r[4], c[4];
+  unsigned pk[EPT];                                       // (local row << 16) | local column; 0xffffffff: no edge / a bad edge
+  {
+    int64_t r[EPT], c[EPT];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int idx = min(e + u * GL_T, e1 - 1);
-      r[u] = a.ei[idx];
-      c[u] = a.ei[a.E + idx];
+    for (int u = 0; u < EPT; ++u) {
+      const int idx = min(e0 + t + u * GL_T, e1 - 1);
+      r[u] = e1 > e0 ? a.ei[idx] : -1;
+      c[u] = e1 > e0 ? a.ei[a.E + idx] : -1;
     }
+    for (int i = t; i <= ng; i += GL_T) { cnt[i] = a.add_diag && i < ng ? 1 : 0; cur[i] = 0; }
+    __syncthreads();
+    int bad = 0;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      if (e + u * GL_T >= e1) continue;
-      const int64_t rl = r[u] - g0, cl = c[u] - g0;
-      if (rl < 0 || rl >= ng || cl < 0 || cl >= ng) ++bad;
-      else atomicAdd(&cnt[(int)rl], 1);
+    for (int u = 0; u < EPT; ++u) {
+      pk[u] = 0xffffffffu;
+      if (e0 + t + u * GL_T < e1) {
+        const int64_t rl = r[u] - g0, cl = c[u] - g0;
+        if (rl < 0 || rl >= ng || cl < 0 || cl >= ng) ++bad;
+        else {
+          pk[u] = ((unsigned)rl << 16) | (unsigned)cl;
+          atomicAdd(&cnt[(int)rl], 1);
+        }
+      }
     }
+    for (int o = 32; o > 0; o >>= 1) bad += __shfl_xor(bad, o);
+    if ((t & 63) == 0) tot[t >> 6] = bad;
+    __syncthreads();
+    if (t == 0) {
+      int bsum = 0;
+      for (int w = 0; w < GL_T / 64; ++w) bsum += tot[w];
+      a.gbad[g] = bsum;
+    }
+    __syncthreads();
   }
-  __syncthreads();
   block_scan_lds(cnt, start, ng, tot);
-  for (int e = e0 + t; e < e1; e += 4 * GL_T) {
-    int64_t r[4], c[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int idx = min(e + u * GL_T, e1 - 1);
-      r[u] = a.ei[idx];
-      c[u] = a.ei[a.E + idx];
+  for (int u = 0; u < EPT; ++u)
+    if (pk[u] != 0xffffffffu) {
+      const int rl = (int)(pk[u] >> 16);
+      craw[start[rl] + atomicAdd(&cur[rl], 1)] = (unsigned short)(pk[u] & 0xffffu);
     }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      if (e + u * GL_T >= e1) continue;
-      const int64_t rl = r[u] - g0, cl = c[u] - g0;
-      if (rl < 0 || rl >= ng || cl < 0 || cl >= ng) continue;
-      craw[start[(int)rl] + atomicAdd(&cur[(int)rl], 1)] = (unsigned short)cl;
-    }
-  }
   if (a.add_diag)
     for (int i = t; i < ng; i += GL_T) craw[start[i] + atomicAdd(&cur[i], 1)] = (unsigned short)i;
   __syncthreads();
@@ -471,22 +479,15 @@ __global__ __launch_bounds__(GL_T) void k_graph_local_rows(const GlArgs a) {
   const int ug = block_scan_lds(cnt, cur, ng, tot);       // cur := the graph's LOCAL row pointers (its offset in the batch: second launch)
   build_block_index(cur, ng, ug, blk);
   for (int i = t; i < ng; i += GL_T) a.rowptr[g0 + i] = cur[i];
+  if (t == 0) a.gnnz[g] = ug;
   __syncthreads();
-  for (int k = t; k < ug; k += GL_T) {                    // the compacted rows, element k by lane k
+  for (int k = t; k < ug; k += GL_T) {                    // the compacted rows, element k by lane k (stores only: nothing waits for them)
     const int i = owner_of(cur, blk, k);
     a.colraw[base + k] = g0 + (int)craw[start[i] + (k - cur[i])];
   }
-  for (int o = 32; o > 0; o >>= 1) bad += __shfl_xor(bad, o);
-  if ((t & 63) == 0) tot[t >> 6] = bad;
-  __syncthreads();
-  if (t == 0) {
-    int bsum = 0;
-    for (int w = 0; w < GL_T / 64; ++w) bsum += tot[w];
-    a.gnnz[g] = ug;
-    a.gbad[g] = bsum;
-  }
 }
 
+template <int EPT>
 __global__ __launch_bounds__(GL_T) void k_graph_local_finish(const GlArgs a) {
   extern __shared__ __attribute__((aligned(16))) int gl_lds[];
   int* const lrp = gl_lds;                                // local row pointers
@@ -501,6 +502,10 @@ __global__ __launch_bounds__(GL_T) void k_graph_local_finish(const GlArgs a) {
   const int g = blockIdx.x, t = threadIdx.x;
   const int g0 = a.gptr[g], ng = a.gptr[g + 1] - g0;
   const int base = a.eptr[g] + (a.add_diag ? g0 : 0);
+  const int ug = a.gnnz[g];
+  int cl[EPT], own[EPT];                                   // this thread's slots t, t + 1024, ...: local column (one batch of loads), row
+#pragma unroll
+  for (int u = 0; u < EPT; ++u) cl[u] = a.colraw[base + min(t + u * GL_T, max(ug - 1, 0))] - g0;
   {                                                        // place of this graph in the compacted arrays: unique counts of the graphs before it
     int s = 0, b = 0;
     for (int j = t; j < a.B; j += GL_T) {
@@ -519,7 +524,7 @@ __global__ __launch_bounds__(GL_T) void k_graph_local_finish(const GlArgs a) {
     }
     __syncthreads();
   }
-  const int G = s_G, ug = a.gnnz[g];
+  const int G = s_G;
   for (int i = t; i <= ng; i += GL_T) {
     lrp[i] = i < ng ? a.rowptr[g0 + i] : ug;
     tc[i] = 0;
@@ -534,12 +539,17 @@ __global__ __launch_bounds__(GL_T) void k_graph_local_finish(const GlArgs a) {
   build_block_index(lrp, ng, ug, blk);
   __syncthreads();
   const bool weights = a.p >= 0.f;
-  for (int k = t; k < ug; k += GL_T) {                    // pass 1 over the slots: column histogram, where each row's diagonal sits
-    const int c = a.colraw[base + k] - g0;
-    const int i = owner_of(lrp, blk, k);
-    atomicAdd(&tc[c], 1);
-    if (c == i) atomicAdd(&dl[i], 1);
-    else if (c < i) atomicAdd(&dl[i], 1 << 16);
+#pragma unroll
+  for (int u = 0; u < EPT; ++u) {                          // pass 1 over the slots: column histogram, where each row's diagonal sits
+    const int k = t + u * GL_T;
+    own[u] = 0;
+    if (k < ug) {
+      const int i = owner_of(lrp, blk, k);
+      own[u] = i;
+      atomicAdd(&tc[cl[u]], 1);
+      if (cl[u] == i) atomicAdd(&dl[i], 1);
+      else if (cl[u] < i) atomicAdd(&dl[i], 1 << 16);
+    }
   }
   __syncthreads();
   for (int i = t; i < ng; i += GL_T) {                    // per row: weight, mean divisor (the sum in slot order, as cgc_csr_invdeg forms it)
@@ -558,13 +568,16 @@ __global__ __launch_bounds__(GL_T) void k_graph_local_finish(const GlArgs a) {
   for (int i = t; i <= ng; i += GL_T) tc[i] = 0;
   for (int i = t; i < ng; i += GL_T) a.t_rowptr[g0 + i] = G + ts[i];
   __syncthreads();
-  for (int k = t; k < ug; k += GL_T) {                    // pass 2 over the slots: the forward arrays out, the transposed fill into LDS
-    const int cg = a.colraw[base + k], c = cg - g0;
-    const int i = owner_of(lrp, blk, k);
-    a.col[G + k] = cg;
-    a.rowidx[G + k] = g0 + i;
-    if (weights) a.val[G + k] = (c == i) ? a.p : w[i];
-    tpair[ts[c] + atomicAdd(&tc[c], 1)] = ((unsigned)i << 15) | (unsigned)k;
+#pragma unroll
+  for (int u = 0; u < EPT; ++u) {                          // pass 2 over the slots: the forward arrays out, the transposed fill into LDS
+    const int k = t + u * GL_T;
+    if (k < ug) {
+      const int c = cl[u], i = own[u];
+      a.col[G + k] = g0 + c;
+      a.rowidx[G + k] = g0 + i;
+      if (weights) a.val[G + k] = (c == i) ? a.p : w[i];
+      tpair[ts[c] + atomicAdd(&tc[c], 1)] = ((unsigned)i << 15) | (unsigned)k;
+    }
   }
   __syncthreads();
   for (int j = t; j < ng; j += GL_T) {                    // every column's sources ascending (the key's high bits; unique per column)
@@ -577,7 +590,7 @@ __global__ __launch_bounds__(GL_T) void k_graph_local_finish(const GlArgs a) {
       seg[q + 1] = v;
     }
   }
-  build_block_index(ts, ng, ug, blk);                      // (blk's readers of pass 2 are behind the barrier above)
+  build_block_index(ts, ng, ug, blk);                      // (blk's readers of pass 1 are behind the barriers above)
   __syncthreads();
   for (int k = t; k < ug; k += GL_T) {                    // the transposed arrays out, element k by lane k
     const unsigned key = tpair[k];
@@ -618,11 +631,22 @@ extern "C" int cgc_graph_build_local(const int64_t* edge_index, int64_t E, int n
   a.gbad = ws + B;                                 // [B]      dropped edges per graph
   a.colraw = ws + 3 * (n + 1);                     // [cap]    as in cgc_csr_build: here every graph's compacted rows at its capacity offset
   a.bad_out = ws + cgc_csr_bad_edges_offset(E, n, a.add_diag);
-  static bool attr_rows[CGC_MAX_DEVICES] = {}, attr_fin[CGC_MAX_DEVICES] = {};
-  cgc_allow_lds(reinterpret_cast<const void*>(&k_graph_local_rows), 156 * 1024, attr_rows);
-  cgc_allow_lds(reinterpret_cast<const void*>(&k_graph_local_finish), 156 * 1024, attr_fin);
-  hipLaunchKernelGGL(k_graph_local_rows, dim3(B), dim3(GL_T), lds_rows, stream, a);
-  hipLaunchKernelGGL(k_graph_local_finish, dim3(B), dim3(GL_T), lds_fin, stream, a);
+  const int ept_e = ceil_div(emax > 0 ? emax : 1, GL_T), ept_s = ceil_div(emax + nmax, GL_T);     // both <= 32 by the envelope
+#define GL_LAUNCH(KERNEL, EPT_, LDS_)                                                               \
+  do {                                                                                              \
+    static bool attr__[CGC_MAX_DEVICES] = {};                                                       \
+    cgc_allow_lds(reinterpret_cast<const void*>(&KERNEL<EPT_>), 156 * 1024, attr__);                \
+    hipLaunchKernelGGL((KERNEL<EPT_>), dim3(B), dim3(GL_T), LDS_, stream, a);                       \
+  } while (0)
+  if (ept_e <= 8) GL_LAUNCH(k_graph_local_rows, 8, lds_rows);
+  else if (ept_e <= 16) GL_LAUNCH(k_graph_local_rows, 16, lds_rows);
+  else if (ept_e <= 24) GL_LAUNCH(k_graph_local_rows, 24, lds_rows);
+  else GL_LAUNCH(k_graph_local_rows, 32, lds_rows);
+  if (ept_s <= 8) GL_LAUNCH(k_graph_local_finish, 8, lds_fin);
+  else if (ept_s <= 16) GL_LAUNCH(k_graph_local_finish, 16, lds_fin);
+  else if (ept_s <= 24) GL_LAUNCH(k_graph_local_finish, 24, lds_fin);
+  else GL_LAUNCH(k_graph_local_finish, 32, lds_fin);
+#undef GL_LAUNCH
   CGC_RETURN_IF_LAUNCH_FAILED();
   return 0;
 }

@@ -163,7 +163,7 @@ def test_graph_build_graph_by_graph_equals_the_general_build(counts, deg, heavy,
     ref = REF.csr_build(ei, n, renorm_p is not None)
     assert torch.equal(got['rowptr'].cpu(), ref['rowptr']) and torch.equal(got['col'].cpu()[:nnz], ref['col'][:nnz])
     real = [i for i, c in enumerate(counts) if c > 0]
-    if len(real) >= 2 and eptr[real[0] + 1] - eptr[real[0]] > 3:
+    if fits and len(real) >= 2 and eptr[real[0] + 1] - eptr[real[0]] > 3:       # (the general build keeps an edge between two graphs of the batch)
         e0 = int(eptr[real[0]])
         dirty = ei.clone()
         other = int(gptr[real[1]])                                    # a node of ANOTHER graph, an id past the batch, a negative id
