@@ -347,7 +347,7 @@ struct GlArgs {
   const int* eptr;
   int *rowptr, *col, *rowidx, *t_rowptr, *t_col, *t_perm;
   float *val, *t_val, *inv_d;
-  int *gnnz, *gbad, *colraw, *bad_out;
+  int *gnnz, *gbad, *dlg, *colraw, *bad_out;
 };
 
 // exclusive scan of v[0 .. m) into out[0 .. m], out[m] = total; GL_T threads, every thread a contiguous slice.  `tot`: 16 ints of LDS.
@@ -394,6 +394,22 @@ __device__ __forceinline__ void build_block_index(const int* __restrict__ ptr, i
     blk[b] = (unsigned short)lo;
   }
 }
+// Lanes of a wave whose key equals their predecessor lane's form a RUN (an edge list sorted by centre: ~9 consecutive edges share a
+// row).  One LDS atomic per run instead of one per lane: same-address atomics of a wave are executed one after the other, and with
+// every lane in a 9-way collision the two atomic passes over 16 k edges WERE the kernel (50 of its 52 us).  Returns the lane's position
+// inside its run, the lane that heads it, and -- for the head -- the run's length.  Invalid lanes belong to no run.
+__device__ __forceinline__ void wave_runs(int key, bool valid, int lane, bool& head, int& head_lane, int& pos, int& len) {
+  const int prev = __shfl_up(key, 1);
+  const int pv = __shfl_up((int)valid, 1);
+  head = valid && (lane == 0 || !pv || prev != key);
+  const unsigned long long hm = __ballot(head), vm = __ballot(valid);
+  const unsigned long long below = hm & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+  head_lane = below ? 63 - __clzll((long long)below) : lane;
+  pos = lane - head_lane;
+  const unsigned long long above = lane == 63 ? 0ull : ((hm | ~vm) >> (lane + 1));
+  len = above ? __ffsll((unsigned long long)above) : 64 - lane;
+}
+
 __device__ __forceinline__ int owner_of(const int* __restrict__ ptr, const unsigned short* __restrict__ blk, int k) {
   int i = blk[k >> 6];
   while (ptr[i + 1] <= k) ++i;
@@ -417,6 +433,7 @@ __global__ __launch_bounds__(GL_T) void k_graph_local_rows(const GlArgs a) {
   const int e0 = a.eptr[g], e1 = a.eptr[g + 1];
   const int base = e0 + (a.add_diag ? g0 : 0);            // this graph's segment of colraw (capacity order = the general build's)
   unsigned pk[EPT];                                       // (local row << 16) | local column; 0xffffffff: no edge / a bad edge
+  int rk[EPT];                                            // the edge's rank inside its row (handed out by the histogram's atomic)
   {
     int64_t r[EPT], c[EPT];
 #pragma unroll
@@ -425,20 +442,32 @@ __global__ __launch_bounds__(GL_T) void k_graph_local_rows(const GlArgs a) {
       r[u] = e1 > e0 ? a.ei[idx] : -1;
       c[u] = e1 > e0 ? a.ei[a.E + idx] : -1;
     }
-    for (int i = t; i <= ng; i += GL_T) { cnt[i] = a.add_diag && i < ng ? 1 : 0; cur[i] = 0; }
+    for (int i = t; i <= ng; i += GL_T) cnt[i] = 0;
     __syncthreads();
     int bad = 0;
+    const int lane = t & 63;
 #pragma unroll
     for (int u = 0; u < EPT; ++u) {
       pk[u] = 0xffffffffu;
+      rk[u] = 0;
+      bool valid = false;
+      int rl = -1;
       if (e0 + t + u * GL_T < e1) {
-        const int64_t rl = r[u] - g0, cl = c[u] - g0;
-        if (rl < 0 || rl >= ng || cl < 0 || cl >= ng) ++bad;
+        const int64_t rl64 = r[u] - g0, cl64 = c[u] - g0;
+        if (rl64 < 0 || rl64 >= ng || cl64 < 0 || cl64 >= ng) ++bad;
         else {
-          pk[u] = ((unsigned)rl << 16) | (unsigned)cl;
-          atomicAdd(&cnt[(int)rl], 1);
+          valid = true;
+          rl = (int)rl64;
+          pk[u] = ((unsigned)rl << 16) | (unsigned)cl64;
         }
       }
+      bool head;
+      int head_lane, pos, len;
+      wave_runs(rl, valid, lane, head, head_lane, pos, len);
+      int old = 0;
+      if (head) old = atomicAdd(&cnt[rl], len);
+      old = __shfl(old, head_lane);
+      rk[u] = old + pos;
     }
     for (int o = 32; o > 0; o >>= 1) bad += __shfl_xor(bad, o);
     if ((t & 63) == 0) tot[t >> 6] = bad;
@@ -448,17 +477,16 @@ __global__ __launch_bounds__(GL_T) void k_graph_local_rows(const GlArgs a) {
       for (int w = 0; w < GL_T / 64; ++w) bsum += tot[w];
       a.gbad[g] = bsum;
     }
+    if (a.add_diag)
+      for (int i = t; i < ng; i += GL_T) cnt[i] += 1;     // the diagonal entry: the row's last slot before the sort
     __syncthreads();
   }
   block_scan_lds(cnt, start, ng, tot);
 #pragma unroll
   for (int u = 0; u < EPT; ++u)
-    if (pk[u] != 0xffffffffu) {
-      const int rl = (int)(pk[u] >> 16);
-      craw[start[rl] + atomicAdd(&cur[rl], 1)] = (unsigned short)(pk[u] & 0xffffu);
-    }
+    if (pk[u] != 0xffffffffu) craw[start[pk[u] >> 16] + rk[u]] = (unsigned short)(pk[u] & 0xffffu);
   if (a.add_diag)
-    for (int i = t; i < ng; i += GL_T) craw[start[i] + atomicAdd(&cur[i], 1)] = (unsigned short)i;
+    for (int i = t; i < ng; i += GL_T) craw[start[i + 1] - 1] = (unsigned short)i;
   __syncthreads();
   // sort every row by column and drop duplicates, in place in LDS; the unique count goes where the histogram was
   for (int i = t; i < ng; i += GL_T) {
@@ -470,10 +498,15 @@ __global__ __launch_bounds__(GL_T) void k_graph_local_rows(const GlArgs a) {
       while (j >= 0 && row[j] > v) { row[j + 1] = row[j]; --j; }
       row[j + 1] = v;
     }
-    int u = 0;
+    int u = 0, less = 0, diag = 0;
     for (int k = 0; k < len; ++k)
-      if (k == 0 || row[k] != row[k - 1]) row[u++] = row[k];
+      if (k == 0 || row[k] != row[k - 1]) {
+        less += row[k] < i;
+        diag |= row[k] == i;
+        row[u++] = row[k];
+      }
     cnt[i] = u;
+    a.dlg[g0 + i] = diag | (less << 16);                  // where the row's diagonal entry sits (second launch: edge weights, mean divisor)
   }
   __syncthreads();
   const int ug = block_scan_lds(cnt, cur, ng, tot);       // cur := the graph's LOCAL row pointers (its offset in the batch: second launch)
@@ -493,7 +526,7 @@ __global__ __launch_bounds__(GL_T) void k_graph_local_finish(const GlArgs a) {
   int* const lrp = gl_lds;                                // local row pointers
   int* const tc = lrp + a.n1;                             // column histogram, then the fill cursors
   int* const ts = tc + a.n1;                              // local transposed row pointers
-  int* const dl = ts + a.n1;                              // per row: has a diagonal entry (bit 0 ..), entries in front of it (<< 16)
+  int* const dl = ts + a.n1;                              // per row (from the first launch): has a diagonal entry (bit 0), entries in front of it (<< 16)
   float* const w = reinterpret_cast<float*>(dl + a.n1);   // per row: the off-diagonal weight of _re_norm_adj
   unsigned* const tpair = reinterpret_cast<unsigned*>(w + a.n1);                    // [ec] (source row << 15) | forward slot, column by column
   unsigned short* const blk = reinterpret_cast<unsigned short*>(tpair + a.ec);      // [ec / 64 + 1]
@@ -528,7 +561,7 @@ __global__ __launch_bounds__(GL_T) void k_graph_local_finish(const GlArgs a) {
   for (int i = t; i <= ng; i += GL_T) {
     lrp[i] = i < ng ? a.rowptr[g0 + i] : ug;
     tc[i] = 0;
-    dl[i] = 0;
+    dl[i] = i < ng ? a.dlg[g0 + i] : 0;
   }
   __syncthreads();
   if (g == a.B - 1 && t == 0) {
@@ -540,15 +573,13 @@ __global__ __launch_bounds__(GL_T) void k_graph_local_finish(const GlArgs a) {
   __syncthreads();
   const bool weights = a.p >= 0.f;
 #pragma unroll
-  for (int u = 0; u < EPT; ++u) {                          // pass 1 over the slots: column histogram, where each row's diagonal sits
+  for (int u = 0; u < EPT; ++u) {                          // pass 1 over the slots: column histogram, the row of every slot
     const int k = t + u * GL_T;
     own[u] = 0;
     if (k < ug) {
       const int i = owner_of(lrp, blk, k);
       own[u] = i;
-      atomicAdd(&tc[cl[u]], 1);
-      if (cl[u] == i) atomicAdd(&dl[i], 1);
-      else if (cl[u] < i) atomicAdd(&dl[i], 1 << 16);
+      atomicAdd(&tc[cl[u]], 1);                            // (the slots of one row have distinct columns: these rarely collide)
     }
   }
   __syncthreads();
@@ -629,6 +660,7 @@ extern "C" int cgc_graph_build_local(const int64_t* edge_index, int64_t E, int n
   a.val = val; a.t_val = t_val; a.inv_d = inv_d;
   a.gnnz = ws;                                     // [B]      unique entries per graph
   a.gbad = ws + B;                                 // [B]      dropped edges per graph
+  a.dlg = ws + (n + 1);                            // [n]      per row: diagonal present | entries in front of it << 16
   a.colraw = ws + 3 * (n + 1);                     // [cap]    as in cgc_csr_build: here every graph's compacted rows at its capacity offset
   a.bad_out = ws + cgc_csr_bad_edges_offset(E, n, a.add_diag);
   const int ept_e = ceil_div(emax > 0 ? emax : 1, GL_T), ept_s = ceil_div(emax + nmax, GL_T);     // both <= 32 by the envelope
