@@ -337,6 +337,7 @@ extern "C" int cgc_graph_build(const int64_t* edge_index, int64_t E, int n, floa
 #define GL_MAXN 4095
 #define GL_MAXE 32767
 #define GL_T 1024
+#define GL_SORT 16          // rows / columns up to this length are sorted by rank in registers
 
 struct GlArgs {
   const int64_t* ei;
@@ -492,11 +493,24 @@ __global__ __launch_bounds__(GL_T) void k_graph_local_rows(const GlArgs a) {
   for (int i = t; i < ng; i += GL_T) {
     unsigned short* row = craw + start[i];
     const int len = start[i + 1] - start[i];
-    for (int k = 1; k < len; ++k) {
-      const unsigned short v = row[k];
-      int j = k - 1;
-      while (j >= 0 && row[j] > v) { row[j + 1] = row[j]; --j; }
-      row[j + 1] = v;
+    if (len <= GL_SORT) {                                  // by RANK, out of registers: no chain of dependent LDS round trips
+      unsigned v[GL_SORT];
+#pragma unroll
+      for (int k = 0; k < GL_SORT; ++k) v[k] = k < len ? (unsigned)row[k] : 0xffffffffu;
+#pragma unroll
+      for (int k = 0; k < GL_SORT; ++k) {
+        int rank = 0;
+#pragma unroll
+        for (int q = 0; q < GL_SORT; ++q) rank += (v[q] < v[k]) || (v[q] == v[k] && q < k);
+        if (k < len) row[rank] = (unsigned short)v[k];
+      }
+    } else {
+      for (int k = 1; k < len; ++k) {
+        const unsigned short v = row[k];
+        int j = k - 1;
+        while (j >= 0 && row[j] > v) { row[j + 1] = row[j]; --j; }
+        row[j + 1] = v;
+      }
     }
     int u = 0, less = 0, diag = 0;
     for (int k = 0; k < len; ++k)
@@ -514,9 +528,9 @@ __global__ __launch_bounds__(GL_T) void k_graph_local_rows(const GlArgs a) {
   for (int i = t; i < ng; i += GL_T) a.rowptr[g0 + i] = cur[i];
   if (t == 0) a.gnnz[g] = ug;
   __syncthreads();
-  for (int k = t; k < ug; k += GL_T) {                    // the compacted rows, element k by lane k (stores only: nothing waits for them)
-    const int i = owner_of(cur, blk, k);
-    a.colraw[base + k] = g0 + (int)craw[start[i] + (k - cur[i])];
+  for (int k = t; k < ug; k += GL_T) {                    // the compacted rows, element k by lane k (stores only: nothing waits for them):
+    const int i = owner_of(cur, blk, k);                  // (local row << 16) | local column -- the second launch never searches for a row
+    a.colraw[base + k] = (i << 16) | (int)craw[start[i] + (k - cur[i])];
   }
 }
 
@@ -528,17 +542,16 @@ __global__ __launch_bounds__(GL_T) void k_graph_local_finish(const GlArgs a) {
   int* const ts = tc + a.n1;                              // local transposed row pointers
   int* const dl = ts + a.n1;                              // per row (from the first launch): has a diagonal entry (bit 0), entries in front of it (<< 16)
   float* const w = reinterpret_cast<float*>(dl + a.n1);   // per row: the off-diagonal weight of _re_norm_adj
-  unsigned* const tpair = reinterpret_cast<unsigned*>(w + a.n1);                    // [ec] (source row << 15) | forward slot, column by column
-  unsigned short* const blk = reinterpret_cast<unsigned short*>(tpair + a.ec);      // [ec / 64 + 1]
+  unsigned* const tpair = reinterpret_cast<unsigned*>(w + a.n1);                    // [ec] (source row << 16) | (forward slot << 1) | diagonal, column by column
   __shared__ int tot[16];
   __shared__ int s_G, s_bad;
   const int g = blockIdx.x, t = threadIdx.x;
   const int g0 = a.gptr[g], ng = a.gptr[g + 1] - g0;
   const int base = a.eptr[g] + (a.add_diag ? g0 : 0);
   const int ug = a.gnnz[g];
-  int cl[EPT], own[EPT];                                   // this thread's slots t, t + 1024, ...: local column (one batch of loads), row
+  int cl[EPT];                                             // this thread's slots t, t + 1024, ...: (local row << 16) | local column, one batch of loads
 #pragma unroll
-  for (int u = 0; u < EPT; ++u) cl[u] = a.colraw[base + min(t + u * GL_T, max(ug - 1, 0))] - g0;
+  for (int u = 0; u < EPT; ++u) cl[u] = a.colraw[base + min(t + u * GL_T, max(ug - 1, 0))];
   {                                                        // place of this graph in the compacted arrays: unique counts of the graphs before it
     int s = 0, b = 0;
     for (int j = t; j < a.B; j += GL_T) {
@@ -569,19 +582,10 @@ __global__ __launch_bounds__(GL_T) void k_graph_local_finish(const GlArgs a) {
     a.t_rowptr[a.n] = G + ug;
   }
   if (g == 0 && t == 0) *a.bad_out = s_bad + (int)(a.E - ((int64_t)a.eptr[a.B] - a.eptr[0]));    // + edges outside every graph's range of the list
-  build_block_index(lrp, ng, ug, blk);
-  __syncthreads();
   const bool weights = a.p >= 0.f;
 #pragma unroll
-  for (int u = 0; u < EPT; ++u) {                          // pass 1 over the slots: column histogram, the row of every slot
-    const int k = t + u * GL_T;
-    own[u] = 0;
-    if (k < ug) {
-      const int i = owner_of(lrp, blk, k);
-      own[u] = i;
-      atomicAdd(&tc[cl[u]], 1);                            // (the slots of one row have distinct columns: these rarely collide)
-    }
-  }
+  for (int u = 0; u < EPT; ++u)                            // pass 1 over the slots: column histogram (the slots of one row have distinct columns:
+    if (t + u * GL_T < ug) atomicAdd(&tc[cl[u] & 0xffff], 1);                                              // these rarely collide)
   __syncthreads();
   for (int i = t; i < ng; i += GL_T) {                    // per row: weight, mean divisor (the sum in slot order, as cgc_csr_invdeg forms it)
     const int u = lrp[i + 1] - lrp[i], diag = dl[i] & 0xffff, less = dl[i] >> 16;
@@ -603,32 +607,44 @@ __global__ __launch_bounds__(GL_T) void k_graph_local_finish(const GlArgs a) {
   for (int u = 0; u < EPT; ++u) {                          // pass 2 over the slots: the forward arrays out, the transposed fill into LDS
     const int k = t + u * GL_T;
     if (k < ug) {
-      const int c = cl[u], i = own[u];
+      const int c = cl[u] & 0xffff, i = cl[u] >> 16;
       a.col[G + k] = g0 + c;
       a.rowidx[G + k] = g0 + i;
       if (weights) a.val[G + k] = (c == i) ? a.p : w[i];
-      tpair[ts[c] + atomicAdd(&tc[c], 1)] = ((unsigned)i << 15) | (unsigned)k;
+      tpair[ts[c] + atomicAdd(&tc[c], 1)] = ((unsigned)i << 16) | ((unsigned)k << 1) | (unsigned)(c == i);
     }
   }
   __syncthreads();
   for (int j = t; j < ng; j += GL_T) {                    // every column's sources ascending (the key's high bits; unique per column)
     unsigned* seg = tpair + ts[j];
     const int len = ts[j + 1] - ts[j];
-    for (int k = 1; k < len; ++k) {
-      const unsigned v = seg[k];
-      int q = k - 1;
-      while (q >= 0 && seg[q] > v) { seg[q + 1] = seg[q]; --q; }
-      seg[q + 1] = v;
+    if (len <= GL_SORT) {
+      unsigned v[GL_SORT];
+#pragma unroll
+      for (int k = 0; k < GL_SORT; ++k) v[k] = k < len ? seg[k] : 0xffffffffu;
+#pragma unroll
+      for (int k = 0; k < GL_SORT; ++k) {
+        int rank = 0;
+#pragma unroll
+        for (int q = 0; q < GL_SORT; ++q) rank += v[q] < v[k];
+        if (k < len) seg[rank] = v[k];
+      }
+    } else {
+      for (int k = 1; k < len; ++k) {
+        const unsigned v = seg[k];
+        int q = k - 1;
+        while (q >= 0 && seg[q] > v) { seg[q + 1] = seg[q]; --q; }
+        seg[q + 1] = v;
+      }
     }
   }
-  build_block_index(ts, ng, ug, blk);                      // (blk's readers of pass 1 are behind the barriers above)
   __syncthreads();
   for (int k = t; k < ug; k += GL_T) {                    // the transposed arrays out, element k by lane k
     const unsigned key = tpair[k];
-    const int i = (int)(key >> 15), slot = (int)(key & 32767u);
+    const int i = (int)(key >> 16), slot = (int)((key >> 1) & 32767u);
     a.t_col[G + k] = g0 + i;
     a.t_perm[G + k] = G + slot;
-    if (weights) a.t_val[G + k] = (owner_of(ts, blk, k) == i) ? a.p : w[i];
+    if (weights) a.t_val[G + k] = (key & 1u) ? a.p : w[i];
   }
 }
 
