@@ -34,6 +34,11 @@ python tools/split_gemm_ksweep.py 20 > gpurun_out/r06_split_gemm_ksweep.txt 2>&1
 python tools/eval_bench.py 32 160 > gpurun_out/r06_eval.txt 2>&1
 python tools/eval_bench.py 4 64 >> gpurun_out/r06_eval.txt 2>&1
 python tools/golden_fp64_report.py > gpurun_out/r06_fp64_report.txt 2>&1
+python tools/golden_fp64_report.py --big-route > gpurun_out/r06_fp64_bigroute_exact.txt 2>&1
+python tools/golden_fp64_report.py --big-route --split > gpurun_out/r06_fp64_bigroute_split.txt 2>&1
+python tools/jk_bench.py > gpurun_out/r06_jk_bench.txt 2>&1
+python tools/operand_range.py 32 > gpurun_out/r06_operand_range.txt 2>&1
+(for b in 32 4; do for m in 1 0; do echo "== batch $b, CGC_GRAPH_LOCAL=$m"; CGC_GRAPH_LOCAL=$m python bench.py --batch $b --no-cpu-baseline --no-split-leg --steps 40 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], 'graphs/s', d['ms_per_step'], 'ms/step')"; done; done) > gpurun_out/r06_graph_local_ab.txt 2>&1
 python bench.py --no-cpu-baseline --spatial > gpurun_out/r06_spatial.json 2>/dev/null
 ls gpurun_out | grep r06_ | head -100
 cat gpurun_out/r06_configurations_raw.txt | tail -12
