@@ -456,7 +456,7 @@ def main():
                         'achieved': round(6.0 * tf, 1), 'peak': 2500.0, 'frac': round(6.0 * tf / 2500.0, 4),
                         'achieved_is': 'bf16 TFLOP/s issued: 6 pairs x 2MNK of the fp32 product / launch duration, against the dense bf16 MFMA peak',
                         'fp32_equivalent_tflops': tf, 'fp32_equivalent_over_fp32_mfma_peak': round(tf / MFMA_F32_PEAK_TFLOPS, 4),
-                        'error_table': 'profiles/r05_split_gemm_error_table.txt (max / rms error vs float64 next to the exact kernel, every form)'})
+                        'error_table': 'profiles/r06_split_gemm_error_table.txt (max / rms error vs float64 next to the exact kernel, every form)'})
         # HBM traffic per launch and counter-derived matrix-core utilisation: from the committed PMC passes of this same command
         # (profiles/make_traffic_json.py, profiles/make_counters_json.py) -- ONLY when they were taken on exactly this kernel source
         # (sha256 over csrc/ + include/, stamped into the json); otherwise null + "stale"
