@@ -8,8 +8,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'tests')]
-if '--split' in sys.argv:
-    os.environ['CGC_GEMM_SPLIT_BF16'] = '1'
+os.environ['CGC_GEMM_SPLIT_BF16'] = '1' if '--split' in sys.argv else '0'      # explicit either way (the module's default is split since round 6)
 import discrete  # noqa: E402
 from util import CASES  # noqa: E402
 from cgc_net_amd import kernels  # noqa: E402
