@@ -66,7 +66,7 @@ def test_radius_graph_semantics():
         assert np.allclose(got, want, atol=1e-3)
 
 
-def test_batch_collate_and_loader():
+def test_batch_collate_and_loader(torch_kernels):
     ds = SyntheticCellGraphs(6, 40, num_features=5, base_seed=3)
     assert ds[2].x.equal(ds[2].x) and ds[2].x.equal(SyntheticCellGraphs(6, 40, 5, base_seed=3)[2].x)   # seeded
     items = [ds[i] for i in range(3)]
@@ -77,6 +77,18 @@ def test_batch_collate_and_loader():
     for g, d in enumerate(items):
         sel = (b.batch[b.edge_index[0]] == g)
         assert torch.equal(b.edge_index[:, sel] - int(off[g]), d.edge_index)
+    # the notes both collates leave for the graph-by-graph CSR build (cgc_graph_build_local): the edge list is grouped by graph
+    ec = [int(d.edge_index.shape[1]) for d in items]
+    assert b._eptr.dtype == torch.int32 and b._eptr.tolist() == [0] + list(np.cumsum(ec)) and b._etotal == sum(ec) and b._emax == max(ec)
+    for g in range(3):
+        seg = b.edge_index[:, b._eptr[g]:b._eptr[g + 1]]
+        assert int(seg.min()) >= off[g] and int(seg.max()) < off[g + 1]
+    assert '_eptr' not in b.keys and '_gptr' not in b.keys and [k for k, _ in b] == b.keys       # notes are not data ...
+    moved = b.to('cpu')
+    assert torch.equal(moved._eptr, b._eptr) and moved._etotal == b._etotal and moved._emax == b._emax    # ... but they travel with to()
+    devb = Batch.from_data_list(items, device='cpu')
+    assert torch.equal(devb._eptr, b._eptr) and devb._etotal == b._etotal and devb._emax == b._emax
+    assert not hasattr(Batch.from_data_list([Data(x=d.x, pos=d.pos, y=d.y) for d in items], device='cpu', knn=(100.0, 8)), '_eptr')
     loader = DataListLoader(ds, batch_size=4, shuffle=False)
     first = next(iter(loader))
     assert isinstance(first, list) and len(first) == 4 and isinstance(first[0], Data)
