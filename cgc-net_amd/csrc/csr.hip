@@ -432,6 +432,19 @@ __global__ __launch_bounds__(GL_T) void k_graph_local_rows(const GlArgs a) {
   const int g = blockIdx.x, t = threadIdx.x;
   const int g0 = a.gptr[g], ng = a.gptr[g + 1] - g0;
   const int e0 = a.eptr[g], e1 = a.eptr[g + 1];
+  // A caller whose nmax / emax understate this graph (the LDS areas and EPT were sized from them): the graph is built EMPTY and all its
+  // edges are reported as bad ones -- never an access past the areas.  (Batch.from_data_list's own numbers cannot disagree.)
+  if (ng + 1 > a.n1 || (e1 - e0) + ng > a.ec || e1 - e0 > EPT * GL_T || ng < 0 || e1 < e0) {      // (workgroup-uniform)
+    for (int i = t; i < ng; i += GL_T) {
+      a.rowptr[g0 + i] = 0;
+      a.dlg[g0 + i] = 0;
+    }
+    if (t == 0) {
+      a.gnnz[g] = 0;
+      a.gbad[g] = e1 > e0 ? e1 - e0 : 0;
+    }
+    return;
+  }
   const int base = e0 + (a.add_diag ? g0 : 0);            // this graph's segment of colraw (capacity order = the general build's)
   unsigned pk[EPT];                                       // (local row << 16) | local column; 0xffffffff: no edge / a bad edge
   int rk[EPT];                                            // the edge's rank inside its row (handed out by the histogram's atomic)
@@ -546,9 +559,13 @@ __global__ __launch_bounds__(GL_T) void k_graph_local_finish(const GlArgs a) {
   __shared__ int tot[16];
   __shared__ int s_G, s_bad;
   const int g = blockIdx.x, t = threadIdx.x;
-  const int g0 = a.gptr[g], ng = a.gptr[g + 1] - g0;
+  const int g0 = a.gptr[g], ng_all = a.gptr[g + 1] - g0;
   const int base = a.eptr[g] + (a.add_diag ? g0 : 0);
   const int ug = a.gnnz[g];
+  // (a graph the rows kernel refused -- see there -- has no entries; its rows still get their pointers and mean divisors below as
+  // long as they fit the LDS areas, otherwise they are written directly)
+  const bool refused = ng_all + 1 > a.n1 || ng_all < 0;
+  const int ng = refused ? 0 : ng_all;
   int cl[EPT];                                             // this thread's slots t, t + 1024, ...: (local row << 16) | local column, one batch of loads
 #pragma unroll
   for (int u = 0; u < EPT; ++u) cl[u] = a.colraw[base + min(t + u * GL_T, max(ug - 1, 0))];
@@ -571,6 +588,12 @@ __global__ __launch_bounds__(GL_T) void k_graph_local_finish(const GlArgs a) {
     __syncthreads();
   }
   const int G = s_G;
+  if (refused)
+    for (int i = t; i < ng_all; i += GL_T) {
+      a.rowptr[g0 + i] = G;
+      a.t_rowptr[g0 + i] = G;
+      a.inv_d[g0 + i] = 1.f;
+    }
   for (int i = t; i <= ng; i += GL_T) {
     lrp[i] = i < ng ? a.rowptr[g0 + i] : ug;
     tc[i] = 0;

@@ -181,6 +181,36 @@ def test_graph_build_graph_by_graph_equals_the_general_build(counts, deg, heavy,
             assert torch.equal(got2[key].cpu()[:nnz2], ref2[key][:nnz2]), key
 
 
+def test_graph_build_local_with_understated_sizes_builds_that_graph_empty():
+    """A C-ABI caller whose nmax / emax understate one graph (the kernels size their LDS areas and per-thread arrays from them): that
+    graph comes out EMPTY with all its edges counted as bad ones -- never an access past the areas -- and the other graphs as always."""
+    k = hip()
+    counts = [60, 400, 90]
+    ei, n, gptr, eptr, emax = grouped_graph(counts, 5, seed=9)
+    ec = [int(eptr[i + 1] - eptr[i]) for i in range(3)]
+    for nmax_arg, emax_arg in ((100, emax), (400, ec[1] // 2)):         # too few nodes; too few edges (beyond the rounding of the areas)
+        n_local = k.graph_local_count
+        got = k.graph_build(g(ei), n, 0.4, gptr=g(gptr), eptr=g(eptr), num_graphs=3, nmax=nmax_arg, emax=emax_arg)
+        torch.cuda.synchronize()
+        assert k.graph_local_count == n_local + 1
+        assert int(got['bad_edges']) == ec[1]
+        keep = torch.cat([ei[:, :int(eptr[1])], ei[:, int(eptr[2]):]], dim=1)
+        ref = REF.csr_build(keep, n, False)                              # (no diagonal for the refused graph's rows either)
+        rp = got['rowptr'].cpu()
+        g0, g1 = int(gptr[1]), int(gptr[2])
+        assert bool((rp[g0:g1 + 1] == rp[g0]).all())                     # its rows are empty
+        other = [r for r in range(n) if r < g0 or r >= g1]
+        deg_ref = (ref['rowptr'][1:] - ref['rowptr'][:-1])
+        deg_got = (rp[1:] - rp[:-1])
+        has_self = torch.zeros(n, dtype=torch.bool)
+        for r in other:
+            s0, s1 = int(ref['rowptr'][r]), int(ref['rowptr'][r + 1])
+            has_self[r] = bool((ref['col'][s0:s1] == r).any())
+        for r in other:                                                  # the weighted build adds the diagonal where it was missing
+            assert int(deg_got[r]) == int(deg_ref[r]) + (0 if has_self[r] else 1), r
+        assert bool(torch.isfinite(got['inv_d']).all())
+
+
 def test_graph_build_takes_the_general_route_outside_the_local_envelope():
     """A graph beyond cgc_graph_local_max_nodes(), and a Batch whose edge_index was replaced after the collate (the note about the
     grouping no longer describes it): the general build runs, results as always."""
