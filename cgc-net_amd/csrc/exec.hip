@@ -176,16 +176,19 @@ int split_parts(int Fa, int Fb, int n) {
   return best;
 }
 
-// out[Fa,Fb] = A[:n,:Fa]^T B[:n,:Fb], rows split over workgroups and combined deterministically (ops.gemm_tn_rows)
-int gemm_tn_rows(const Ctx& c, const float* A, int lda, int Fa, const float* B, int ldb, int Fb, int n, float* out) {
+// out[Fa,Fb] = A[:n,:Fa]^T B[:n,:Fb], rows split over workgroups and combined deterministically (ops.gemm_tn_rows); ldo = row stride
+// of out (0: Fb) -- a piece of a wider weight gradient is written in place
+int reduce_batch_sum_rows(const float* ws, float* out, int parts, int rows, int width, int ldo, float beta, hipStream_t stream);   // gemm.hip
+int gemm_tn_rows(const Ctx& c, const float* A, int lda, int Fa, const float* B, int ldb, int Fb, int n, float* out, int ldo = 0) {
+  if (ldo <= 0) ldo = Fb;
   int parts = split_parts(Fa, Fb, n);
-  if (parts == 1) return gemm(c, 1, 0, Fa, Fb, n, A, lda, B, ldb, 0.f, out, Fb);
+  if (parts == 1) return gemm(c, 1, 0, Fa, Fb, n, A, lda, B, ldb, 0.f, out, ldo);
   const int chunk = up(ceil_div(n, parts), 32);
   parts = ceil_div(n, chunk);
   const size_t m = c.scratch->mark();
   float* ws = c.scratch->f((size_t)parts * Fa * Fb);
   TRY(gemm(c, 1, 0, Fa, Fb, n, A, lda, B, ldb, 0.f, ws, Fb, nullptr, parts, 0, 0, (int64_t)Fa * Fb, nullptr, 3, chunk));
-  CALL(cgc_reduce_batch_sum(ws, out, parts, (int64_t)Fa * Fb, 0.f, c.s));
+  CALL(reduce_batch_sum_rows(ws, out, parts, Fa, Fb, ldo, 0.f, as_stream(c.s)));
   c.scratch->release(m);
   return 0;
 }
@@ -711,23 +714,10 @@ int level_bwd(const Ctx& c, Level& L, const cgc_block_params* emb, const cgc_blo
     float* dy3 = sc.f((size_t)n * L.ldC);
     TRY(gemm(c, 0, 0, n, 2 * AH, C, dz, L.ldC, pl->lin_W, L.ftot, 0.f, dx12, 2 * AH));
     TRY(gemm(c, 0, 0, n, C, C, dz, L.ldC, pl->lin_W + 2 * AH, L.ftot, 0.f, dy3, L.ldC));
-    {
-      const size_t m = sc.mark();
-      float* tmp = sc.f((size_t)C * (C > 2 * AH ? C : 2 * AH));
+    {      // the Linear's weight gradient, piece by piece straight into its columns of the flat buffer (row stride ftot)
       float* dW = grads + L.gl.lin_W;
-      TRY(gemm_tn_rows(c, dz, L.ldC, C, L.x12, 2 * AH, 2 * AH, n, tmp));
-      {
-        const float* s1[1] = {tmp};
-        const int l1[1] = {2 * AH}, w1[1] = {2 * AH};
-        CALL(cgc_cat_cols(dW, L.ftot, C, 1, s1, l1, w1, 0, c.s));
-      }
-      TRY(gemm_tn_rows(c, dz, L.ldC, C, L.hp3, L.ldC, C, n, tmp));
-      {
-        const float* s1[1] = {tmp};
-        const int l1[1] = {C}, w1[1] = {C};
-        CALL(cgc_cat_cols(dW + 2 * AH, L.ftot, C, 1, s1, l1, w1, 0, c.s));
-      }
-      sc.release(m);
+      TRY(gemm_tn_rows(c, dz, L.ldC, C, L.x12, 2 * AH, 2 * AH, n, dW, L.ftot));
+      TRY(gemm_tn_rows(c, dz, L.ldC, C, L.hp3, L.ldC, C, n, dW + 2 * AH, L.ftot));
     }
     // third layer of the assignment block, from d hp3
     (void)m0;

@@ -864,23 +864,27 @@ extern "C" int cgc_gemm_f32_cat(int transA, int transB, int M, int N, int K, flo
 }
 
 // ---- deterministic split-K combine
-__global__ void k_reduce_batch_sum(const float* __restrict__ ws, float* __restrict__ out, int parts, long long numel, float beta) {
+// (width, ldo): the result is a [numel / width, width] matrix written with row stride ldo -- a weight-gradient piece goes straight into its
+// columns of the flat gradient buffer instead of through a temporary + a copy launch; width = ldo = numel: a flat vector as before
+__global__ void k_reduce_batch_sum(const float* __restrict__ ws, float* __restrict__ out, int parts, long long numel, float beta, int width,
+                                   int ldo) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < numel; i += (long long)gridDim.x * blockDim.x) {
     float s = 0.f;
     for (int p = 0; p < parts; ++p) s += ws[(size_t)p * numel + i];
-    out[i] = beta != 0.f ? s + beta * out[i] : s;
+    const long long o = (i / width) * ldo + i % width;
+    out[o] = beta != 0.f ? s + beta * out[o] : s;
   }
 }
 
 // many slices of a small tensor (the weight gradients of the narrow layers: 50-110 slices of <= 64 x 64): 8 slice groups x
 // 32 elements per workgroup, 8 loads in flight per thread, fixed summation order
 __global__ __launch_bounds__(256) void k_reduce_many_parts(const float* __restrict__ ws, float* __restrict__ out, int parts, int numel,
-                                                           float beta) {
+                                                           float beta, int width, int ldo) {
   __shared__ float part[8][32];
   const int cl = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
   ws += (size_t)blockIdx.y * parts * numel;     // blockIdx.y = outer batch: ws is [outer][parts][numel], out is [outer][numel]
-  out += (size_t)blockIdx.y * numel;
+  out += (size_t)blockIdx.y * numel;            // (outer > 1 only with width = ldo = numel)
   float s = 0.f;
   if (c < numel) {
     float a[8];
@@ -900,7 +904,8 @@ __global__ __launch_bounds__(256) void k_reduce_many_parts(const float* __restri
     float t = part[0][cl];
 #pragma unroll
     for (int g = 1; g < 8; ++g) t += part[g][cl];
-    out[c] = beta != 0.f ? t + beta * out[c] : t;
+    const int o = (c / width) * ldo + c % width;
+    out[o] = beta != 0.f ? t + beta * out[o] : t;
   }
 }
 
@@ -908,7 +913,25 @@ extern "C" int cgc_reduce_batched(const float* ws, float* out, int outer, int pa
   if (numel <= 0 || outer <= 0) return 0;
   if (outer > 65535) return CGC_EINVAL;
   hipLaunchKernelGGL(k_reduce_many_parts, dim3((unsigned)ceil_div(numel, 32), (unsigned)outer), dim3(256), 0, as_stream(stream), ws, out,
-                     parts, numel, beta);
+                     parts, numel, beta, numel, numel);
+  CGC_RETURN_IF_LAUNCH_FAILED();
+  return 0;
+}
+
+// out[r * ldo + c] (r < rows, c < width) = sum over parts of ws[p][r * width + c]: cgc_reduce_batch_sum with a row stride on the result
+// (the same kernels, the same summation order: the same bits)
+int reduce_batch_sum_rows(const float* ws, float* out, int parts, int rows, int width, int ldo, float beta, hipStream_t stream) {
+  const int64_t numel = (int64_t)rows * width;
+  if (numel <= 0) return 0;
+  if (width <= 0 || ldo < width || numel > 0x7fffffff) return CGC_EINVAL;
+  if (parts >= 16 && numel <= (1 << 20)) {
+    hipLaunchKernelGGL(k_reduce_many_parts, dim3((unsigned)ceil_div((int)numel, 32), 1u), dim3(256), 0, stream, ws, out, parts, (int)numel, beta,
+                       width, ldo);
+  } else {
+    const int64_t blocks = ceil_div64(numel, 256);
+    hipLaunchKernelGGL(k_reduce_batch_sum, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, stream, ws, out, parts,
+                       (long long)numel, beta, width, ldo);
+  }
   CGC_RETURN_IF_LAUNCH_FAILED();
   return 0;
 }
@@ -917,8 +940,9 @@ extern "C" int cgc_reduce_batch_sum(const float* ws, float* out, int parts, int6
   if (numel <= 0) return 0;
   if (parts >= 16 && numel <= (1 << 20)) return cgc_reduce_batched(ws, out, 1, parts, (int)numel, beta, stream);
   const int64_t blocks = ceil_div64(numel, 256);
+  const int w = numel <= 0x7fffffff ? (int)numel : 0x7fffffff;       // (one row: the stride is never applied)
   hipLaunchKernelGGL(k_reduce_batch_sum, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, as_stream(stream), ws, out,
-                     parts, (long long)numel, beta);
+                     parts, (long long)numel, beta, w, w);
   CGC_RETURN_IF_LAUNCH_FAILED();
   return 0;
 }
