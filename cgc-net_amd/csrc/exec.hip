@@ -83,6 +83,8 @@ extern "C" int cgc_transpose(const float* src, int lds, int rows, int cols, floa
   return 0;
 }
 
+int reduce_batch_sum_rows(const float* ws, float* out, int parts, int rows, int width, int ldo, float beta, hipStream_t stream);   // gemm.hip
+
 // ------------------------------------------------------------------------------------------------ host-side plumbing
 namespace {
 
@@ -178,7 +180,6 @@ int split_parts(int Fa, int Fb, int n) {
 
 // out[Fa,Fb] = A[:n,:Fa]^T B[:n,:Fb], rows split over workgroups and combined deterministically (ops.gemm_tn_rows); ldo = row stride
 // of out (0: Fb) -- a piece of a wider weight gradient is written in place
-int reduce_batch_sum_rows(const float* ws, float* out, int parts, int rows, int width, int ldo, float beta, hipStream_t stream);   // gemm.hip
 int gemm_tn_rows(const Ctx& c, const float* A, int lda, int Fa, const float* B, int ldb, int Fb, int n, float* out, int ldo = 0) {
   if (ldo <= 0) ldo = Fb;
   int parts = split_parts(Fa, Fb, n);
