@@ -222,23 +222,13 @@ struct SplitFrags {
 };
 __device__ __forceinline__ uint4v frag16(const unsigned char* p) { return *reinterpret_cast<const uint4v*>(p); }
 
-template <bool TA, bool TB>
-__global__ __launch_bounds__(256, 1) void k_gemm_split(const GemmArgs a) {
+// One tile (HALF: a tile of <= 128 valid rows, see below) or one K piece of a tail tile.  Two instantiations per kernel, chosen per
+// workgroup: as two loop nests inside ONE body the accumulators, fragments and operand registers had to agree at every merge point and
+// the allocator spilled 107-124 registers; as two bodies that share nothing but the arguments it spills none.
+template <bool TA, bool TB, bool HALF>
+__device__ __forceinline__ void split_body(const GemmArgs& a, const int b, const int tile_id, const int piece, const int S, const unsigned tj,
+                                           unsigned char* const slds) {
   constexpr int TM = 4, TN = 2, WGN = 2;
-  extern __shared__ __attribute__((aligned(16))) unsigned char slds[];
-
-  int b, tile_id, piece, S;
-  unsigned tj;
-  {
-    TileMap<S_BM> map;
-    map.init(a, threadIdx.x & 63);
-    if (!map.select(a, blockIdx.x, threadIdx.x & 63, b, tile_id, tj, piece, S)) return;
-  }
-  b = __builtin_amdgcn_readfirstlane(b);
-  tile_id = __builtin_amdgcn_readfirstlane(tile_id);
-  piece = __builtin_amdgcn_readfirstlane(piece);
-  S = __builtin_amdgcn_readfirstlane(S);
-  tj = __builtin_amdgcn_readfirstlane(tj);
   const TileBase tb(a, b);
   const int M = tb.M, K = tb.K, N = a.N;
   const float* A = tb.A;
@@ -298,7 +288,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_split(const GemmArgs a) {
   const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, 0xffffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(B), 0, 0xffffffff, 0x00020000);
 
-  const unsigned fa_off = (unsigned)(wm * 128 + l31) * SROW + lhi * 16, fb_off = 3 * S_PLA + (unsigned)(wn * 64 + l31) * SROW + lhi * 16;
+  const unsigned fa_off = (unsigned)((HALF ? wm * 64 : wm * 128) + l31) * SROW + lhi * 16, fb_off = 3 * S_PLA + (unsigned)(wn * 64 + l31) * SROW + lhi * 16;
   const unsigned wa_off = LoaderA::wbase(), wb_off = 3 * S_PLA + LoaderB::wbase();
 
   SplitFrags fr;
@@ -338,7 +328,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_split(const GemmArgs a) {
 
   auto tile_step = [&](auto pos_c, auto full_c, int lt) {
     constexpr int POS = decltype(pos_c)::value;          // local tile index mod 2
-    constexpr bool FULL = decltype(full_c)::value;
+    constexpr bool FULL = decltype(full_c)::value;       // (HALF: sub-tiles i >= 2 of the wave do not exist)
     const unsigned char* rstage = slds + (POS ^ 1) * S_STAGE;      // tile lt + 1
     unsigned char* wa = slds + POS * S_STAGE + wa_off;             // tile lt + 2 goes where tile lt was
     unsigned char* wb = slds + POS * S_STAGE + wb_off;
@@ -361,13 +351,15 @@ __global__ __launch_bounds__(256, 1) void k_gemm_split(const GemmArgs a) {
 #pragma clang loop unroll(full)
     for (int m = 0; m < 48; ++m) {
       const int t = m / 8, ij = m % 8, i = ij >> 1, j = ij & 1;
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fr.b[j][PB_[t]]), __builtin_bit_cast(bf16x8, fr.a[i][PA_[t]]),
-                                                          acc[i][j], 0, 0, 0);
-      // the next tile's fragments, 18 reads of 16 bytes, each plane as soon as this tile's copy is dead
-      if (m < 4) fr.a0n[m] = frag16(rstage + fa_off + m * 32 * SROW);                                        // A.hi' (second copy)
+      if (!HALF || i < 2)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fr.b[j][PB_[t]]), __builtin_bit_cast(bf16x8, fr.a[i][PA_[t]]),
+                                                            acc[i][j], 0, 0, 0);
+      // the next tile's fragments, 18 reads of 16 bytes (12 for a half tile), each plane as soon as this tile's copy is dead
+      constexpr int NA = HALF ? 2 : 4;
+      if (m < 4) { if (m < NA) fr.a0n[m] = frag16(rstage + fa_off + m * 32 * SROW); }                          // A.hi' (second copy)
       else if (m < 6) fr.b0n[m - 4] = frag16(rstage + fb_off + (m - 4) * 32 * SROW);                         // B.hi' (second copy)
-      else if (m >= 8 && m < 12) fr.a[m - 8][2] = frag16(rstage + fa_off + (m - 8) * 32 * SROW + 2 * S_PLA);   // A.lo (pair 0 only)
-      else if (m >= 24 && m < 28) fr.a[m - 24][1] = frag16(rstage + fa_off + (m - 24) * 32 * SROW + S_PLA);   // A.mid (pairs 1, 2)
+      else if (m >= 8 && m < 12) { if (m - 8 < NA) fr.a[m - 8][2] = frag16(rstage + fa_off + (m - 8) * 32 * SROW + 2 * S_PLA); }   // A.lo (pair 0 only)
+      else if (m >= 24 && m < 28) { if (m - 24 < NA) fr.a[m - 24][1] = frag16(rstage + fa_off + (m - 24) * 32 * SROW + S_PLA); }   // A.mid (pairs 1, 2)
       else if (m >= 32 && m < 34) fr.b[m - 32][2] = frag16(rstage + fb_off + (m - 32) * 32 * SROW + 2 * S_PLB);   // B.lo (pair 3)
       else if (m >= 40 && m < 42) fr.b[m - 40][1] = frag16(rstage + fb_off + (m - 40) * 32 * SROW + S_PLB);   // B.mid (pairs 1, 4)
       split_micro<LoaderA, LoaderB, !FULL, S_PLA, S_PLB>(m, gs, ra[POS], rb[POS], wa, wb, k0s, klims);
@@ -382,7 +374,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_split(const GemmArgs a) {
       __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) fr.a[i][0] = fr.a0n[i];
+    for (int i = 0; i < (HALF ? 2 : 4); ++i) fr.a[i][0] = fr.a0n[i];
     fr.b[0][0] = fr.b0n[0];
     fr.b[1][0] = fr.b0n[1];
     __syncthreads();
@@ -416,7 +408,42 @@ __global__ __launch_bounds__(256, 1) void k_gemm_split(const GemmArgs a) {
               make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
     return;
   }
-  gemm_epilogue<TM, TN>(a, C, M, N, m0 + wm * TM * 32, n0 + wn * TN * 32, acc, lds_f + wave * 32 * (TN * 32 + 4), lane);
+  if constexpr (HALF) {
+    floatx16 ah[2][TN];                    // (by value: a reference to a part of acc would put the accumulators in memory)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) ah[i][j] = acc[i][j];
+    gemm_epilogue<2, TN>(a, C, M, N, m0 + wm * 64, n0 + wn * TN * 32, ah, lds_f + wave * 32 * (TN * 32 + 4), lane);
+  } else {
+    gemm_epilogue<TM, TN>(a, C, M, N, m0 + wm * TM * 32, n0 + wn * TN * 32, acc, lds_f + wave * 32 * (TN * 32 + 4), lane);
+  }
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256, 1) void k_gemm_split(const GemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char slds[];
+  int b, tile_id, piece, S;
+  unsigned tj;
+  {
+    TileMap<S_BM> map;
+    map.init(a, threadIdx.x & 63);
+    if (!map.select(a, blockIdx.x, threadIdx.x & 63, b, tile_id, tj, piece, S)) return;
+  }
+  b = __builtin_amdgcn_readfirstlane(b);
+  tile_id = __builtin_amdgcn_readfirstlane(tile_id);
+  piece = __builtin_amdgcn_readfirstlane(piece);
+  S = __builtin_amdgcn_readfirstlane(S);
+  tj = __builtin_amdgcn_readfirstlane(tj);
+  const TileBase tb(a, b);
+  const int rows_left = tb.M - (tile_id / a.tiles_n) * S_BM;
+#ifndef S_NO_HALF            // (-DS_NO_HALF: A/B timing builds)
+  if (S == 1 && rows_left <= 128) {
+    split_body<TA, TB, true>(a, b, tile_id, piece, S, tj, slds);
+    return;
+  }
+#endif
+  split_body<TA, TB, false>(a, b, tile_id, piece, S, tj, slds);
 }
 
 // Workgroups the chip holds at once: one per CU
