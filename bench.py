@@ -77,7 +77,7 @@ def parse():
     p.add_argument('--no-split-leg', action='store_true',
                    help='N=1: skip the second leg that runs the same W + K steps with the six dominant products in mode CGC_GEMM_SPLIT_BF16 '
                         '(reported beside the headline as value_split / roofline_split; the headline is always the exact fp32 kernel)')
-    p.add_argument('--gemm-mode', type=int, default=0, help='experiments: mode of the HEADLINE leg (0 exact, 1 split); the JSON says so')
+    p.add_argument('--gemm-mode', type=int, default=0, help='experiments: mode of the HEADLINE leg (0 exact, 1 split bf16, 2 three fp16 pairs); the JSON says so')
     p.add_argument('--no-gc', action='store_true',
                    help="experiment: Python's cyclic garbage collector off during the timed steps (gc.disable() after a gc.collect()): does "
                         "the idle gap at the forward -> backward turn of some traced steps come from a collection pause?")
@@ -250,7 +250,7 @@ def main():
     # ---- synthetic workload: `pool` distinct batches, resident in HBM.  weak: per rank, seeded by rank; strong: the SAME
     # global batches on every rank, each rank keeping its chunk of the cumulative-node-count split (data.partition_by_nodes)
     from cgc_net_amd.data import partition_by_nodes
-    legs = (['single'] + ([] if args.no_split_leg else ['split'])) if world == 1 else (['strong', 'weak'] if args.scaling == 'both' else [args.scaling])
+    legs = (['single'] + ([] if args.no_split_leg else ['split', 'half'])) if world == 1 else (['strong', 'weak'] if args.scaling == 'both' else [args.scaling])
 
     def make_batches(leg):
         strong_ = leg == 'strong'
@@ -292,7 +292,7 @@ def main():
     def run_leg(leg, with_kernel_timing):
         """W untimed + exactly K timed steps, bracketed by barrier + synchronize; returns the leg's measurements."""
         lists_, cpu_, dev_ = make_batches(leg)
-        model.gemm_mode = 1 if leg == 'split' else args.gemm_mode      # (cgc_gemm_f32_ws's mode; the headline leg is exact unless asked otherwise)
+        model.gemm_mode = 1 if leg == 'split' else 2 if leg == 'half' else args.gemm_mode      # (cgc_gemm_f32_ws's mode; the headline leg is exact unless asked otherwise)
         for i in range(args.warmup):
             step(dev_[i % len(dev_)])
         kernels.get()
@@ -341,7 +341,7 @@ def main():
             raise SystemExit('non-finite loss')
         return res
 
-    results = [run_leg(leg, (not args.no_kernel_timing) and (i == 0 or leg == 'split')) for i, leg in enumerate(legs)]
+    results = [run_leg(leg, (not args.no_kernel_timing) and (i == 0 or leg in ('split', 'half'))) for i, leg in enumerate(legs)]
     model.gemm_mode = args.gemm_mode
     head = results[0]
     strong = head['leg'] == 'strong'
@@ -438,8 +438,8 @@ def main():
                 out['roofline'] = dict({'kernel': SPLIT_KERNEL if args.gemm_mode == 1 else EXACT_KERNEL}, **gemm)
             if spmm is not None:
                 out['roofline_aggregation'] = spmm
-        if args.gemm_mode == 1:
-            out['config']['gemm_mode'] = 'CGC_GEMM_SPLIT_BF16 (experiment: the headline leg itself ran in split mode)'
+        if args.gemm_mode:
+            out['config']['gemm_mode'] = '%s (experiment: the headline leg itself ran in this mode)' % {1: 'CGC_GEMM_SPLIT_BF16', 2: 'CGC_GEMM_SPLIT_F16'}[args.gemm_mode]
         for r in results[1:]:
             if r['leg'] != 'split':
                 continue
@@ -457,6 +457,24 @@ def main():
                         'achieved_is': 'bf16 TFLOP/s issued: 6 pairs x 2MNK of the fp32 product / launch duration, against the dense bf16 MFMA peak',
                         'fp32_equivalent_tflops': tf, 'fp32_equivalent_over_fp32_mfma_peak': round(tf / MFMA_F32_PEAK_TFLOPS, 4),
                         'error_table': 'profiles/r06_split_gemm_error_table.txt (max / rms error vs float64 next to the exact kernel, every form)'})
+        HALF_KERNEL = ('k_gemm_absmax<*> + k_gemm_half<*> (the same six products per step as three v_mfma_f32_32x32x16_f16 pairs per fp32 product '
+                       'of operands scaled per batch item, 256x128x16 tile; the operand-maximum pass and the tail fix-up kernel included)')
+        for r in results[1:]:
+            if r['leg'] != 'half':
+                continue
+            # ... and in mode CGC_GEMM_SPLIT_F16
+            out['value_half'] = round(args.batch * args.steps / r['elapsed'], 2)
+            out['ms_per_step_half'] = round(1e3 * r['elapsed'] / args.steps, 3)
+            if r['timer'] is not None:
+                gemm, _ = rooflines(r['timer'])
+                if gemm is not None:
+                    tf = gemm['achieved']
+                    out['roofline_half'] = dict({'kernel': HALF_KERNEL}, **gemm)
+                    out['roofline_half'].update({
+                        'achieved': round(3.0 * tf, 1), 'peak': 2500.0, 'frac': round(3.0 * tf / 2500.0, 4),
+                        'achieved_is': 'fp16 TFLOP/s issued: 3 pairs x 2MNK of the fp32 product / duration of the product (maximum pass + kernel + fix-up), against the dense 16-bit MFMA peak',
+                        'fp32_equivalent_tflops': tf, 'fp32_equivalent_over_fp32_mfma_peak': round(tf / MFMA_F32_PEAK_TFLOPS, 4),
+                        'error_table': 'profiles/r06_half_gemm_error_table.txt (max / rms error vs float64 next to the exact kernel, every form)'})
         # HBM traffic per launch and counter-derived matrix-core utilisation: from the committed PMC passes of this same command
         # (profiles/make_traffic_json.py, profiles/make_counters_json.py) -- ONLY when they were taken on exactly this kernel source
         # (sha256 over csrc/ + include/, stamped into the json); otherwise null + "stale"

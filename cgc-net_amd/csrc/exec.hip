@@ -110,7 +110,7 @@ struct Ctx {
   Arena* scratch;
   float* gws;                     // slab workspace of the GEMM's tail split
   int64_t gws_floats;
-  int gemm_mode = CGC_GEMM_EXACT; // cgc_level_desc.flags bit 1: CGC_GEMM_SPLIT_BF16 for the products that qualify (gemm_split.hip)
+  int gemm_mode = CGC_GEMM_EXACT; // cgc_level_desc.flags bit 1: CGC_GEMM_SPLIT_BF16 (gemm_split.hip), bit 2: CGC_GEMM_SPLIT_F16 (gemm_half.hip) for the products that qualify
 };
 
 static int fail_at(int rc, const char* what, int line) {      // CGC_EXEC_DEBUG=1: say which call of the schedule failed
@@ -743,7 +743,7 @@ extern "C" int cgc_level_supported(const cgc_level_desc* d) {
   if (d->level == 1 && (d->nmax < 1 || d->npad < d->nmax)) return 0;
   if (d->C > 0 && (d->AH < 1 || d->H + d->AH > 256 || (2 * d->AH) % 4 != 0)) return 0;
   if (d->C == 0 && d->level == 1) return 0;
-  if (d->flags & ~2) return 0;                                            // bit 0 is reserved (ABI 4), bits above 1 are unassigned
+  if ((d->flags & ~6) || (d->flags & 6) == 6) return 0;                   // bit 0 is reserved (ABI 4), bits 1 and 2 exclude each other, bits above 2 are unassigned
   if (d->jk && (d->E != d->H || !cgc_jk_matrix_core(d->H))) return 0;   // (other channel counts: staged parameter gradients, per-operator path)
   return 1;
 }
@@ -800,7 +800,7 @@ extern "C" int cgc_level_fwd(const cgc_level_desc* d, const cgc_block_params* em
   L.layout_grads();
   Ctx c{stream, false, &sc, nullptr, cgc_gemm_ws_floats()};
   c.gws = sc.f((size_t)c.gws_floats);
-  c.gemm_mode = (d->flags & 2) ? CGC_GEMM_SPLIT_BF16 : CGC_GEMM_EXACT;
+  c.gemm_mode = (d->flags & 2) ? CGC_GEMM_SPLIT_BF16 : (d->flags & 4) ? CGC_GEMM_SPLIT_F16 : CGC_GEMM_EXACT;
   const int rc = level_fwd(c, L, emb, pool, jk, g, gptr, x_in, A_in, readout, x_out, A_out);
   if (assign_out != nullptr) *assign_out = L.S;
   if (assign_ld != nullptr) *assign_ld = L.ldC;
@@ -819,6 +819,6 @@ extern "C" int cgc_level_bwd(const cgc_level_desc* d, const cgc_block_params* em
   L.layout_grads();
   Ctx c{stream, false, &sc, nullptr, cgc_gemm_ws_floats()};
   c.gws = sc.f((size_t)c.gws_floats);
-  c.gemm_mode = (d->flags & 2) ? CGC_GEMM_SPLIT_BF16 : CGC_GEMM_EXACT;
+  c.gemm_mode = (d->flags & 2) ? CGC_GEMM_SPLIT_BF16 : (d->flags & 4) ? CGC_GEMM_SPLIT_F16 : CGC_GEMM_EXACT;
   return level_bwd(c, L, emb, pool, jk, g, gptr, x_in, A_in, d_readout, d_x_out, d_A_out, grads, d_x_in, d_A_in);
 }

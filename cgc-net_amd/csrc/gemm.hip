@@ -647,7 +647,9 @@ static bool gemm_all_fast(const GemmArgs& a, int transA, int transB, int batch, 
 // Workgroups of k_gemm_f32 the chip holds at once: 2 per CU (LDS: 73.7 KB for the 128 x 128 tile; __launch_bounds__(256, 2))
 static const int kResident = 512;
 // slab workspace the tail split may use (floats): up to 1.5 * kResident pieces of one 128 x 128 tile
-extern "C" int64_t cgc_gemm_ws_floats(void) { return (int64_t)(kResident + kResident / 2) * 128 * 128; }
+// + the scale slots of mode CGC_GEMM_SPLIT_F16 (gemm_half.hip), which sit at the workspace's end
+int64_t gemm_half_scale_floats();      // gemm_half.hip
+extern "C" int64_t cgc_gemm_ws_floats(void) { return (int64_t)(kResident + kResident / 2) * 128 * 128 + gemm_half_scale_floats(); }
 
 template <int WGM, int WGN, int TM, int TN>
 static int launch_cfg(const GemmArgs& a0, int transA, int transB, int batch, int m_extent, int k_extent, bool short_k, float* ws,
@@ -728,6 +730,8 @@ extern "C" int cgc_gemm_tuning(int cfg) {
 
 int gemm_split_launch(const GemmArgs& a0, int transA, int transB, int batch, int m_extent, int k_extent, float* ws, int64_t ws_floats,
                       hipStream_t stream);      // gemm_split.hip
+int gemm_half_launch(const GemmArgs& a0, int transA, int transB, int batch, int m_extent, int k_extent, float* ws, int64_t ws_floats,
+                     hipStream_t stream);       // gemm_half.hip
 
 static int gemm_dispatch(GemmArgs& a, int transA, int transB, int batch, int max_ragged, float* ws, int64_t ws_floats, int mode,
                          hipStream_t stream) {
@@ -756,10 +760,13 @@ static int gemm_dispatch(GemmArgs& a, int transA, int transB, int batch, int max
   // the 128 x 128 pipelined route; mode CGC_GEMM_SPLIT_BF16: as six bf16 MFMA pairs on 256 x 128 tiles (gemm_split.hip) when every
   // operand segment is fit for unguarded 16-byte loads; otherwise -- and for every other route -- the exact kernel
   static const int force_mode = getenv("CGC_GEMM_MODE") ? atoi(getenv("CGC_GEMM_MODE")) : -1;      // experiments: overrides the argument
-  const bool want_split = (force_mode >= 0 ? force_mode : mode) == CGC_GEMM_SPLIT_BF16;
+  // mode CGC_GEMM_SPLIT_F16: as three fp16 MFMA pairs of operands scaled per batch item (gemm_half.hip), same tiles, same condition
+  const int eff_mode = force_mode >= 0 ? force_mode : mode;
+  const bool want_split = eff_mode == CGC_GEMM_SPLIT_BF16, want_half = eff_mode == CGC_GEMM_SPLIT_F16;
   auto big_route = [&](bool shortk, float* w) -> int {
-    if (want_split && !shortk && !(transA && transB) && gemm_all_fast(a, transA, transB, batch, m_extent, k_extent)) {
-      const int rc = gemm_split_launch(a, transA, transB, batch, m_extent, k_extent, w, ws_floats, stream);
+    if ((want_split || want_half) && !shortk && !(transA && transB) && gemm_all_fast(a, transA, transB, batch, m_extent, k_extent)) {
+      const int rc = want_half ? gemm_half_launch(a, transA, transB, batch, m_extent, k_extent, w, ws_floats, stream)
+                               : gemm_split_launch(a, transA, transB, batch, m_extent, k_extent, w, ws_floats, stream);
       if (rc != CGC_EINVAL) return rc;
     }
     return launch_cfg<2, 2, 2, 2>(a, transA, transB, batch, m_extent, k_extent, shortk, w, ws_floats, stream);
@@ -811,7 +818,7 @@ static void gemm_fill(GemmArgs& a, int M, int N, int K, float alpha, const float
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
   a.strideA = strideA; a.strideB = strideB; a.strideC = strideC;
   a.alpha = alpha; a.beta = beta; a.ragged = ragged; a.tiles_n = 0;
-  a.per_batch = a.nb = 0; a.ws = nullptr; a.resident = 0; a.s_max = 1; a.map_mode = 0; a.chunk = 0;
+  a.per_batch = a.nb = 0; a.ws = nullptr; a.resident = 0; a.s_max = 1; a.map_mode = 0; a.chunk = 0; a.scale = nullptr;
   a.nx = 0;
   for (int i = 0; i < 2; ++i) { a.xA[i] = a.xB[i] = nullptr; a.xlda[i] = a.xldb[i] = a.xK[i] = 0; a.xsA[i] = a.xsB[i] = 0; }
 }
@@ -820,7 +827,7 @@ extern "C" int cgc_gemm_f32_ws(int transA, int transB, int M, int N, int K, floa
                                int ldb, float beta, float* C, int ldc, const float* bias, int batch, int64_t strideA, int64_t strideB,
                                int64_t strideC, const int* gptr, int ragged, int max_ragged, float* ws, int64_t ws_floats, int mode,
                                cgc_stream_t stream_) {
-  if (mode != CGC_GEMM_EXACT && mode != CGC_GEMM_SPLIT_BF16) return CGC_EINVAL;
+  if (mode != CGC_GEMM_EXACT && mode != CGC_GEMM_SPLIT_BF16 && mode != CGC_GEMM_SPLIT_F16) return CGC_EINVAL;
   GemmArgs a;
   gemm_fill(a, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, strideA, strideB, strideC, gptr, ragged);
   return gemm_dispatch(a, transA, transB, batch, max_ragged, ws, ws_floats, mode, as_stream(stream_));
@@ -840,7 +847,7 @@ extern "C" int cgc_gemm_f32_cat_ws(int transA, int transB, int M, int N, int K, 
                                    const int* xldb, const int64_t* xstrideB, const int* xK, float* ws, int64_t ws_floats, int mode,
                                    cgc_stream_t stream_) {
   if (nx < 0 || nx > 2) return CGC_EINVAL;
-  if (mode != CGC_GEMM_EXACT && mode != CGC_GEMM_SPLIT_BF16) return CGC_EINVAL;
+  if (mode != CGC_GEMM_EXACT && mode != CGC_GEMM_SPLIT_BF16 && mode != CGC_GEMM_SPLIT_F16) return CGC_EINVAL;
   GemmArgs a;
   gemm_fill(a, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, strideA, strideB, strideC, gptr, ragged);
   int kept = 0;

@@ -28,6 +28,7 @@ struct GemmArgs {
   int resident;   // workgroups the chip holds at once = the quantum of a "round"
   int chunk;      // ragged 3: rows per part
   int s_max;      // most pieces a tail tile is cut into
+  const unsigned* scale;   // gemm_half.hip only: bits of max |A|, max |B| per batch item (2 per item); nullptr elsewhere
   // optional extra K segments: C += alpha * A_x[s] * B_x[s] (same op() orientation, M, N as the main pair), i.e. the
   // product of the column-concatenated [A | A_x0 | A_x1] with the row-concatenated [B ; B_x0 ; B_x1] without ever
   // materialising the concatenation (Linear over cat[x1,x2,x3]; dS = P dA'^T + X dX'^T)

@@ -247,7 +247,7 @@ def get():
 
 
 _EINVAL = -1                            # include/cgc_hip.h: CGC_EINVAL (nothing was launched)
-GEMM_EXACT, GEMM_SPLIT_BF16 = 0, 1      # include/cgc_hip.h: CGC_GEMM_EXACT / CGC_GEMM_SPLIT_BF16
+GEMM_EXACT, GEMM_SPLIT_BF16, GEMM_SPLIT_F16 = 0, 1, 2      # include/cgc_hip.h: CGC_GEMM_EXACT / CGC_GEMM_SPLIT_BF16 / CGC_GEMM_SPLIT_F16
 
 
 def is_native():
@@ -358,9 +358,10 @@ _NO_WS = _NoWorkspace()
 
 class HipKernels(KernelSpec):
     tail_split = True   # hand cgc_gemm_f32_ws its slab workspace (False: every output tile is computed whole; tests / A-B timing)
-    # cgc_gemm_f32_ws's `mode` for the products issued through this table (the per-operator path): GEMM_EXACT (default) or
-    # GEMM_SPLIT_BF16 -- the big products as six bf16 MFMA pairs per fp32 product (csrc/gemm_split.hip).  The encoder sets it from
-    # its own ``gemm_mode`` at the top of forward(); the sequencer gets the same choice through cgc_level_desc.flags bit 1.
+    # cgc_gemm_f32_ws's `mode` for the products issued through this table (the per-operator path): GEMM_EXACT (default),
+    # GEMM_SPLIT_BF16 -- the big products as six bf16 MFMA pairs per fp32 product (csrc/gemm_split.hip) -- or GEMM_SPLIT_F16 -- as
+    # three fp16 pairs of operands scaled per batch item (csrc/gemm_half.hip).  The encoder sets it from its own ``gemm_mode`` at
+    # the top of forward(); the sequencer gets the same choice through cgc_level_desc.flags bits 1 / 2.
     gemm_mode = 0
     # graph structure graph by graph in two launches when the Batch says how its edge list is grouped (cgc_graph_build_local;
     # CGC_GRAPH_LOCAL=0 / False: always the general build -- A-B timing, tests)
@@ -531,15 +532,17 @@ class HipKernels(KernelSpec):
 
     # -- dense contractions
     def _gemm_ws(self, device, stream):
-        """The slab workspace of the GEMM's tail split (include/cgc_hip.h: cgc_gemm_f32_ws), one per (device, stream): products
-        queued on one stream run one after the other and may share it; two streams must not."""
-        if not self.tail_split:
+        """The workspace of cgc_gemm_f32_ws (include/cgc_hip.h): the slabs of the tail split and, at its end, the scale slots of mode
+        GEMM_SPLIT_F16; one per (device, stream): products queued on one stream run one after the other and may share it; two
+        streams must not.  tail_split = False: no slabs -- mode GEMM_SPLIT_F16 still gets its scale slots (a workspace too small for
+        a slab)."""
+        if not self.tail_split and int(self.gemm_mode) != GEMM_SPLIT_F16:
             return _NO_WS
         key = (device.index, stream)
         ws = self._ws_cache.get(key)
         if ws is None:
             ws = self._ws_cache[key] = torch.empty(int(self.lib.cgc_gemm_ws_floats()), dtype=torch.float32, device=device)
-        return ws
+        return ws if self.tail_split else ws[-8192:]
 
     def gemm(self, A, B, C, M, N, K, transA, transB, lda, ldb, ldc, alpha=1.0, beta=0.0, bias=None,
              batch=1, strideA=0, strideB=0, strideC=0, gptr=None, ragged=0, max_ragged=0, ragged_total=0, extra=()):

@@ -188,7 +188,7 @@ def describe(enc, level, emb, pool, jk, B, n, rows_per_graph, nmax, npad, fin, c
     d.act, d.jk = ACT_CODES[emb.activation], int(jk is not None)
     d.renorm, d.renorm_p = int(enc.norm_adj), float(RENORM_P)
     d.eval = int(not enc.training)
-    d.flags = 2 if int(getattr(enc, 'gemm_mode', 0)) == 1 else 0      # (bit 0 is reserved: include/cgc_hip.h)
+    d.flags = {0: 0, 1: 2, 2: 4}[int(getattr(enc, 'gemm_mode', 0))]      # bit 1: six bf16 pairs, bit 2: three fp16 pairs (bit 0 is reserved: include/cgc_hip.h)
     for b_i, blk in enumerate(blocks):
         if blk.use_bn:
             for k in range(3):

@@ -25,6 +25,18 @@ RENORM_P = 0.4      # model/network.py:260,271,280
 REORDER_MIN_NODES = 4000    # graphs at least this large get their nodes listed grid cell by grid cell (_spatially_ordered)
 
 
+def default_gemm_mode():
+    """An encoder's ``gemm_mode`` when nothing else sets it: ``CGC_GEMM_16BIT`` = ``0`` / ``exact`` (kernels.GEMM_EXACT), ``1`` / ``bf16``
+    (GEMM_SPLIT_BF16), ``2`` / ``f16`` (GEMM_SPLIT_F16); unset: the older switch ``CGC_GEMM_SPLIT_BF16`` (0 / 1 / 2), whose default is 1."""
+    v = os.environ.get('CGC_GEMM_16BIT')
+    if v is None:
+        v = os.environ.get('CGC_GEMM_SPLIT_BF16', '1')
+    names = {'0': 0, 'exact': 0, 'off': 0, '1': 1, 'bf16': 1, '2': 2, 'f16': 2, 'fp16': 2}
+    if v.lower() not in names:
+        raise ValueError('CGC_GEMM_16BIT / CGC_GEMM_SPLIT_BF16 = %r: expected one of %s' % (v, sorted(names)))
+    return names[v.lower()]
+
+
 def _activation_module(name):
     assert name in ('relu', 'elu', 'leakyrelu')          # model/network.py:84-91
     return {'relu': nn.ReLU, 'elu': nn.ELU, 'leakyrelu': nn.LeakyReLU}[name](inplace=True)
@@ -335,7 +347,7 @@ class SoftPoolingGcnEncoder(nn.Module):
         # tests/test_split_gemm_gpu.py has the bounds, the reference's fixtures run through it with every product forced onto that
         # route), 1.3-1.4x faster on those products, the step 1.18x.  0 = kernels.GEMM_EXACT (CGC_GEMM_SPLIT_BF16=0): the fp32
         # matrix-core chain for every product -- what bench.py's headline `value` is measured with.  Smaller products are exact either way.
-        self.gemm_mode = int(os.environ.get('CGC_GEMM_SPLIT_BF16', '1'))
+        self.gemm_mode = default_gemm_mode()
         self._unorder = None
 
     def __getstate__(self):

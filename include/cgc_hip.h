@@ -200,7 +200,9 @@ int cgc_gemm_f32_cat(int transA, int transB, int M, int N, int K, float alpha, c
  * mode does not apply to run on the exact kernel.  The plain entry points above are always exact. */
 #define CGC_GEMM_EXACT 0
 #define CGC_GEMM_SPLIT_BF16 1
+#define CGC_GEMM_SPLIT_F16 2
 int64_t cgc_gemm_split_count(void);   /* products this process has sent to the split kernel so far (diagnostic: did the mode apply?) */
+int64_t cgc_gemm_half_count(void);    /* ... and to the fp16 kernel of mode CGC_GEMM_SPLIT_F16 */
 int64_t cgc_gemm_ws_floats(void);
 int cgc_gemm_f32_ws(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
                     const float* B, int ldb, float beta, float* C, int ldc, const float* bias, int batch,

@@ -22,16 +22,19 @@ def torch_kernels(monkeypatch):
     yield
 
 
-@pytest.fixture(params=['exact', 'split'])
+@pytest.fixture(params=['exact', 'split', 'half'])
 def gemm_mode(request, monkeypatch):
-    """Run a model-level GPU test twice: with the default exact fp32 GEMM and with CGC_GEMM_SPLIT_BF16 (csrc/gemm_split.hip: the big
-    products as six bf16 MFMA pairs per fp32 product) -- same test body, same bars.  Encoders built inside the test pick the mode up
-    from the environment (network.SoftPoolingGcnEncoder.gemm_mode); the fixture also reports how many products took the split kernel."""
+    """Run a model-level GPU test three times: with the exact fp32 GEMM, with CGC_GEMM_SPLIT_BF16 (csrc/gemm_split.hip: the big
+    products as six bf16 MFMA pairs per fp32 product) and with CGC_GEMM_SPLIT_F16 (csrc/gemm_half.hip: three fp16 pairs of scaled
+    operands) -- same test body, same bars.  Encoders built inside the test pick the mode up from the environment
+    (network.default_gemm_mode); the fixture also reports how many products took the 16-bit kernels."""
     import cgc_net_amd.kernels as kernels
-    split = request.param == 'split'
-    monkeypatch.setenv('CGC_GEMM_SPLIT_BF16', '1' if split else '0')
+    split = request.param != 'exact'
+    monkeypatch.delenv('CGC_GEMM_SPLIT_BF16', raising=False)
+    monkeypatch.setenv('CGC_GEMM_16BIT', {'exact': '0', 'split': '1', 'half': '2'}[request.param])
     K = kernels.get()
-    before = int(K.lib.cgc_gemm_split_count())
+    count = lambda: int(K.lib.cgc_gemm_split_count()) + int(K.lib.cgc_gemm_half_count())
+    before = count()
 
     class Mode(object):
         name = request.param
@@ -39,7 +42,7 @@ def gemm_mode(request, monkeypatch):
 
         @staticmethod
         def launches():
-            return int(K.lib.cgc_gemm_split_count()) - before
+            return count() - before
     yield Mode
     K.gemm_mode = kernels.GEMM_EXACT
 

@@ -46,7 +46,7 @@ def _log_decisions(what, winner_flips, relu_flips):
     if path:
         with open(path, 'a') as fh:
             fh.write('%s | mode %s | winners differing %d, largest relative fp64 gap there %.3e | signs differing %d, largest |fp64 value| there %.3e\n'
-                     % (what, os.environ.get('CGC_GEMM_SPLIT_BF16', '0'), winner_flips, STATS.get('winner_gap', 0.0), relu_flips, STATS.get('flip_at', 0.0)))
+                     % (what, os.environ.get('CGC_GEMM_16BIT', os.environ.get('CGC_GEMM_SPLIT_BF16', '1')), winner_flips, STATS.get('winner_gap', 0.0), relu_flips, STATS.get('flip_at', 0.0)))
 
 
 class HipDecisions(object):

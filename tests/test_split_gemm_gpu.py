@@ -17,7 +17,7 @@ from cgc_net_amd import kernels
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
-EXACT, SPLIT = kernels.GEMM_EXACT, kernels.GEMM_SPLIT_BF16
+EXACT, SPLIT, HALF = kernels.GEMM_EXACT, kernels.GEMM_SPLIT_BF16, kernels.GEMM_SPLIT_F16
 
 
 def hip():
@@ -49,20 +49,27 @@ def gen(shape, seed, kind, mn=-2):
     return x.to(DEV)
 
 
-def both_modes(run, want, mag):
-    """run(mode) -> output tensor; returns {mode: (max, rms)} of |out - want| / mag and asserts the split kernel really ran."""
+def mode_count(k, mode):
+    """launches so far of the kernel that serves ``mode`` (0 for the exact one: it has no counter)"""
+    return int(k.lib.cgc_gemm_split_count()) if mode == SPLIT else int(k.lib.cgc_gemm_half_count()) if mode == HALF else 0
+
+
+def both_modes(run, want, mag, modes=None):
+    """run() -> output tensor under k.gemm_mode; returns {mode: (max, rms)} of |out - want| / mag and asserts that the kernel of the mode
+    really ran (and no other 16-bit kernel did)."""
     k = hip()
     res = {}
-    for mode in (EXACT, SPLIT):
-        before = int(k.lib.cgc_gemm_split_count())
+    for mode in (modes or (EXACT, SPLIT)):
+        before = {m: mode_count(k, m) for m in (SPLIT, HALF)}
         k.gemm_mode = mode
         try:
             out = run()
         finally:
             k.gemm_mode = EXACT
         torch.cuda.synchronize()
-        ran = int(k.lib.cgc_gemm_split_count()) - before
-        assert (ran > 0) == (mode == SPLIT), (mode, ran)
+        for m in (SPLIT, HALF):
+            ran = mode_count(k, m) - before[m]
+            assert (ran > 0) == (mode == m), (mode, m, ran)
         e = (out.double() - want).abs() / mag
         assert torch.isfinite(out).all()
         res[mode] = (float(e.max()), float(e.pow(2).mean().sqrt()))

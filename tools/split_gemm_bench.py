@@ -1,8 +1,9 @@
 #!/usr/bin/env python
 """The six dominant products of a 32-graph step (profiles/r04_gemm_calls_by_shape.txt), stand-alone, in both modes of cgc_gemm_f32_ws:
-exact (fp32 MFMA chain) and split (six bf16 MFMA pairs, csrc/gemm_split.hip).  Operands on the row strides the step uses.  Per product:
+exact (fp32 MFMA chain), split (six bf16 MFMA pairs, csrc/gemm_split.hip) and half (three fp16 pairs of scaled operands, csrc/gemm_half.hip;
+its time includes the operand-maximum pass).  Operands on the row strides the step uses.  Per product:
 time of a launch (mean over `reps` back-to-back launches after a long warm-up: the clock ramps over milliseconds), fp32-equivalent
-TFLOP/s, fraction of the fp32 MFMA peak (157.3) and -- split mode -- of the bf16 pipe: 6 x 2MNK / t / 2500 TF.
+TFLOP/s, fraction of the fp32 MFMA peak (157.3) and -- split / half mode -- of the 16-bit pipe: (6 | 3) x 2MNK / t / 2500 TF.
 usage: python tools/split_gemm_bench.py [reps] [graphs]     CGC_LIB selects a variant library."""
 import os
 import sys
@@ -48,12 +49,15 @@ cases_all = [
 ]
 sel = os.environ.get('SPLIT_BENCH_CASES')          # e.g. 1,4: only these products
 cases = [c for i, c in enumerate(cases_all) if sel is None or str(i) in sel.split(',')]
-tot = {0: 0.0, 1: 0.0}
+MODES = [int(m) for m in os.environ.get('SPLIT_BENCH_MODES', '0,1,2').split(',')]     # 0 exact, 1 six bf16 pairs, 2 three fp16 pairs
+NAMES = {0: 'exact', 1: 'split', 2: 'half'}
+PAIRS = {1: 6, 2: 3}
+tot = {m: 0.0 for m in MODES}
 print('%d graphs, %d rows; lib=%s' % (B, n, os.path.basename(kernels.lib_path())))
 for name, fn, rows in cases:
     fl = 2.0 * rows * C * C
     line = '%-62s' % name
-    for mode in (0, 1):
+    for mode in MODES:
         K.gemm_mode = mode
         out_n.zero_()
         for _ in range(25):
@@ -68,8 +72,8 @@ for name, fn, rows in cases:
         ms = s.elapsed_time(e) / reps
         tot[mode] += ms
         tf = fl / ms / 1e9
-        line += '  %s %7.1f us %6.1f TF (%.3f of fp32 MFMA%s)' % ('exact' if mode == 0 else 'split', ms * 1e3, tf, tf / 157.3,
-                                                                   '' if mode == 0 else '; bf16 pipe %.3f' % (6 * tf / 2500.0))
+        line += '  %s %7.1f us %6.1f TF (%.3f of fp32 MFMA%s)' % (NAMES[mode], ms * 1e3, tf, tf / 157.3,
+                                                                   '' if mode == 0 else '; 16-bit pipe %.3f' % (PAIRS[mode] * tf / 2500.0))
     K.gemm_mode = 0
     print(line)
-print('six products: exact %.1f us, split %.1f us  (%.2fx)' % (tot[0] * 1e3, tot[1] * 1e3, tot[0] / tot[1]))
+print('six products: ' + ', '.join('%s %.1f us' % (NAMES[m], tot[m] * 1e3) for m in MODES))
