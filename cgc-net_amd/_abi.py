@@ -3,7 +3,7 @@ import ctypes as C
 
 P, I, F, D, L = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_int64
 
-ABI_VERSION = 4      # = CGC_ABI_VERSION of include/cgc_hip.h these prototypes were written against (tests compare the two)
+ABI_VERSION = 5      # = CGC_ABI_VERSION of include/cgc_hip.h these prototypes were written against (tests compare the two)
 
 PROTOTYPES = {
     'cgc_abi_version': [],
@@ -29,6 +29,7 @@ PROTOTYPES = {
     'cgc_gemm_ws_floats': [],
     'cgc_gemm_split_count': [],
     'cgc_gemm_half_count': [],
+    'cgc_gemm_half_ws_floats': [],
     'cgc_gemm_f32_ws': [I, I, I, I, I, F, P, I, P, I, F, P, I, P, I, L, L, L, P, I, I, P, L, I, P],
     'cgc_gemm_f32_cat_ws': [I, I, I, I, I, F, P, I, P, I, F, P, I, P, I, L, L, L, P, I, I, I, P, P, P, P, P, P, P, P, L, I, P],
     'cgc_gemm_tuning': [I],

@@ -1,5 +1,5 @@
-// fp32 products on the fp16 matrix cores of gfx950 in THREE passes: every operand element, scaled by a power of two chosen per batch
-// item from the operand's largest magnitude, is split into two fp16 values  s x = h + l  (h = fp16(s x), l = fp16(s x - h), both
+// fp32 products on the fp16 matrix cores of gfx950 in THREE passes: every operand element, scaled by a power of two chosen per OUTPUT
+// TILE from the largest magnitude of the tile's operand panel, is split into two fp16 values  s x = h + l  (h = fp16(s x), l = fp16(s x - h), both
 // round-to-nearest; the residual is exact in fp32), and the product is formed as the three most significant pairs  l h + h l + h h  in
 // the matrix core's fp32 accumulator, descaled in registers before the epilogue.  h + l carries 22-23 of the 24 significand bits
 // (|s x - h - l| <= 2^-23 |s x| while l is a normal fp16) and the dropped pair l l is below 2^-22 |a||b|: with fp32 accumulation over
@@ -9,11 +9,13 @@
 // fp32 chain.
 //
 // What fp16 costs is RANGE, and that is what the scale is for: 5 exponent bits, normal from 2^-14.  A first launch (k_gemm_absmax)
-// takes max |x| over each batch item's A segments and over its B segments (one streaming pass over both operands: the price of the
-// mode, ~45 us per 263 MB operand); the product kernel places that maximum in [2^14, 2^15).  Elements down to 2^-17 of their item's
-// maximum then keep both planes normal; below, l and finally h go subnormal and the element's ABSOLUTE error stops shrinking at
-// 2^-25 / s = 2^-40 of the item's maximum (fp32 itself: 2^-24 of the element).  Zeros are exact; an item that is all zero takes s = 1.
-// Domain: finite inputs (an infinite element makes its whole batch item NaN; the exact kernel confines it to its row / column).
+// takes max |x| over the 256 rows of op(A) that an output tile multiplies (all of K, every segment) and over its 128 columns of
+// op(B) -- one streaming pass over both operands: the price of the mode, ~50 us per 263 MB operand -- and the product kernel places
+// each panel's maximum in [2^14, 2^15).  Elements down to 2^-17 of their panel's maximum then keep both planes normal; below, l and
+// finally h go subnormal and the element's ABSOLUTE error stops shrinking at 2^-25 / s = 2^-40 of the panel's maximum (fp32 itself:
+// 2^-24 of the element).  Zeros are exact; a panel that is all zero takes s = 1.  (One scale per batch item was the first version:
+// the gradient of a 32-graph batch, one item of 58 k rows, had 46 % of its elements below 2^-17 of the tensor's maximum.)
+// Domain: finite inputs (an infinite element makes the tiles of its panel NaN; the exact kernel confines it to its row / column).
 //
 // Third MODE of the same entry points (CGC_GEMM_SPLIT_F16; cgc_level_desc.flags bit 2), for the same products and forms as
 // gemm_split.hip, and with its structure: tile 256 x 128, one wave per SIMD with a 128 x 64 wave tile, k-tiles of 16, two LDS stages
@@ -27,8 +29,9 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int H_PLA = S_BM * SROW, H_PLB = S_BN * SROW, H_STAGE = 2 * H_PLA + 2 * H_PLB, H_LDS = 2 * H_STAGE;   // 73728 bytes
-// scale slots at the end of the caller's workspace (floats reserved: cgc_gemm_ws_floats() counts them): max |A|, max |B| per batch item
-constexpr int H_SCALE_FLOATS = 8192;
+// scale slots at the end of the caller's workspace (floats reserved: cgc_gemm_ws_floats() counts them): max |A| per (batch item, 256-row
+// tile), max |B| per (batch item, 128-column tile)
+constexpr int H_SCALE_FLOATS = 65536;
 
 __device__ __forceinline__ unsigned pack_f16(float a, float b) {      // round to nearest even, a in the low half
   float2v t;
@@ -132,8 +135,12 @@ __device__ __forceinline__ void half_body(const GemmArgs& a, const int b, const 
   if (m0 >= M) return;
 
   float sa, sb, isa, isb;
-  half_scale(a.scale[2 * b], sa, isa);
-  half_scale(a.scale[2 * b + 1], sb, isb);
+  {
+    const int ta = a.per_batch / a.tiles_n;                    // row tiles of the largest item: the slot layout of k_gemm_absmax
+    const unsigned* sc = a.scale + (size_t)b * (ta + a.tiles_n);
+    half_scale(sc[tile_m], sa, isa);
+    half_scale(sc[ta + tile_n], sb, isb);
+  }
 
   typedef typename std::conditional<TA, SplitLoaderMN<S_BM, SROW>, SplitLoaderK<S_BM, SROW>>::type LoaderA;
   typedef typename std::conditional<TB, SplitLoaderK<S_BN, SROW>, SplitLoaderMN<S_BN, SROW>>::type LoaderB;
@@ -344,54 +351,70 @@ __global__ __launch_bounds__(256, 1) void k_gemm_half(const GemmArgs a) {
   half_body<TA, TB, false>(a, b, tile_id, piece, S, tj, slds);
 }
 
-// ---- max |x| over the operand segments of every batch item: scale[2 b] for A, scale[2 b + 1] for B (bits of a non-negative float:
-// unsigned order is magnitude order; the caller zeroes the slots).  grid (parts, batch items); a wave streams whole rows.
-__device__ __forceinline__ float region_absmax(const float* __restrict__ p, int rows, int cols, int ld, int w, int nw, int lane) {
-  float m = 0.f;
+// ---- max |x| per OUTPUT TILE's operand panel: for batch item b, scale[b * (ta + tn) + t] = the bits of max |x| over rows
+// 256 t .. 256 t + 255 of op(A) (all of K, every segment) and scale[b * (ta + tn) + ta + t] over columns 128 t .. 128 t + 127 of op(B)
+// (bits of a non-negative float: unsigned order is magnitude order; the caller zeroes the slots).  grid (panels x their sub-ranges,
+// batch items): a workgroup streams a share of one panel's rows -- stored rows of 16-byte units, one or two per wave-load.
+__device__ __forceinline__ float rect_absmax(const float* __restrict__ p, int rows, int cols, int ld, int w, int nw, int lane) {
+  float m0 = 0.f, m1 = 0.f;
   const int cv = cols & ~3;
-  for (int r = w; r < rows; r += nw) {
-    const float* row = p + (size_t)r * ld;
+  const int lpr = cols > 128 ? 64 : 32, rpl = 64 / lpr;      // lanes per stored row, stored rows per wave-load
+  const int l = lane % lpr, step = nw * rpl;
+  int r = w * rpl + lane / lpr;
+  for (; r + step < rows; r += 2 * step) {                    // two trips' loads in flight
+    const float* q0 = p + (size_t)r * ld;
+    const float* q1 = p + (size_t)(r + step) * ld;
 #pragma unroll 5
-    for (int c = lane * 4; c < cv; c += 256) {
-      const float4 v = *reinterpret_cast<const float4*>(row + c);
-      m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    for (int c = l * 4; c < cv; c += lpr * 4) {
+      const float4 u = *reinterpret_cast<const float4*>(q0 + c), v = *reinterpret_cast<const float4*>(q1 + c);
+      m0 = fmaxf(m0, fmaxf(fmaxf(fabsf(u.x), fabsf(u.y)), fmaxf(fabsf(u.z), fabsf(u.w))));
+      m1 = fmaxf(m1, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
     }
-    if (lane < cols - cv) m = fmaxf(m, fabsf(row[cv + lane]));      // (the padding behind a row's end is not the operand's)
+    if (l < cols - cv) {                                      // (the padding behind the panel's last column is not the operand's)
+      m0 = fmaxf(m0, fabsf(q0[cv + l]));
+      m1 = fmaxf(m1, fabsf(q1[cv + l]));
+    }
   }
-  return m;
+  if (r < rows) {
+    const float* q0 = p + (size_t)r * ld;
+    for (int c = l * 4; c < cv; c += lpr * 4) {
+      const float4 u = *reinterpret_cast<const float4*>(q0 + c);
+      m0 = fmaxf(m0, fmaxf(fmaxf(fabsf(u.x), fabsf(u.y)), fmaxf(fabsf(u.z), fabsf(u.w))));
+    }
+    if (l < cols - cv) m0 = fmaxf(m0, fabsf(q0[cv + l]));
+  }
+  return fmaxf(m0, m1);
 }
 template <bool TA, bool TB>
-__global__ __launch_bounds__(256) void k_gemm_absmax(const GemmArgs a, unsigned* __restrict__ scale) {
-  const int b = blockIdx.y, lane = threadIdx.x & 63;
-  const int w = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
+__global__ __launch_bounds__(256) void k_gemm_absmax(const GemmArgs a, unsigned* __restrict__ scale, int ta, int sub_a, int sub_b) {
+  const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const TileBase tb(a, b);
   const int M = tb.M, K = tb.K, N = a.N;
-  float ma = TA ? region_absmax(tb.A, K, M, a.lda, w, nw, lane) : region_absmax(tb.A, M, K, a.lda, w, nw, lane);
-  float mb = TB ? region_absmax(tb.B, N, K, a.ldb, w, nw, lane) : region_absmax(tb.B, K, N, a.ldb, w, nw, lane);
+  const bool is_a = (int)blockIdx.x < ta * sub_a;
+  const int id = is_a ? (int)blockIdx.x : (int)blockIdx.x - ta * sub_a;
+  const int sub = is_a ? sub_a : sub_b, t = id / sub, w = (id - t * sub) * 4 + wave, nw = sub * 4;
+  const int lo = t * (is_a ? S_BM : S_BN), ext = is_a ? M : N;
+  if (lo >= ext) return;
+  const int len = min(is_a ? S_BM : S_BN, ext - lo);
   const size_t roff = a.ragged == 1 ? (size_t)a.gptr[b] : 0;
-  for (int i = 0; i < a.nx; ++i) {
-    const float* xa = a.xA[i] + (size_t)b * a.xsA[i] + roff * a.xlda[i];
-    const float* xb = a.xB[i] + (size_t)b * a.xsB[i];
-    ma = fmaxf(ma, TA ? region_absmax(xa, a.xK[i], M, a.xlda[i], w, nw, lane) : region_absmax(xa, M, a.xK[i], a.xlda[i], w, nw, lane));
-    mb = fmaxf(mb, TB ? region_absmax(xb, N, a.xK[i], a.xldb[i], w, nw, lane) : region_absmax(xb, a.xK[i], N, a.xldb[i], w, nw, lane));
+  float m = 0.f;
+  for (int i = -1; i < a.nx; ++i) {            // the main pair, then the extra K segments
+    const float* base = is_a ? (i < 0 ? tb.A : a.xA[i] + (size_t)b * a.xsA[i] + roff * a.xlda[i]) : (i < 0 ? tb.B : a.xB[i] + (size_t)b * a.xsB[i]);
+    const int ld = is_a ? (i < 0 ? a.lda : a.xlda[i]) : (i < 0 ? a.ldb : a.xldb[i]);
+    const int kk = i < 0 ? K : a.xK[i];
+    const bool k_is_row = is_a ? TA : !TB;     // the operand is stored [K, .]: the panel is a column window of it
+    m = fmaxf(m, k_is_row ? rect_absmax(base + lo, kk, len, ld, w, nw, lane) : rect_absmax(base + (size_t)lo * ld, len, kk, ld, w, nw, lane));
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    ma = fmaxf(ma, __shfl_xor(ma, o));
-    mb = fmaxf(mb, __shfl_xor(mb, o));
-  }
-  // one pair of atomics per WORKGROUP, and only when it would raise the slot: thousands of atomics on one address execute one after
-  // the other at the memory side (the first version -- two per wave, 16 k per launch -- spent two thirds of its time there)
-  __shared__ float red[2][4];
-  if (lane == 0) {
-    red[0][threadIdx.x >> 6] = ma;
-    red[1][threadIdx.x >> 6] = mb;
-  }
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  // one atomic per WORKGROUP, and only when it would raise the slot: thousands of atomics on one address execute one after the other
+  // at the memory side (the first version -- two per wave, 16 k per launch on two addresses -- spent two thirds of its time there)
+  __shared__ float red[4];
+  if (lane == 0) red[wave] = m;
   __syncthreads();
-  if (threadIdx.x < 2) {
-    const float m = fmaxf(fmaxf(red[threadIdx.x][0], red[threadIdx.x][1]), fmaxf(red[threadIdx.x][2], red[threadIdx.x][3]));
-    const unsigned bits = __builtin_bit_cast(unsigned, m);
-    unsigned* slot = scale + 2 * b + threadIdx.x;
+  if (threadIdx.x == 0) {
+    const unsigned bits = __builtin_bit_cast(unsigned, fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+    unsigned* slot = scale + (size_t)b * (ta + a.tiles_n) + (is_a ? t : ta + t);
     if (bits > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, bits);
   }
 }
@@ -402,6 +425,7 @@ static const int kHalfResident = 256;
 static int64_t g_half_launches = 0;
 extern "C" int64_t cgc_gemm_half_count(void) { return __atomic_load_n(&g_half_launches, __ATOMIC_RELAXED); }
 int64_t gemm_half_scale_floats() { return H_SCALE_FLOATS; }
+extern "C" int64_t cgc_gemm_half_ws_floats(void) { return H_SCALE_FLOATS; }
 
 // Launch for a product that qualifies (gemm.hip: gemm_dispatch decided: 128 x 128 route, every operand segment fit for unguarded
 // 16-byte loads).  CGC_EINVAL: no workspace for the scales / more batch items than slots / a shape outside what the kernel indexes --
@@ -409,7 +433,7 @@ int64_t gemm_half_scale_floats() { return H_SCALE_FLOATS; }
 int gemm_half_launch(const GemmArgs& a0, int transA, int transB, int batch, int m_extent, int k_extent, float* ws, int64_t ws_floats,
                      hipStream_t stream) {
   if (transA && transB) return CGC_EINVAL;
-  if (ws == nullptr || ws_floats < H_SCALE_FLOATS || 2LL * batch > H_SCALE_FLOATS || batch > 65535) return CGC_EINVAL;
+  if (ws == nullptr || ws_floats < H_SCALE_FLOATS || batch > 65535) return CGC_EINVAL;
   GemmArgs a = a0;
   a.tiles_n = ceil_div(a.N, S_BN);
   static const int map_mode = getenv("CGC_GEMM_MAP") ? atoi(getenv("CGC_GEMM_MAP")) : 3;
@@ -417,6 +441,9 @@ int gemm_half_launch(const GemmArgs& a0, int transA, int transB, int batch, int 
   const long long per_batch = (long long)ceil_div(m_extent, S_BM) * a.tiles_n;
   const long long tiles = per_batch * batch;
   if (per_batch <= 0 || tiles > 0x7ffffff0LL) return CGC_EINVAL;
+  const int ta = ceil_div(m_extent, S_BM);
+  const long long slots = (long long)batch * (ta + a.tiles_n);
+  if (slots > H_SCALE_FLOATS) return CGC_EINVAL;
   a.per_batch = (int)per_batch;
   a.nb = batch;
   a.ws = nullptr;
@@ -444,16 +471,18 @@ int gemm_half_launch(const GemmArgs& a0, int transA, int transB, int batch, int 
   const int trec = cgc_timing_begin(CGC_TAG_GEMM_128, a.M, a.N, a.K, batch, a.ragged, a.ragged ? (a.ragged == 1 ? m_extent : k_extent) : 0,
                                     xk, stream);
   {
-    const hipError_t e = hipMemsetAsync(scale, 0, sizeof(unsigned) * 2 * (size_t)batch, stream);
+    const hipError_t e = hipMemsetAsync(scale, 0, sizeof(unsigned) * (size_t)slots, stream);
     if (e != hipSuccess) return (int)e;
   }
-  const int parts = batch >= 1024 ? 1 : ceil_div(1024, batch);      // ~4 workgroups per CU, each streaming many rows
-  dim3 grid((unsigned)(tiles + extra)), block(256), mgrid((unsigned)parts, (unsigned)batch);
+  // ~4 workgroups per CU for each operand, a panel's rows shared by up to 64 of them
+  auto subs = [&](int panels) { const long long n = (long long)batch * panels; const int v = n >= 1024 ? 1 : ceil_div(1024, (int)n); return v > 64 ? 64 : v; };
+  const int sub_a = subs(ta), sub_b = subs(a.tiles_n);
+  dim3 grid((unsigned)(tiles + extra)), block(256), mgrid((unsigned)(ta * sub_a + a.tiles_n * sub_b), (unsigned)batch);
 #define HALF_LAUNCH(TA_, TB_)                                                                               \
   do {                                                                                                      \
     static bool attr__[CGC_MAX_DEVICES] = {};                                                               \
     cgc_allow_lds(reinterpret_cast<const void*>(&k_gemm_half<TA_, TB_>), H_LDS, attr__);                    \
-    hipLaunchKernelGGL((k_gemm_absmax<TA_, TB_>), mgrid, block, 0, stream, a, scale);                       \
+    hipLaunchKernelGGL((k_gemm_absmax<TA_, TB_>), mgrid, block, 0, stream, a, scale, ta, sub_a, sub_b);                       \
     hipLaunchKernelGGL((k_gemm_half<TA_, TB_>), grid, block, H_LDS, stream, a);                             \
   } while (0)
   if (!transA && !transB) HALF_LAUNCH(false, false);

@@ -542,7 +542,7 @@ class HipKernels(KernelSpec):
         ws = self._ws_cache.get(key)
         if ws is None:
             ws = self._ws_cache[key] = torch.empty(int(self.lib.cgc_gemm_ws_floats()), dtype=torch.float32, device=device)
-        return ws if self.tail_split else ws[-8192:]
+        return ws if self.tail_split else ws[-int(self.lib.cgc_gemm_half_ws_floats()):]
 
     def gemm(self, A, B, C, M, N, K, transA, transB, lda, ldb, ldc, alpha=1.0, beta=0.0, bias=None,
              batch=1, strideA=0, strideB=0, strideC=0, gptr=None, ragged=0, max_ragged=0, ragged_total=0, extra=()):

@@ -43,8 +43,10 @@ typedef void* cgc_stream_t; /* hipStream_t */
  *   3: round 5 (cgc_gemm_f32_ws / cgc_gemm_f32_cat_ws take a `mode`; cgc_level_desc.flags bit 1; head: a label outside [0, L) other
  *      than -100 makes the loss NaN instead of being ignored)
  *   4: round 6 (removed: cgc_adj_prep_fwd2, cgc_adj_grad_operands, cgc_zero_diag and cgc_level_desc.flags bit 0 -- the thin-operand
- *      adjacency gradient; a descriptor with bit 0 set is refused.  Added: cgc_graph_build_local, cgc_graph_local_max_nodes) */
-#define CGC_ABI_VERSION 4
+ *      adjacency gradient; a descriptor with bit 0 set is refused.  Added: cgc_graph_build_local, cgc_graph_local_max_nodes)
+ *   5: round 6 (mode CGC_GEMM_SPLIT_F16 of cgc_gemm_f32_ws / cgc_gemm_f32_cat_ws; cgc_level_desc.flags bit 2; cgc_gemm_half_count, cgc_gemm_half_ws_floats;
+ *      cgc_gemm_ws_floats() grew by the mode's scale slots: workspaces sized by an older library are too small for the tail split) */
+#define CGC_ABI_VERSION 5
 int cgc_abi_version(void);
 
 /* ---- A1: graph structure.  Replaces to_dense_adj (model/utils.py:3-36, called at model/network.py:241).
@@ -197,12 +199,22 @@ int cgc_gemm_f32_cat(int transA, int transB, int M, int N, int K, float alpha, c
  * the six pairs above 2^-24 multiplied exactly and summed in fp32 (csrc/gemm_split.hip).  Same forms (NN / NT / TN, ragged 1 / 2 / 3,
  * extra K segments, beta, bias, tail split), same determinism; max and rms error against float64 within 1.25 x the exact kernel's
  * (tests/test_kernels_gpu.py::test_split_gemm_*).  Inputs must be finite; magnitudes below ~2^-108 lose the low planes.  Products the
- * mode does not apply to run on the exact kernel.  The plain entry points above are always exact. */
+ * mode does not apply to run on the exact kernel.  The plain entry points above are always exact.
+ * CGC_GEMM_SPLIT_F16 (round 6, csrc/gemm_half.hip) -- the same products on the fp16 matrix cores in THREE passes: a first launch
+ * takes max |x| over every output tile's operand panels (256 rows of op(A), 128 columns of op(B), all of K); every element, scaled
+ * by the power of two that puts its panel's maximum in [2^14, 2^15), is split into two fp16 values h + l, the pairs l h, h l, h h
+ * are summed in fp32 and the tile is descaled.  Same forms, same determinism; needs ws (its scale slots are the last
+ * cgc_gemm_half_ws_floats() floats of the workspace; ws = NULL or more panels than slots: the exact kernel runs).  Error against
+ * float64 within 1.25 x the exact kernel's -- measured 0.55-1.0 x -- while an element is within 2^17 of its panel's largest; below
+ * that the element's ABSOLUTE error stops shrinking at 2^-40 of the panel's maximum (bound and measurements:
+ * tests/test_half_gemm_gpu.py, tools/operand_range.py for the step's own operands).  Inputs must be finite (an infinite element
+ * makes the tiles of its panel NaN).  1.25 x faster than CGC_GEMM_SPLIT_BF16 on the step's six products, operand pass included. */
 #define CGC_GEMM_EXACT 0
 #define CGC_GEMM_SPLIT_BF16 1
 #define CGC_GEMM_SPLIT_F16 2
 int64_t cgc_gemm_split_count(void);   /* products this process has sent to the split kernel so far (diagnostic: did the mode apply?) */
 int64_t cgc_gemm_half_count(void);    /* ... and to the fp16 kernel of mode CGC_GEMM_SPLIT_F16 */
+int64_t cgc_gemm_half_ws_floats(void); /* the part of cgc_gemm_ws_floats() that mode CGC_GEMM_SPLIT_F16 needs by itself (scale slots, at the end) */
 int64_t cgc_gemm_ws_floats(void);
 int cgc_gemm_f32_ws(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
                     const float* B, int ldb, float beta, float* C, int ldc, const float* bias, int batch,

@@ -54,8 +54,31 @@ def report(tag, a, bm):
     tot = t.sum(1).clamp_min(1e-300)
     top2 = t.topk(min(2, Kd), dim=1).values.sum(1) / tot
     sa, sb = spread(a, 1), spread(bm, 0)
+    # mode CGC_GEMM_SPLIT_F16 (csrc/gemm_half.hip): the representation bound of the same outputs.  An element's error is at most
+    # max(2^-22 |x|, 2^-24 / s) with s the scale of its panel (256 rows of op(A) / 128 columns of op(B); max |x| s in [2^14, 2^15)); the first term alone gives 2 x 2^-22 = 8 U of
+    # sum |a||b| (U = 2^-24) on any input -- what is printed is how much the second term (elements more than 2^17 below their panel's
+    # maximum) adds on THESE operands: 8.0 = nothing.
+    def rep(x, axis, blk):
+        """per panel (``blk`` consecutive output indices along ``axis``): scale and representation error of every element"""
+        n = x.shape[axis]
+        pad = (-n) % blk
+        ax = x.abs()
+        if axis == 1:
+            ax = ax.t()
+        mx = torch.nn.functional.pad(ax, (0, 0, 0, pad)).view(-1, blk, ax.shape[1]).amax(dim=(1, 2))          # [panels]
+        sc = torch.where(mx > 0, torch.exp2(14 - torch.floor(torch.log2(mx.clamp_min(1e-300)))), torch.ones_like(mx))
+        sc = sc.repeat_interleave(blk)[:n]
+        sc = sc[:, None] if axis == 0 else sc[None, :]
+        return torch.maximum(2.0 ** -22 * x.abs(), (2.0 ** -24 / sc).expand_as(x)), sc
+    (da, s_a), (db, s_b) = rep(a, 0, 256), rep(bm, 1, 128)
+    bnd = (da[i] * bm[:, j].t().abs() + a[i].abs() * db[:, j].t() + da[i] * db[:, j].t()).sum(1) / tot / 2.0 ** -24
+    low_a = float((a.abs() * s_a < 2.0 ** -3).double().mean()), float((a.abs() * s_a < 2.0 ** -14).double().mean())
+    low_b = float((bm.abs() * s_b < 2.0 ** -3).double().mean()), float((bm.abs() * s_b < 2.0 ** -14).double().mean())
     print('%-44s K = %-6d spread along K (log2 max / rms; median, max over outputs): A %.1f, %.1f   B %.1f, %.1f   top-2 share of sum |a||b|: '
-          'median %.4f  p99 %.4f  max %.4f' % (tag, Kd, sa[0], sa[1], sb[0], sb[1], float(top2.median()), float(top2.quantile(0.99)), float(top2.max())))
+          'median %.4f  p99 %.4f  max %.4f | fp16 mode: representation bound / (U sum |a||b|): median %.2f  p99 %.2f  max %.2f; elements with a '
+          'subnormal l plane / subnormal h plane: A %.3f / %.5f  B %.3f / %.5f'
+          % (tag, Kd, sa[0], sa[1], sb[0], sb[1], float(top2.median()), float(top2.quantile(0.99)), float(top2.max()),
+             float(bnd.median()), float(bnd.quantile(0.99)), float(bnd.max()), low_a[0], low_a[1], low_b[0], low_b[1]))
 
 
 def spy(A, Bm, C, M, N, Kd, tA, tB, lda, ldb, ldc, alpha=1.0, beta=0.0, bias=None, batch=1, sA=0, sB=0, sC=0, gptr=None,
