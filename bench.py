@@ -492,16 +492,16 @@ def main():
                     continue
                 fresh = js.get('source_sha256') == src
                 for obj, tag in (('roofline', 'gemm_split' if args.gemm_mode == 1 else 'gemm_128x128'), ('roofline_aggregation', 'spmm_wide'),
-                                 ('roofline_split', 'gemm_split')):
+                                 ('roofline_split', 'gemm_split'), ('roofline_half', 'gemm_half')):
                     if obj not in out or tag not in js:
                         continue
                     if key == 'traffic':
                         if fresh:
-                            out[obj]['traffic'] = round(js[tag]['hbm_bytes_per_launch'])
+                            out[obj]['traffic'] = round(js[tag]['hbm_bytes_per_launch'] + (js.get('gemm_half_absmax', {}).get('hbm_bytes_per_launch', 0.0) if tag == 'gemm_half' else 0.0))
                             out[obj]['traffic_source'] = 'profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes/launch; same kernel source)' % fname
                         else:
                             out[obj]['traffic_stale'] = True
-                    elif tag in ('gemm_128x128', 'gemm_split') and js[tag].get('mfma_busy') is not None:
+                    elif tag in ('gemm_128x128', 'gemm_split', 'gemm_half') and js[tag].get('mfma_busy') is not None:
                         if fresh:
                             out[obj]['mfma_busy_counter'] = js[tag]['mfma_busy']
                             out[obj]['mfma_busy_source'] = ('profiles/%s: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE/8) of this '

@@ -27,10 +27,10 @@ REORDER_MIN_NODES = 4000    # graphs at least this large get their nodes listed 
 
 def default_gemm_mode():
     """An encoder's ``gemm_mode`` when nothing else sets it: ``CGC_GEMM_16BIT`` = ``0`` / ``exact`` (kernels.GEMM_EXACT), ``1`` / ``bf16``
-    (GEMM_SPLIT_BF16), ``2`` / ``f16`` (GEMM_SPLIT_F16); unset: the older switch ``CGC_GEMM_SPLIT_BF16`` (0 / 1 / 2), whose default is 1."""
+    (GEMM_SPLIT_BF16), ``2`` / ``f16`` (GEMM_SPLIT_F16); unset: the older switch ``CGC_GEMM_SPLIT_BF16`` (0 / 1 / 2); neither set: 2."""
     v = os.environ.get('CGC_GEMM_16BIT')
     if v is None:
-        v = os.environ.get('CGC_GEMM_SPLIT_BF16', '1')
+        v = os.environ.get('CGC_GEMM_SPLIT_BF16', '2')
     names = {'0': 0, 'exact': 0, 'off': 0, '1': 1, 'bf16': 1, '2': 2, 'f16': 2, 'fp16': 2}
     if v.lower() not in names:
         raise ValueError('CGC_GEMM_16BIT / CGC_GEMM_SPLIT_BF16 = %r: expected one of %s' % (v, sorted(names)))
@@ -341,12 +341,15 @@ class SoftPoolingGcnEncoder(nn.Module):
         self.native = os.environ.get('CGC_NATIVE', '1') != '0'
         self.native_head = os.environ.get('CGC_NATIVE_HEAD', '1') != '0'     # classification head + loss as one kernel each way
         self.reorder_large = os.environ.get('CGC_REORDER', '1') != '0'       # see _spatially_ordered
-        # 1 = kernels.GEMM_SPLIT_BF16 (the module's default since round 6): the products that take the 128 x 128 route -- from ~450
-        # output tiles up: the six dominant products of a step (assignment Linear, S^T(AS), their backward: model/network.py:121-122,
-        # 206-207) -- run as six bf16 MFMA pairs per fp32 product: same results to fp32 rounding (include/cgc_hip.h: cgc_gemm_f32_ws;
-        # tests/test_split_gemm_gpu.py has the bounds, the reference's fixtures run through it with every product forced onto that
-        # route), 1.3-1.4x faster on those products, the step 1.18x.  0 = kernels.GEMM_EXACT (CGC_GEMM_SPLIT_BF16=0): the fp32
-        # matrix-core chain for every product -- what bench.py's headline `value` is measured with.  Smaller products are exact either way.
+        # How the products on the 128 x 128 route -- from ~450 output tiles up: the six dominant products of a step (assignment Linear,
+        # S^T(AS), their backward: model/network.py:121-122, 206-207) -- are computed (include/cgc_hip.h: cgc_gemm_f32_ws):
+        #   2 = kernels.GEMM_SPLIT_F16 (the module's default): three fp16 MFMA pairs of operands scaled per output tile
+        #       (csrc/gemm_half.hip); those products 1.75x faster than exact, the step 1.37x;
+        #   1 = kernels.GEMM_SPLIT_BF16: six bf16 MFMA pairs (csrc/gemm_split.hip; no scaling, no range caveat); 1.4x / 1.2x;
+        #   0 = kernels.GEMM_EXACT: the fp32 matrix-core chain for every product -- what bench.py's headline `value` is measured with.
+        # All three give the reference's results to fp32 rounding (tests/test_split_gemm_gpu.py, tests/test_half_gemm_gpu.py have the
+        # bounds; the reference's fixtures run through each with every product forced onto that route).  Smaller products are exact
+        # in every mode.  CGC_GEMM_16BIT = 0 | bf16 | f16 chooses (default_gemm_mode above).
         self.gemm_mode = default_gemm_mode()
         self._unorder = None
 

@@ -61,5 +61,23 @@ for k, c in vals.items():
 if sc:
     out['gemm_split'] = {'mfma_busy': round(sb / sc, 4),
                          'definition': 'SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE / 8) over the launches of k_gemm_split<*> (bf16 matrix pipe)'}
+# the fp16 three-pair kernel (csrc/gemm_half.hip; a third file = the pass with mode CGC_GEMM_SPLIT_F16): the product kernel alone
+# (its operand-maximum pass k_gemm_absmax is a streaming kernel and is listed separately)
+hb = hc = 0.0
+for k, c in vals.items():
+    if not k.startswith('k_gemm_half<') or 'SQ_VALU_MFMA_BUSY_CYCLES' not in c or 'GRBM_GUI_ACTIVE' not in c:
+        continue
+    calls, busy = c['SQ_VALU_MFMA_BUSY_CYCLES']
+    cyc = c['GRBM_GUI_ACTIVE'][1] / 8.0
+    wave = c.get('SQ_WAVE_CYCLES', (0, 0.0))[1]
+    out[k] = {'launches_profiled': calls, 'mfma_busy': round(busy / (1024.0 * cyc), 4), 'kernel_cycles': round(cyc),
+              'wave_wait_any_frac': round(c.get('SQ_WAIT_ANY', (0, 0.0))[1] / wave, 4) if wave else None,
+              'wave_wait_inst_frac': round(c.get('SQ_WAIT_INST_ANY', (0, 0.0))[1] / wave, 4) if wave else None,
+              'lds_bank_conflict_cycles': c.get('SQ_LDS_BANK_CONFLICT', (0, 0.0))[1]}
+    hb += busy * calls
+    hc += 1024.0 * cyc * calls
+if hc:
+    out['gemm_half'] = {'mfma_busy': round(hb / hc, 4),
+                        'definition': 'SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE / 8) over the launches of k_gemm_half<*> (fp16 matrix pipe; the product kernel without its operand-maximum pass)'}
 out['source_sha256'] = source_hash()
 print(json.dumps(out, indent=1))

@@ -27,9 +27,14 @@ def main():
         f2, w2 = per_kernel(sys.argv[3], 'FETCH_SIZE'), per_kernel(sys.argv[4], 'WRITE_SIZE')
         f.update({k: v for k, v in f2.items() if k.startswith('k_gemm_split<')})
         w.update({k: v for k, v in w2.items() if k.startswith('k_gemm_split<')})
+    if len(sys.argv) > 6:          # (round 6: a third pair = mode CGC_GEMM_SPLIT_F16: the product kernel and its operand-maximum pass)
+        f3, w3 = per_kernel(sys.argv[5], 'FETCH_SIZE'), per_kernel(sys.argv[6], 'WRITE_SIZE')
+        f.update({k: v for k, v in f3.items() if k.startswith(('k_gemm_half<', 'k_gemm_absmax<'))})
+        w.update({k: v for k, v in w3.items() if k.startswith(('k_gemm_half<', 'k_gemm_absmax<'))})
     out = {}
     for tag, match, big_only in (('gemm_128x128', 'k_gemm_f32<2, 2, 2, 2', False), ('spmm_wide', 'k_spmm_wide<', True),
-                                 ('gemm_split', 'k_gemm_split<', False)):
+                                 ('gemm_split', 'k_gemm_split<', False), ('gemm_half', 'k_gemm_half<', False),
+                                 ('gemm_half_absmax', 'k_gemm_absmax<', False)):
         fs = [v for k in f if k.startswith(match) for v in f[k]]
         ws = [v for k in w if k.startswith(match) for v in w[k]]
         if big_only:      # the wide (cluster-count) launches are the ones moving > 100 MB

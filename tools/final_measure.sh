@@ -16,9 +16,10 @@ import json
 try:
     d = json.loads(open('gpurun_out/${tag}_$f.json').read().strip().splitlines()[-1])
     r, a = d.get('roofline', {}), d.get('roofline_aggregation', {})
-    print('%-18s %9.1f graphs/s %8.3f ms/step  gemm frac %s  K4 frac %s  cpu %s   split mode: %s graphs/s %s ms/step (six products %s ms, bf16 pipe %s)' % (
+    print('%-18s %9.1f graphs/s %8.3f ms/step  gemm frac %s  K4 frac %s  cpu %s   split mode: %s graphs/s %s ms/step (six products %s ms, bf16 pipe %s)   half mode: %s graphs/s %s ms/step (six products %s ms, fp16 pipe %s)' % (
         '$f', d['value'], d['ms_per_step'], r.get('frac'), a.get('frac'), d.get('cpu_baseline', {}).get('value'), d.get('value_split'),
-        d.get('ms_per_step_split'), d.get('roofline_split', {}).get('ms_per_step'), d.get('roofline_split', {}).get('frac')))
+        d.get('ms_per_step_split'), d.get('roofline_split', {}).get('ms_per_step'), d.get('roofline_split', {}).get('frac'),
+        d.get('value_half'), d.get('ms_per_step_half'), d.get('roofline_half', {}).get('ms_per_step'), d.get('roofline_half', {}).get('frac')))
 except Exception as e:
     print('$f', 'failed', e)
 PY
