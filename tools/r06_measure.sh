@@ -50,5 +50,13 @@ python tools/operand_range.py 32 > gpurun_out/r06_operand_range.txt 2>&1
 python bench.py --no-cpu-baseline --spatial > gpurun_out/r06_spatial.json 2>/dev/null
 cp gpurun_out/r06_counters.json gpurun_out/r06_traffic.json profiles/      # (on the box: the line below then quotes this run's own counter summaries)
 python bench.py > gpurun_out/r06_default_last.json 2> gpurun_out/r06_default_last.err      # (after the counter passes: nothing else is meant to differ)
+# timing-only ablations (variant libraries built beforehand by tools/ablate_presplit.sh / tools/variant_lib.sh; skipped when absent)
+V=$R/cgc-net_amd/csrc/variants
+if [ -f $V/libcgc_abl_valu.so ]; then
+  (for v in "" abl_valu abl_valu_lds ""; do if [ -z "$v" ]; then unset CGC_LIB; echo "== k_gemm_split as built"; else export CGC_LIB=$V/libcgc_$v.so; echo "== $v"; fi; SPLIT_BENCH_MODES=1 python tools/split_gemm_bench.py 20 2>&1 | grep -v amdgpu.ids | tail -7 | cut -c1-150; done; unset CGC_LIB) > gpurun_out/r06_split_gemm_presplit_ablation.txt 2>&1
+fi
+if [ -f $V/libcgc_h_none.so ]; then
+  (for v in "" h_nosplit h_nowrite h_nofrag h_noload h_nobar h_none ""; do if [ -z "$v" ]; then unset CGC_LIB; echo "== k_gemm_half as built"; else export CGC_LIB=$V/libcgc_$v.so; echo "== $v"; fi; SPLIT_BENCH_MODES=2 SPLIT_BENCH_CASES=1,4 python tools/split_gemm_bench.py 20 2>&1 | grep -v amdgpu.ids | tail -3 | cut -c1-150; done; unset CGC_LIB) > gpurun_out/r06_half_gemm_ablation.txt 2>&1
+fi
 ls gpurun_out | grep r06_ | head -100
 cat gpurun_out/r06_configurations_raw.txt | tail -12
