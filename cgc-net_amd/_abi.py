@@ -30,6 +30,7 @@ PROTOTYPES = {
     'cgc_gemm_split_count': [],
     'cgc_gemm_half_count': [],
     'cgc_gemm_half_ws_floats': [],
+    'cgc_gemm_half_min_work': [L],
     'cgc_gemm_f32_ws': [I, I, I, I, I, F, P, I, P, I, F, P, I, P, I, L, L, L, P, I, I, P, L, I, P],
     'cgc_gemm_f32_cat_ws': [I, I, I, I, I, F, P, I, P, I, F, P, I, P, I, L, L, L, P, I, I, I, P, P, P, P, P, P, P, P, L, I, P],
     'cgc_gemm_tuning': [I],
@@ -105,4 +106,4 @@ def declare(lib):
         if name == 'cgc_timing_create':
             fn.restype = P          # a handle, not a status
             continue
-        fn.restype = C.c_int64 if name.endswith(('_ws_ints', '_ws_floats', '_offset', '_grad_floats', '_saved_floats', '_scratch_floats', '_split_count', '_half_count')) else C.c_int
+        fn.restype = C.c_int64 if name.endswith(('_ws_ints', '_ws_floats', '_offset', '_grad_floats', '_saved_floats', '_scratch_floats', '_split_count', '_half_count', '_min_work')) else C.c_int

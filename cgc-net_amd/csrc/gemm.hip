@@ -765,8 +765,8 @@ static int gemm_dispatch(GemmArgs& a, int transA, int transB, int batch, int max
   const bool want_split = eff_mode == CGC_GEMM_SPLIT_BF16, want_half = eff_mode == CGC_GEMM_SPLIT_F16;
   auto big_route = [&](bool shortk, float* w) -> int {
     if ((want_split || want_half) && !shortk && !(transA && transB) && gemm_all_fast(a, transA, transB, batch, m_extent, k_extent)) {
-      const int rc = want_half ? gemm_half_launch(a, transA, transB, batch, m_extent, k_extent, w, ws_floats, stream)
-                               : gemm_split_launch(a, transA, transB, batch, m_extent, k_extent, w, ws_floats, stream);
+      int rc = want_half ? gemm_half_launch(a, transA, transB, batch, m_extent, k_extent, w, ws_floats, stream) : CGC_EINVAL;
+      if (rc == CGC_EINVAL) rc = gemm_split_launch(a, transA, transB, batch, m_extent, k_extent, w, ws_floats, stream);   // (mode F16: products too small for its maximum pass to pay)
       if (rc != CGC_EINVAL) return rc;
     }
     return launch_cfg<2, 2, 2, 2>(a, transA, transB, batch, m_extent, k_extent, shortk, w, ws_floats, stream);

@@ -423,13 +423,20 @@ __global__ __launch_bounds__(256) void k_gemm_absmax(const GemmArgs a, unsigned*
 static const int kHalfResident = 256;
 
 static int64_t g_half_launches = 0;
+// tile x k-tile steps below which gemm_half_launch declines (tuning hook, tests: 0 = never decline)
+static int64_t g_half_min_work = getenv("CGC_HALF_MIN_WORK") ? atoll(getenv("CGC_HALF_MIN_WORK")) : 28000;
+extern "C" int64_t cgc_gemm_half_min_work(int64_t v) {
+  const int64_t old = __atomic_load_n(&g_half_min_work, __ATOMIC_RELAXED);
+  if (v >= 0) __atomic_store_n(&g_half_min_work, v, __ATOMIC_RELAXED);
+  return old;
+}
 extern "C" int64_t cgc_gemm_half_count(void) { return __atomic_load_n(&g_half_launches, __ATOMIC_RELAXED); }
 int64_t gemm_half_scale_floats() { return H_SCALE_FLOATS; }
 extern "C" int64_t cgc_gemm_half_ws_floats(void) { return H_SCALE_FLOATS; }
 
 // Launch for a product that qualifies (gemm.hip: gemm_dispatch decided: 128 x 128 route, every operand segment fit for unguarded
-// 16-byte loads).  CGC_EINVAL: no workspace for the scales / more batch items than slots / a shape outside what the kernel indexes --
-// the caller then runs the exact kernel.
+// 16-byte loads).  CGC_EINVAL: no workspace for the scales / more panels than slots / a shape outside what the kernel indexes / a
+// product too small for the mode to pay -- the caller then tries the bf16 kernel and, failing that, the exact one.
 int gemm_half_launch(const GemmArgs& a0, int transA, int transB, int batch, int m_extent, int k_extent, float* ws, int64_t ws_floats,
                      hipStream_t stream) {
   if (transA && transB) return CGC_EINVAL;
@@ -444,6 +451,16 @@ int gemm_half_launch(const GemmArgs& a0, int transA, int transB, int batch, int 
   const int ta = ceil_div(m_extent, S_BM);
   const long long slots = (long long)batch * (ta + a.tiles_n);
   if (slots > H_SCALE_FLOATS) return CGC_EINVAL;
+  // The mode pays once the product kernel's saving (~30 % of the bf16 kernel's time) exceeds its own fixed cost (the slot fill, the
+  // maximum pass: two launches and one more trip over the operands).  Measured on the step's six products at 32 / 16 / 8 / 4 graphs
+  // (profiles/r06_configurations.txt): ahead of the bf16 mode by 18 / 17 / 10 % down to 8 graphs (37-47 k tile x k-tile steps per
+  // product), behind it by 6 % at 4 (19-23 k) and at C1 = 180 (5 k).  Below 28 k steps the caller runs the bf16 kernel instead.
+  const long long min_work = __atomic_load_n(&g_half_min_work, __ATOMIC_RELAXED);
+  {
+    long long kt = ceil_div(k_extent, SBK);
+    for (int i = 0; i < a.nx; ++i) kt += ceil_div(a.xK[i], SBK);
+    if (tiles * kt < min_work) return CGC_EINVAL;
+  }
   a.per_batch = (int)per_batch;
   a.nb = batch;
   a.ws = nullptr;

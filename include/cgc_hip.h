@@ -44,7 +44,7 @@ typedef void* cgc_stream_t; /* hipStream_t */
  *      than -100 makes the loss NaN instead of being ignored)
  *   4: round 6 (removed: cgc_adj_prep_fwd2, cgc_adj_grad_operands, cgc_zero_diag and cgc_level_desc.flags bit 0 -- the thin-operand
  *      adjacency gradient; a descriptor with bit 0 set is refused.  Added: cgc_graph_build_local, cgc_graph_local_max_nodes)
- *   5: round 6 (mode CGC_GEMM_SPLIT_F16 of cgc_gemm_f32_ws / cgc_gemm_f32_cat_ws; cgc_level_desc.flags bit 2; cgc_gemm_half_count, cgc_gemm_half_ws_floats;
+ *   5: round 6 (mode CGC_GEMM_SPLIT_F16 of cgc_gemm_f32_ws / cgc_gemm_f32_cat_ws; cgc_level_desc.flags bit 2; cgc_gemm_half_count, cgc_gemm_half_ws_floats, cgc_gemm_half_min_work;
  *      cgc_gemm_ws_floats() grew by the mode's scale slots: workspaces sized by an older library are too small for the tail split) */
 #define CGC_ABI_VERSION 5
 int cgc_abi_version(void);
@@ -208,13 +208,19 @@ int cgc_gemm_f32_cat(int transA, int transB, int M, int N, int K, float alpha, c
  * float64 within 1.25 x the exact kernel's -- measured 0.55-1.0 x -- while an element is within 2^17 of its panel's largest; below
  * that the element's ABSOLUTE error stops shrinking at 2^-40 of the panel's maximum (bound and measurements:
  * tests/test_half_gemm_gpu.py, tools/operand_range.py for the step's own operands).  Inputs must be finite (an infinite element
- * makes the tiles of its panel NaN).  1.25 x faster than CGC_GEMM_SPLIT_BF16 on the step's six products, operand pass included. */
+ * makes the tiles of its panel NaN).  1.25 x faster than CGC_GEMM_SPLIT_BF16 on the step's six products, operand pass included; products
+ * too small for that (cgc_gemm_half_min_work) run as CGC_GEMM_SPLIT_BF16. */
 #define CGC_GEMM_EXACT 0
 #define CGC_GEMM_SPLIT_BF16 1
 #define CGC_GEMM_SPLIT_F16 2
 int64_t cgc_gemm_split_count(void);   /* products this process has sent to the split kernel so far (diagnostic: did the mode apply?) */
 int64_t cgc_gemm_half_count(void);    /* ... and to the fp16 kernel of mode CGC_GEMM_SPLIT_F16 */
 int64_t cgc_gemm_half_ws_floats(void); /* the part of cgc_gemm_ws_floats() that mode CGC_GEMM_SPLIT_F16 needs by itself (scale slots, at the end) */
+/* Mode CGC_GEMM_SPLIT_F16 declines products of fewer than this many (256 x 128 output tile) x (16-wide k-tile) steps -- its maximum pass
+ * would cost more than the kernel saves -- and they run in mode CGC_GEMM_SPLIT_BF16 instead (default 28000: the six products of a step
+ * from 8 graphs of ~1800 nodes up).  Sets the threshold (v >= 0) and returns the previous one; v < 0 only reads.  Tuning hook like
+ * cgc_gemm_tuning: process-wide, not meant to be changed while products are in flight. */
+int64_t cgc_gemm_half_min_work(int64_t v);
 int64_t cgc_gemm_ws_floats(void);
 int cgc_gemm_f32_ws(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
                     const float* B, int ldb, float beta, float* C, int ldc, const float* bias, int batch,

@@ -34,7 +34,7 @@ def gemm_mode(request, monkeypatch):
     monkeypatch.setenv('CGC_GEMM_16BIT', {'exact': '0', 'split': '1', 'half': '2'}[request.param])
     K = kernels.get()
     count = lambda: int(K.lib.cgc_gemm_split_count()) + int(K.lib.cgc_gemm_half_count())
-    before = count()
+    before, before_half = count(), int(K.lib.cgc_gemm_half_count())
 
     class Mode(object):
         name = request.param
@@ -43,17 +43,34 @@ def gemm_mode(request, monkeypatch):
         @staticmethod
         def launches():
             return count() - before
+
+        @staticmethod
+        def half_launches():
+            return int(K.lib.cgc_gemm_half_count()) - before_half
+
+        @staticmethod
+        def check_applied(least):
+            """the mode's kernels took at least ``least`` products (none in the exact mode); mode 'half': the fp16 kernel itself did --
+            a product of these sizes is above the threshold below which it hands over to the bf16 kernel"""
+            assert (count() - before >= least) == split, (request.param, count() - before)
+            if request.param == 'half':
+                assert int(K.lib.cgc_gemm_half_count()) - before_half >= least, (int(K.lib.cgc_gemm_half_count()) - before_half, least)
     yield Mode
     K.gemm_mode = kernels.GEMM_EXACT
 
 
 @pytest.fixture
 def forced_big_route():
-    """Every product of the test takes the 128 x 128 pipelined route (cgc_gemm_tuning(11)) -- the route CGC_GEMM_SPLIT_BF16 applies to --
+    """Every product of the test takes the 128 x 128 pipelined route (cgc_gemm_tuning(11)) -- the route the 16-bit GEMM modes apply to --
     at sizes a test can afford (automatically it is taken from ~450 output tiles up: none of the reference-generated fixtures gets
-    there by itself)."""
+    there by itself), and mode CGC_GEMM_SPLIT_F16 takes every product however small (cgc_gemm_half_min_work(0): by itself it hands
+    products below ~28 k tile x k-tile steps to the bf16 kernel)."""
+    import ctypes
+
     import cgc_net_amd.kernels as kernels
     K = kernels.get()
     old = K.lib.cgc_gemm_tuning(11)
+    old_work = K.lib.cgc_gemm_half_min_work(ctypes.c_int64(0))
     yield
     K.lib.cgc_gemm_tuning(old)
+    K.lib.cgc_gemm_half_min_work(ctypes.c_int64(old_work))

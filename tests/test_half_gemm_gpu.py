@@ -307,3 +307,29 @@ def test_half_mode_leaves_other_routes_exact():
             assert int(k.lib.cgc_gemm_half_count()) == before
             outs.append(out)
         assert torch.equal(outs[0], outs[1])
+
+
+def test_half_mode_hands_small_products_to_the_bf16_kernel():
+    """Below cgc_gemm_half_min_work tile x k-tile steps the mode's maximum pass costs more than its kernel saves: such a product runs
+    in mode CGC_GEMM_SPLIT_BF16 (same route, no scaling); at or above it, on the fp16 kernel."""
+    import ctypes
+    k = hip()
+    M, N, K = 2600, 1140, 1140              # 11 x 9 tiles x 72 k-tiles = 7128 steps
+    A, B = gen((M, K), 1, 'normal'), gen((K, N), 2, 'normal', -1)
+    want, mag = A.double() @ B.double(), A.double().abs() @ B.double().abs()
+    old = k.lib.cgc_gemm_half_min_work(ctypes.c_int64(-1))
+    try:
+        for thr, to_half in ((7129, False), (7128, True)):
+            assert k.lib.cgc_gemm_half_min_work(ctypes.c_int64(thr)) >= 0
+            h0, s0 = int(k.lib.cgc_gemm_half_count()), int(k.lib.cgc_gemm_split_count())
+            out = torch.empty(M, N, device=DEV)
+            k.gemm_mode = HALF
+            try:
+                k.gemm(A, B, out, M, N, K, False, False, K, N, N)
+            finally:
+                k.gemm_mode = EXACT
+            torch.cuda.synchronize()
+            assert (int(k.lib.cgc_gemm_half_count()) - h0, int(k.lib.cgc_gemm_split_count()) - s0) == ((1, 0) if to_half else (0, 1))
+            assert float(((out.double() - want).abs() / mag).max()) < 5e-7
+    finally:
+        k.lib.cgc_gemm_half_min_work(ctypes.c_int64(old))

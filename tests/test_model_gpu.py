@@ -104,7 +104,7 @@ def test_golden_forward_backward_on_the_big_route(name, gemm_mode, forced_big_ro
     csrc/gemm_split.hip) -- the kernels that carry 60 % of the benchmarked step and that no fixture reaches by itself (their products
     are far below the ~450-tile route).  Same bars as the default routing."""
     _golden_forward_backward(name)
-    assert (gemm_mode.launches() > 0) == gemm_mode.is_split, (gemm_mode.name, gemm_mode.launches())
+    gemm_mode.check_applied(1)
 
 
 @pytest.mark.parametrize('name', CASES)
@@ -114,7 +114,7 @@ def test_golden_gradients_within_1e4_of_the_reference_in_fp64_on_the_big_route(n
     (profiles/r06_gradients_vs_reference_fp64_split.txt has the per-case margins)."""
     import discrete
     discrete.compare_with_reference_fp64(name)
-    assert (gemm_mode.launches() > 0) == gemm_mode.is_split, (gemm_mode.name, gemm_mode.launches())
+    gemm_mode.check_applied(1)
 
 
 @pytest.mark.parametrize('name', CASES)
