@@ -333,3 +333,72 @@ def test_half_mode_hands_small_products_to_the_bf16_kernel():
             assert float(((out.double() - want).abs() / mag).max()) < 5e-7
     finally:
         k.lib.cgc_gemm_half_min_work(ctypes.c_int64(old))
+
+
+@pytest.mark.parametrize('M,N,K,tA,tB', [(300, 140, 5, False, False), (129, 257, 1, False, True), (513, 131, 17, True, False)])
+def test_half_gemm_reductions_shorter_than_the_pipeline(M, N, K, tA, tB):
+    """K = 1, 5, 17: fewer k-tiles than the pipeline is deep (one or two, the last one partial), odd extents in both output directions.
+    With so few terms nothing averages the representation error and the exact kernel's own error is a rounding or two, so the yardstick
+    here is the mode's worst case, not the exact kernel: |s x - h - l| <= 2^-23 |s x| per operand element and the dropped pair
+    l l <= 2^-22 |a||b| give 8 U of sum |a||b|, + the accumulation allowance of test_half_gemm_error_bound_with_range.  (By itself the
+    dispatcher sends no product with K <= 160 to this kernel; the forced route of this file does.)"""
+    k = hip()
+    up4 = lambda v: (v + 3) // 4 * 4
+    lda, ldb = up4(M if tA else K), up4(K if tB else N)
+    A, B = gen((K, lda) if tA else (M, lda), 1, 'normal'), gen((N, ldb) if tB else (K, ldb), 2, 'normal')
+    a = (A[:, :M].t() if tA else A[:, :K]).double()
+    b = (B[:, :K].t() if tB else B[:, :N]).double()
+    want, mag = a @ b, a.abs() @ b.abs()
+
+    def run():
+        out = torch.full((M, N), float('nan'), device=DEV)
+        k.gemm(A, B, out, M, N, K, tA, tB, lda, ldb, N)
+        return out
+    res = both_modes(run, want, mag, MODES)
+    bound = (8 + 2 * 3 * (-(-K // 16)) + 4) * U
+    print('short K %s: exact max %.2e rms %.2e | half max %.2e rms %.2e | worst case %.2e' % ((M, N, K, tA, tB), res[EXACT][0], res[EXACT][1],
+                                                                                               res[HALF][0], res[HALF][1], bound))
+    assert res[HALF][0] <= bound and res[HALF][1] <= 0.25 * bound, (res, bound)
+
+
+def test_half_gemm_non_finite_input_stays_in_its_panels():
+    """The mode's domain is finite inputs; what an infinite element does is stated in the header and held here: the output tiles that
+    multiply its panel (256 rows of op(A)) are not finite, every other row of the product is as accurate as without it."""
+    k = hip()
+    M, N, K = 1100, 300, 400
+    A, B = gen((M, K), 1, 'normal'), gen((K, N), 2, 'normal', -1)
+    A[300, 7] = float('inf')                   # row 300: panel 1 (rows 256 .. 511)
+    out = torch.empty(M, N, device=DEV)
+    k.gemm_mode = HALF
+    try:
+        k.gemm(A, B, out, M, N, K, False, False, K, N, N)
+    finally:
+        k.gemm_mode = EXACT
+    torch.cuda.synchronize()
+    rows = torch.ones(M, dtype=torch.bool, device=DEV)
+    rows[256:512] = False
+    assert not bool(torch.isfinite(out[300]).all())
+    assert bool(torch.isfinite(out[rows]).all())
+    want, mag = A[rows].double() @ B.double(), A[rows].double().abs() @ B.double().abs()
+    assert float(((out[rows].double() - want).abs() / mag).max()) < 5e-7
+
+
+def test_half_mode_without_a_workspace_runs_the_exact_kernel():
+    """cgc_gemm_f32_ws with ws = NULL in mode CGC_GEMM_SPLIT_F16: no room for the scale slots -- the product runs on another kernel
+    (the bf16 one needs no workspace) instead of failing; the plain entry point cgc_gemm_f32 is always exact."""
+    import ctypes
+    k = hip()
+    M, N, K = 700, 300, 400
+    A, B = gen((M, K), 1, 'normal'), gen((K, N), 2, 'normal', -1)
+    want, mag = A.double() @ B.double(), A.double().abs() @ B.double().abs()
+    out = torch.empty(M, N, device=DEV)
+    h0 = int(k.lib.cgc_gemm_half_count())
+    rc = k.lib.cgc_gemm_f32_ws(0, 0, M, N, K, ctypes.c_float(1.0), A.data_ptr(), K, B.data_ptr(), N, ctypes.c_float(0.0), out.data_ptr(), N, None, 1,
+                               ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0), None, 0, 0, None, ctypes.c_int64(0), int(HALF),
+                               ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert rc == 0 and int(k.lib.cgc_gemm_half_count()) == h0
+    assert float(((out.double() - want).abs() / mag).max()) < 5e-7
+    assert k.lib.cgc_gemm_f32_ws(0, 0, M, N, K, ctypes.c_float(1.0), A.data_ptr(), K, B.data_ptr(), N, ctypes.c_float(0.0), out.data_ptr(), N, None, 1,
+                                 ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0), None, 0, 0, None, ctypes.c_int64(0), 3,
+                                 ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)) != 0          # an unknown mode is refused
